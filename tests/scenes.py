@@ -1,0 +1,44 @@
+"""Seeded synthetic inputs shared by the parity tests (SURVEY.md section 8d recipes, scaled)."""
+import math
+
+import torch
+
+
+def look_at_viewmat(eye, target=(0.0, 0.0, 0.0), up=(0.0, 1.0, 0.0)):
+    """World->camera [3,4] with +z forward (the convention gsplat's viewmat expects)."""
+    eye = torch.tensor(eye, dtype=torch.float32)
+    fwd = torch.tensor(target, dtype=torch.float32) - eye
+    fwd = fwd / fwd.norm()
+    upv = torch.tensor(up, dtype=torch.float32)
+    right = torch.linalg.cross(upv, fwd)
+    right = right / right.norm()
+    down = torch.linalg.cross(fwd, right)
+    R = torch.stack([right, down, fwd], 0)
+    return torch.cat([R, (-R @ eye)[:, None]], 1).contiguous()
+
+
+def head_scene(N, H, W, seed=1234, cam_angle=0.3, focal=None, radii=(90.0, 120.0, 100.0),
+               scale_range=(0.3, 3.0), cam_dist=700.0, max_opacity=1.0):
+    """Gaussians uniform in an ellipsoid (mm), ring camera looking at the origin."""
+    g = torch.Generator().manual_seed(seed)
+    d = torch.randn(N, 3, generator=g)
+    d = d / d.norm(dim=-1, keepdim=True)
+    r = torch.rand(N, 1, generator=g) ** (1.0 / 3.0)
+    means = d * r * torch.tensor(radii)
+    quats = torch.randn(N, 4, generator=g)
+    quats = quats / quats.norm(dim=-1, keepdim=True)
+    lo, hi = math.log(scale_range[0]), math.log(scale_range[1])
+    scales = torch.exp(lo + (hi - lo) * torch.rand(N, 3, generator=g))
+    opacity = torch.sigmoid(1.5 * torch.randn(N, 1, generator=g)) * max_opacity
+    colors = torch.rand(N, 3, generator=g)
+    if focal is None:
+        focal = 3000.0 * W / 1334.0
+    eye = (cam_dist * math.sin(cam_angle), 0.0, -cam_dist * math.cos(cam_angle))
+    viewmat = look_at_viewmat(eye)
+    return dict(means=means, scales=scales, quats=quats, opacity=opacity, colors=colors,
+                viewmat=viewmat, fx=focal, fy=focal, cx=W / 2.0, cy=H / 2.0, H=H, W=W)
+
+
+def rel_l2(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).norm() / b.norm().clamp_min(1e-30))
