@@ -1,0 +1,88 @@
+"""ctypes binding of libgoliath_hip.so (C ABI: include/goliath_hip.h).
+
+PyTorch is only plumbing here: tensors provide device memory (`data_ptr()`) and the current HIP
+stream.  There is NO CPU fallback: if the HIP library is missing or a tensor is not on the GPU the
+call raises, loudly.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libgoliath_hip.so")
+
+_lib = None
+
+_SYMBOLS = [
+    "gol_version", "gol_last_error", "gol_sg_eval_fwd", "gol_sg_eval_bwd", "gol_project_fwd",
+    "gol_project_bwd", "gol_bin_sort", "gol_rasterize_fwd", "gol_rasterize_bwd",
+]
+
+
+class GoliathHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the shared library (build it with `python -m goliath_amd.build`)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise GoliathHipError(
+                f"{LIB_PATH} not found: the HIP extension is not built. Run "
+                "`python -m goliath_amd.build` (or __graft_entry__.build()). There is no CPU fallback."
+            )
+        lib = ctypes.CDLL(LIB_PATH)
+        lib.gol_version.restype = ctypes.c_char_p
+        lib.gol_last_error.restype = ctypes.c_char_p
+        for name in _SYMBOLS:
+            getattr(lib, name)  # AttributeError if the ABI and the build disagree
+        _lib = lib
+    return _lib
+
+
+def exported_symbols():
+    return list(_SYMBOLS)
+
+
+def version():
+    return load().gol_version().decode()
+
+
+def ptr(t, dtype=None, name="tensor"):
+    """Device pointer of a contiguous CUDA(HIP) tensor; None -> NULL.  Mirrors the reference's
+    CHECK_INPUT (extensions/sgutils/utils.h:1-5): RuntimeError for non-GPU / non-contiguous."""
+    if t is None:
+        return ctypes.c_void_p(0)
+    if not t.is_cuda:
+        raise GoliathHipError(f"{name} must be a CUDA tensor")
+    if not t.is_contiguous():
+        raise GoliathHipError(f"{name} must be contiguous")
+    if dtype is not None and t.dtype != dtype:
+        raise GoliathHipError(f"{name} must have dtype {dtype}, got {t.dtype}")
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def fptr(t, name="tensor"):
+    return ptr(t, torch.float32, name)
+
+
+def iptr(t, name="tensor"):
+    return ptr(t, torch.int32, name)
+
+
+def stream_ptr():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def call(fn_name, *args):
+    lib = load()
+    rc = getattr(lib, fn_name)(*args)
+    if rc != 0:
+        raise GoliathHipError(f"{fn_name} failed ({rc}): {lib.gol_last_error().decode()}")
+
+
+c_int = ctypes.c_int
+c_float = ctypes.c_float
+c_i64 = ctypes.c_int64

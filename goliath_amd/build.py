@@ -1,0 +1,78 @@
+"""Build libgoliath_hip.so (the C-ABI library of include/goliath_hip.h) for gfx950 with hipcc.
+
+In-tree build: goliath_amd/csrc/*.hip -> goliath_amd/csrc/_obj/*.o -> goliath_amd/lib/libgoliath_hip.so
+so the shared object travels with the source tree (no JIT cache).  hipcc cross-compiles without
+a GPU.  Usage:  python -m goliath_amd.build [--force] [--verbose]
+"""
+import concurrent.futures
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(CSRC, "_obj")
+LIBDIR = os.path.join(HERE, "lib")
+LIB = os.path.join(LIBDIR, "libgoliath_hip.so")
+
+HIPCC = os.environ.get("HIPCC") or shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+FLAGS = [
+    "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics",
+    "-ffp-contract=fast", "-Wall", "-Wno-unused-function",
+]
+
+
+def _sources():
+    return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip"))
+
+
+def _headers():
+    hs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    hs.append(os.path.join(os.path.dirname(HERE), "include", "goliath_hip.h"))
+    return hs
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def _compile(src, verbose):
+    obj = os.path.join(OBJ, os.path.basename(src)[:-4] + ".o")
+    cmd = [HIPCC, *FLAGS, "-c", src, "-o", obj]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"hipcc failed on {src}:\n{r.stdout}\n{r.stderr}")
+    if verbose and r.stderr.strip():
+        print(r.stderr)
+    return obj
+
+
+def build(force=False, verbose=False):
+    """Compile every HIP source for gfx950 and link the C-ABI shared library.  Returns its path."""
+    os.makedirs(OBJ, exist_ok=True)
+    os.makedirs(LIBDIR, exist_ok=True)
+    srcs, hdrs = _sources(), _headers()
+    todo = [s for s in srcs
+            if force or _stale(os.path.join(OBJ, os.path.basename(s)[:-4] + ".o"), [s, *hdrs])]
+    if todo:
+        with concurrent.futures.ThreadPoolExecutor(max_workers=min(8, len(todo))) as ex:
+            list(ex.map(lambda s: _compile(s, verbose), todo))
+    objs = [os.path.join(OBJ, os.path.basename(s)[:-4] + ".o") for s in srcs]
+    if force or todo or _stale(LIB, objs):
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", LIB]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose="--verbose" in sys.argv or "-v" in sys.argv))

@@ -1,0 +1,359 @@
+// raster.hip -- tile rasterizer of depth-sorted 2-D Gaussians, forward + backward, gfx950.
+//
+// Replaces gsplat 0.1.11 rasterize_forward / rasterize_backward_kernel (3-channel specialisation;
+// not in the reference tree; call sites /root/reference/ca_code/utils/render_gsplat.py:65-78 and
+// :91-104; semantics SURVEY.md A.3 / A.4).  CDNA4 design:
+//   * one 256-thread workgroup per 16x16 tile = 4 wave64s, each wave owns an 8x8 pixel quadrant
+//     (compact footprint -> coherent early-out and coherent culling);
+//   * the tile's sorted list is staged through LDS in batches of 256 Gaussians as three float4
+//     records; the per-Gaussian reads in the pixel loop are wave-uniform ds_read_b128 broadcasts;
+//   * at staging time every Gaussian gets a 4-bit quadrant mask from the bounding box of its
+//     alpha >= 1/255 ellipse, so a wave skips (scalar branch) Gaussians that cannot touch its
+//     quadrant -- gsplat's 3-sigma tile bbox is far looser than the 1/255 cut;
+//   * colour and the optional 4th "extra" channel (depth) are composited in ONE pass instead of
+//     the reference's two rasterize calls (render_gsplat.py:65-104);
+//   * backward: per-Gaussian gradients are reduced over the 64 lanes with DPP row/bcast adds (no
+//     LDS), merged across the 4 waves with ds_add_f32 into a per-batch LDS accumulator, and leave
+//     the workgroup as ONE global atomic per Gaussian per tile per component (gsplat: one per
+//     32-lane warp => 8x more).
+//   * tile -> workgroup mapping is XCD-chunked (blockIdx % 8 selects an eighth of the image) so a
+//     die's L2 sees a spatially compact slice of the Gaussian attribute arrays.
+#include "gol_common.h"
+
+namespace {
+
+constexpr int kBatch = 256;
+
+struct TileCoord { int tile, tx, ty; bool ok; };
+
+// XCD-aware remap: consecutive workgroups land on different XCDs (observed b % 8), so give XCD x
+// the x-th contiguous chunk of row-major tiles.  Speed only -- any mapping is correct.
+__device__ __forceinline__ TileCoord tile_of_block(int bid, int T, int tiles_x) {
+  const int chunk = (T + 7) >> 3;
+  const int tile = (bid & 7) * chunk + (bid >> 3);
+  TileCoord tc;
+  tc.tile = tile;
+  tc.ok = (bid >> 3) < chunk && tile < T;
+  tc.ty = tile / tiles_x;
+  tc.tx = tile - tc.ty * tiles_x;
+  return tc;
+}
+
+// 4-bit mask of the 8x8 quadrants (bit q = qy*2+qx) that the alpha >= 1/255 region of a
+// Gaussian can reach.  Conservative (axis-aligned box of the ellipse sigma <= ln(255*opacity),
+// with margin); degenerate conics fall back to "all quadrants".
+__device__ __forceinline__ int quadrant_mask(float gx, float gy, float ca, float cb, float cc, float op,
+                                             float tile_x0, float tile_y0) {
+  const float k = 255.f * op;
+  if (!(k > 1.f)) return 0;  // alpha < 1/255 everywhere (also catches NaN opacity -> skipped by gsplat too)
+  const float det = ca * cc - cb * cb;
+  if (!(det > 0.f) || !(ca > 0.f) || !(cc > 0.f)) return 0xf;
+  const float tau2 = 2.f * (__logf(k) * 1.001f + 1e-3f);
+  const float hx = sqrtf(tau2 * cc / det) + 0.02f, hy = sqrtf(tau2 * ca / det) + 0.02f;
+  if (!(hx < 1e30f) || !(hy < 1e30f)) return 0xf;
+  int m = 0;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const float x0 = tile_x0 + (float)((q & 1) * 8) + 0.5f, y0 = tile_y0 + (float)((q >> 1) * 8) + 0.5f;
+    const bool hit = (gx + hx >= x0) && (gx - hx <= x0 + 7.f) && (gy + hy >= y0) && (gy - hy <= y0 + 7.f);
+    m |= hit ? (1 << q) : 0;
+  }
+  return m;
+}
+
+template <bool EXTRA>
+__global__ __launch_bounds__(256) void raster_fwd_kernel(
+    int N, int img_h, int img_w, int tiles_x, int tiles_y, const int2* __restrict__ tile_bins,
+    const int32_t* __restrict__ sorted_ids, int64_t capacity, const float* __restrict__ xys,
+    const float* __restrict__ conics, const float* __restrict__ colors, const float* __restrict__ extra,
+    const float* __restrict__ opacities, const float* __restrict__ background, float* __restrict__ out_img,
+    float* __restrict__ out_extra, float* __restrict__ final_Ts, int32_t* __restrict__ final_idx) {
+  __shared__ float4 s_a[kBatch];  // x, y, conic.a, conic.b
+  __shared__ float4 s_b[kBatch];  // conic.c, opacity, r, g
+  __shared__ float4 s_c[kBatch];  // b, extra, quadrant mask (int bits), -
+  const int T = tiles_x * tiles_y;
+  const TileCoord tc = tile_of_block(blockIdx.x, T, tiles_x);
+  if (!tc.ok) return;
+  const int view = blockIdx.y;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lx = ((wave & 1) << 3) + (lane & 7), ly = ((wave >> 1) << 3) + (lane >> 3);
+  const int j = tc.tx * 16 + lx, i = tc.ty * 16 + ly;
+  const bool inside = (i < img_h) && (j < img_w);
+  const float px = (float)j + 0.5f, py = (float)i + 0.5f;
+
+  const int2 range = tile_bins[(size_t)view * T + tc.tile];
+  const int32_t* ids = sorted_ids + (size_t)view * capacity;
+  const size_t goff = (size_t)view * N;
+
+  float T_cur = 1.f;
+  int cur_idx = 0;
+  float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
+  bool done = !inside;
+
+  const int n_batches = (range.y - range.x + kBatch - 1) / kBatch;
+  for (int bb = 0; bb < n_batches; ++bb) {
+    if (__syncthreads_and(done)) break;  // also protects the LDS batch from being overwritten early
+    const int batch_start = range.x + bb * kBatch;
+    const int idx = batch_start + tid;
+    if (idx < range.y) {
+      const size_t g = goff + (size_t)ids[idx];
+      const float2 xy = *reinterpret_cast<const float2*>(xys + 2 * g);
+      const float ca = conics[3 * g], cb = conics[3 * g + 1], cc = conics[3 * g + 2];
+      const float op = opacities[g];
+      const float r = colors[3 * g], gg = colors[3 * g + 1], bl = colors[3 * g + 2];
+      const float ex = EXTRA ? extra[g] : 0.f;
+      const int qm = quadrant_mask(xy.x, xy.y, ca, cb, cc, op, (float)(tc.tx * 16), (float)(tc.ty * 16));
+      s_a[tid] = make_float4(xy.x, xy.y, ca, cb);
+      s_b[tid] = make_float4(cc, op, r, gg);
+      s_c[tid] = make_float4(bl, ex, __int_as_float(qm), 0.f);
+    }
+    __syncthreads();
+    const int batch_size = min(kBatch, range.y - batch_start);
+    for (int t = 0; t < batch_size; ++t) {
+      if (__ballot(!done) == 0ull) break;  // this wave's quadrant is finished
+      const float4 c4 = s_c[t];
+      const int qm = __builtin_amdgcn_readfirstlane(__float_as_int(c4.z));
+      if (!((qm >> wave) & 1)) continue;  // wave-uniform cull
+      const float4 a4 = s_a[t];
+      const float4 b4 = s_b[t];
+      if (!done) {
+        const float dx = a4.x - px, dy = a4.y - py;
+        const float sigma = 0.5f * (a4.z * dx * dx + b4.x * dy * dy) + a4.w * dx * dy;
+        const float alpha = fminf(GOL_ALPHA_CAP_FWD, b4.y * __expf(-sigma));
+        if (!(sigma < 0.f || alpha < GOL_ALPHA_FLOOR)) {
+          const float next_T = T_cur * (1.f - alpha);
+          if (next_T <= GOL_T_STOP) {
+            done = true;
+          } else {
+            const float vis = alpha * T_cur;
+            acc0 += b4.z * vis; acc1 += b4.w * vis; acc2 += c4.x * vis;
+            if (EXTRA) acc3 += c4.y * vis;
+            T_cur = next_T;
+            cur_idx = batch_start + t;
+          }
+        }
+      }
+    }
+  }
+
+  if (inside) {
+    const size_t p = ((size_t)view * img_h + i) * img_w + j;
+    final_Ts[p] = T_cur;
+    final_idx[p] = cur_idx;
+    out_img[3 * p] = acc0 + T_cur * background[0];
+    out_img[3 * p + 1] = acc1 + T_cur * background[1];
+    out_img[3 * p + 2] = acc2 + T_cur * background[2];
+    if (EXTRA) out_extra[p] = acc3;
+  }
+}
+
+constexpr int kAcc = 10;  // r g b extra Sx Sy Sxx Sxy Syy v_opacity
+
+template <bool EXTRA>
+__global__ __launch_bounds__(256) void raster_bwd_kernel(
+    int N, int img_h, int img_w, int tiles_x, int tiles_y, const int2* __restrict__ tile_bins,
+    const int32_t* __restrict__ sorted_ids, int64_t capacity, const float* __restrict__ xys,
+    const float* __restrict__ conics, const float* __restrict__ colors, const float* __restrict__ extra,
+    const float* __restrict__ opacities, const float* __restrict__ background,
+    const float* __restrict__ final_Ts, const int32_t* __restrict__ final_idx,
+    const float* __restrict__ v_out_img, const float* __restrict__ v_out_extra,
+    const float* __restrict__ v_out_alpha, float* __restrict__ v_xy, float* __restrict__ v_conic,
+    float* __restrict__ v_colors, float* __restrict__ v_extra, float* __restrict__ v_opacity) {
+  __shared__ float4 s_a[kBatch];
+  __shared__ float4 s_b[kBatch];
+  __shared__ float4 s_c[kBatch];
+  __shared__ int32_t s_id[kBatch];
+  __shared__ float s_acc[kBatch * kAcc];
+  __shared__ int32_t s_touched[kBatch];
+  __shared__ int32_t s_wmax[4];
+  const int T = tiles_x * tiles_y;
+  const TileCoord tc = tile_of_block(blockIdx.x, T, tiles_x);
+  if (!tc.ok) return;
+  const int view = blockIdx.y;
+  const int2 range = tile_bins[(size_t)view * T + tc.tile];
+  if (range.y <= range.x) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lx = ((wave & 1) << 3) + (lane & 7), ly = ((wave >> 1) << 3) + (lane >> 3);
+  const int j = tc.tx * 16 + lx, i = tc.ty * 16 + ly;
+  const bool inside = (i < img_h) && (j < img_w);
+  const float px = (float)j + 0.5f, py = (float)i + 0.5f;
+  const size_t p = inside ? ((size_t)view * img_h + i) * img_w + j : 0;
+  const int32_t* ids = sorted_ids + (size_t)view * capacity;
+  const size_t goff = (size_t)view * N;
+
+  const float T_final = inside ? final_Ts[p] : 1.f;
+  float T_cur = T_final;
+  // pixels outside the image never contribute; bin_final = range.x - 1 makes every entry "behind" them
+  const int bin_final = inside ? final_idx[p] : (range.x - 1);
+  float vo0 = 0.f, vo1 = 0.f, vo2 = 0.f, vo3 = 0.f, voa = 0.f;
+  if (inside) {
+    vo0 = v_out_img[3 * p]; vo1 = v_out_img[3 * p + 1]; vo2 = v_out_img[3 * p + 2];
+    if (EXTRA && v_out_extra) vo3 = v_out_extra[p];
+    if (v_out_alpha) voa = v_out_alpha[p];
+  }
+  const float bgdot = background[0] * vo0 + background[1] * vo1 + background[2] * vo2;
+  float buf0 = 0.f, buf1 = 0.f, buf2 = 0.f, buf3 = 0.f;
+
+  // wave / workgroup maxima of bin_final bound the part of the list that matters
+  int wmax = bin_final;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) wmax = max(wmax, __shfl_xor(wmax, off, 64));
+  if (lane == 0) s_wmax[wave] = wmax;
+  __syncthreads();
+  const int bmax = min(max(max(s_wmax[0], s_wmax[1]), max(s_wmax[2], s_wmax[3])), range.y - 1);
+  if (bmax < range.x) return;
+
+  const int n_batches = (bmax - range.x + kBatch) / kBatch;
+  for (int bb = 0; bb < n_batches; ++bb) {
+    __syncthreads();  // previous batch fully consumed
+    const int batch_end = bmax - bb * kBatch;           // list index of slot 0 (furthest back)
+    const int batch_size = min(kBatch, batch_end + 1 - range.x);
+    const int idx = batch_end - tid;
+    if (tid < batch_size) {
+      const int gid = ids[idx];
+      const size_t g = goff + (size_t)gid;
+      const float2 xy = *reinterpret_cast<const float2*>(xys + 2 * g);
+      const float ca = conics[3 * g], cb = conics[3 * g + 1], cc = conics[3 * g + 2];
+      const float op = opacities[g];
+      const float r = colors[3 * g], gg = colors[3 * g + 1], bl = colors[3 * g + 2];
+      const float ex = EXTRA ? extra[g] : 0.f;
+      const int qm = quadrant_mask(xy.x, xy.y, ca, cb, cc, op, (float)(tc.tx * 16), (float)(tc.ty * 16));
+      s_a[tid] = make_float4(xy.x, xy.y, ca, cb);
+      s_b[tid] = make_float4(cc, op, r, gg);
+      s_c[tid] = make_float4(bl, ex, __int_as_float(qm), 0.f);
+      s_id[tid] = gid;
+    }
+#pragma unroll
+    for (int k = 0; k < kAcc; ++k) s_acc[tid * kAcc + k] = 0.f;
+    s_touched[tid] = 0;
+    __syncthreads();
+
+    const int t0 = max(0, batch_end - wmax);  // entries behind every pixel of this wave are skipped
+    for (int t = t0; t < batch_size; ++t) {
+      const float4 c4 = s_c[t];
+      const int qm = __builtin_amdgcn_readfirstlane(__float_as_int(c4.z));
+      if (!((qm >> wave) & 1)) continue;
+      const float4 a4 = s_a[t];
+      const float4 b4 = s_b[t];
+      bool valid = (batch_end - t) <= bin_final;
+      const float dx = a4.x - px, dy = a4.y - py;
+      const float sigma = 0.5f * (a4.z * dx * dx + b4.x * dy * dy) + a4.w * dx * dy;
+      const float vis = __expf(-sigma);
+      const float alpha = fminf(GOL_ALPHA_CAP_BWD, b4.y * vis);
+      valid = valid && !(sigma < 0.f || alpha < GOL_ALPHA_FLOOR);
+      if (__ballot(valid) == 0ull) continue;
+      float g0 = 0.f, g1 = 0.f, g2 = 0.f, g3 = 0.f, sx = 0.f, sy = 0.f, sxx = 0.f, sxy = 0.f, syy = 0.f, gop = 0.f;
+      if (valid) {
+        const float ra = __builtin_amdgcn_rcpf(1.f - alpha);
+        T_cur *= ra;
+        const float fac = alpha * T_cur;
+        g0 = fac * vo0; g1 = fac * vo1; g2 = fac * vo2;
+        float v_alpha = (b4.z * T_cur - buf0 * ra) * vo0 + (b4.w * T_cur - buf1 * ra) * vo1 +
+                        (c4.x * T_cur - buf2 * ra) * vo2;
+        if (EXTRA) {
+          g3 = fac * vo3;
+          v_alpha += (c4.y * T_cur - buf3 * ra) * vo3;
+          buf3 += c4.y * fac;
+        }
+        v_alpha += T_final * ra * (voa - bgdot);
+        buf0 += b4.z * fac; buf1 += b4.w * fac; buf2 += c4.x * fac;
+        const float v_sigma = -b4.y * vis * v_alpha;
+        sx = v_sigma * dx; sy = v_sigma * dy;
+        sxx = sx * dx; sxy = sx * dy; syy = sy * dy;
+        gop = vis * v_alpha;
+      }
+      g0 = gol_wave_sum_to_lane63(g0); g1 = gol_wave_sum_to_lane63(g1); g2 = gol_wave_sum_to_lane63(g2);
+      if (EXTRA) g3 = gol_wave_sum_to_lane63(g3);
+      sx = gol_wave_sum_to_lane63(sx); sy = gol_wave_sum_to_lane63(sy);
+      sxx = gol_wave_sum_to_lane63(sxx); sxy = gol_wave_sum_to_lane63(sxy); syy = gol_wave_sum_to_lane63(syy);
+      gop = gol_wave_sum_to_lane63(gop);
+      if (lane == 63) {
+        float* a = s_acc + t * kAcc;
+        atomicAdd(a + 0, g0); atomicAdd(a + 1, g1); atomicAdd(a + 2, g2);
+        if (EXTRA) atomicAdd(a + 3, g3);
+        atomicAdd(a + 4, sx); atomicAdd(a + 5, sy); atomicAdd(a + 6, sxx); atomicAdd(a + 7, sxy);
+        atomicAdd(a + 8, syy); atomicAdd(a + 9, gop);
+        s_touched[t] = 1;
+      }
+    }
+    __syncthreads();
+    if (tid < batch_size && s_touched[tid]) {
+      const size_t g = goff + (size_t)s_id[tid];
+      const float* a = s_acc + tid * kAcc;
+      const float4 a4 = s_a[tid];
+      const float cc = s_b[tid].x;
+      atomicAdd(v_colors + 3 * g, a[0]); atomicAdd(v_colors + 3 * g + 1, a[1]); atomicAdd(v_colors + 3 * g + 2, a[2]);
+      if (EXTRA && v_extra) atomicAdd(v_extra + g, a[3]);
+      atomicAdd(v_xy + 2 * g, a4.z * a[4] + a4.w * a[5]);
+      atomicAdd(v_xy + 2 * g + 1, a4.w * a[4] + cc * a[5]);
+      atomicAdd(v_conic + 3 * g, 0.5f * a[6]); atomicAdd(v_conic + 3 * g + 1, a[7]); atomicAdd(v_conic + 3 * g + 2, 0.5f * a[8]);
+      atomicAdd(v_opacity + g, a[9]);
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int gol_rasterize_fwd(int B, int N, int img_h, int img_w, int block, const int32_t* tile_bins,
+                                 const int32_t* sorted_ids, int64_t capacity, const float* xys,
+                                 const float* conics, const float* colors, const float* extra,
+                                 const float* opacities, const float* background, float* out_img,
+                                 float* out_extra, float* final_Ts, int32_t* final_idx, void* stream) {
+  GOL_REQUIRE(B >= 0 && N >= 0, "negative size");
+  GOL_REQUIRE(block == 16, "only block_width == 16 is implemented (the reference's value, render_gsplat.py:28)");
+  GOL_REQUIRE(img_h > 0 && img_w > 0, "empty image");
+  if (B == 0) return GOL_OK;
+  GOL_REQUIRE(B <= 65535, "B > 65535");
+  GOL_REQUIRE(tile_bins && background && out_img && final_Ts && final_idx, "null pointer");
+  GOL_REQUIRE(capacity == 0 || sorted_ids, "null sorted_ids");
+  GOL_REQUIRE(N == 0 || (xys && conics && colors && opacities), "null Gaussian attribute");
+  GOL_REQUIRE((extra == nullptr) == (out_extra == nullptr), "extra and out_extra go together");
+  const int tiles_x = (img_w + 15) / 16, tiles_y = (img_h + 15) / 16, T = tiles_x * tiles_y;
+  dim3 grid(8 * ((T + 7) / 8), B);
+  const int2* bins = reinterpret_cast<const int2*>(tile_bins);
+  hipStream_t s = (hipStream_t)stream;
+  if (extra)
+    raster_fwd_kernel<true><<<grid, 256, 0, s>>>(N, img_h, img_w, tiles_x, tiles_y, bins, sorted_ids, capacity, xys,
+                                                  conics, colors, extra, opacities, background, out_img, out_extra,
+                                                  final_Ts, final_idx);
+  else
+    raster_fwd_kernel<false><<<grid, 256, 0, s>>>(N, img_h, img_w, tiles_x, tiles_y, bins, sorted_ids, capacity, xys,
+                                                   conics, colors, extra, opacities, background, out_img, out_extra,
+                                                   final_Ts, final_idx);
+  GOL_CHECK_LAUNCH();
+  return GOL_OK;
+}
+
+extern "C" int gol_rasterize_bwd(int B, int N, int img_h, int img_w, int block, const int32_t* tile_bins,
+                                 const int32_t* sorted_ids, int64_t capacity, const float* xys,
+                                 const float* conics, const float* colors, const float* extra,
+                                 const float* opacities, const float* background, const float* final_Ts,
+                                 const int32_t* final_idx, const float* v_out_img, const float* v_out_extra,
+                                 const float* v_out_alpha, float* v_xy, float* v_conic, float* v_colors,
+                                 float* v_extra, float* v_opacity, void* stream) {
+  GOL_REQUIRE(B >= 0 && N >= 0, "negative size");
+  GOL_REQUIRE(block == 16, "only block_width == 16 is implemented (the reference's value, render_gsplat.py:28)");
+  GOL_REQUIRE(img_h > 0 && img_w > 0, "empty image");
+  if (B == 0 || N == 0 || capacity == 0) return GOL_OK;
+  GOL_REQUIRE(B <= 65535, "B > 65535");
+  GOL_REQUIRE(tile_bins && sorted_ids && background && final_Ts && final_idx && v_out_img, "null pointer");
+  GOL_REQUIRE(xys && conics && colors && opacities, "null Gaussian attribute");
+  GOL_REQUIRE(v_xy && v_conic && v_colors && v_opacity, "null gradient output");
+  GOL_REQUIRE(!(v_out_extra || v_extra) || extra, "extra-channel gradients need extra");
+  const int tiles_x = (img_w + 15) / 16, tiles_y = (img_h + 15) / 16, T = tiles_x * tiles_y;
+  dim3 grid(8 * ((T + 7) / 8), B);
+  const int2* bins = reinterpret_cast<const int2*>(tile_bins);
+  hipStream_t s = (hipStream_t)stream;
+  if (extra && (v_out_extra || v_extra))
+    raster_bwd_kernel<true><<<grid, 256, 0, s>>>(N, img_h, img_w, tiles_x, tiles_y, bins, sorted_ids, capacity, xys,
+                                                  conics, colors, extra, opacities, background, final_Ts, final_idx,
+                                                  v_out_img, v_out_extra, v_out_alpha, v_xy, v_conic, v_colors,
+                                                  v_extra, v_opacity);
+  else
+    raster_bwd_kernel<false><<<grid, 256, 0, s>>>(N, img_h, img_w, tiles_x, tiles_y, bins, sorted_ids, capacity, xys,
+                                                   conics, colors, nullptr, opacities, background, final_Ts,
+                                                   final_idx, v_out_img, nullptr, v_out_alpha, v_xy, v_conic,
+                                                   v_colors, nullptr, v_opacity);
+  GOL_CHECK_LAUNCH();
+  return GOL_OK;
+}

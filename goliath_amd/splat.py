@@ -1,0 +1,389 @@
+"""Differentiable Gaussian-splat render path (host side) on top of the C ABI.
+
+Three layers, all backed by libgoliath_hip.so (no CPU fallback):
+
+  project_gaussians / rasterize_gaussians   gsplat-0.1.11-compatible operators, the signatures
+        the reference calls at ca_code/utils/render_gsplat.py:49-63 and :65-104.
+  render_views(...)                         the fused, batched, host-sync-free path: all B views
+        of a batch in ONE launch sequence (project+count -> scan -> scatter -> per-tile sort ->
+        colour+depth raster), replacing the Python view loop and its 4 `.item()` syncs per view
+        (ca_code/models/rgca.py:119-138) and gsplat's `cum_tiles_hit[-1].item()`.
+
+Host/device contract: Gaussian attributes are fp32 [B,N,.] tensors resident in HBM; intrinsics and
+view matrices are read by the kernels from device memory.
+"""
+import os
+
+import torch
+
+from . import _lib
+from ._lib import c_float, c_i64, c_int, fptr, iptr, ptr, stream_ptr
+
+BLOCK = 16  # tile width; the reference's only value (render_gsplat.py:28)
+
+
+def _tiles(img_h, img_w, block=BLOCK):
+    return ((img_w + block - 1) // block) * ((img_h + block - 1) // block)
+
+
+# --------------------------------------------------------------------------------------------
+# Intersection-capacity planning (replaces the host sync on the intersection count).
+# --------------------------------------------------------------------------------------------
+class CapacityPlanner:
+    """Per-shape capacity (max Gaussian/tile intersections per view) for the sync-free path.
+
+    First call for a shape: one blocking calibration (reads the true count, sizes the buffers
+    with 50 % head-room).  Later calls: no sync; the true counts are copied to pinned host memory
+    asynchronously and inspected at the NEXT call -- an overflow then raises (the affected render
+    dropped intersections) after growing the capacity so a re-run succeeds.
+    Set GOLIATH_STRICT_CAPACITY=1 to verify every call synchronously.
+    """
+
+    def __init__(self):
+        self.capacity = {}
+        self.pending = []  # (event, pinned counts, capacity, key)
+
+    def strict(self):
+        return os.environ.get("GOLIATH_STRICT_CAPACITY", "0") == "1"
+
+    def get(self, key, N):
+        return self.capacity.get(key)
+
+    def initial(self, N, T):
+        return int(min(2**31 - 1, max(1 << 16, 16 * N + T)))
+
+    def set(self, key, counts_max):
+        self.capacity[key] = int(min(2**31 - 1, max(1 << 16, int(counts_max * 1.5) + 4096)))
+        return self.capacity[key]
+
+    def note(self, key, n_isect, capacity):
+        host = torch.empty(n_isect.shape, dtype=torch.int32, pin_memory=True)
+        host.copy_(n_isect, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self.pending.append((ev, host, capacity, key))
+
+    def poll(self, block=False):
+        still = []
+        for ev, host, capacity, key in self.pending:
+            if block:
+                ev.synchronize()
+            if ev.query():
+                worst = int(host.max()) if host.numel() else 0
+                if worst > capacity:
+                    self.set(key, worst)
+                    raise _lib.GoliathHipError(
+                        f"a previous render_views call overflowed its intersection capacity "
+                        f"({worst} > {capacity}); its image is incomplete. Capacity was raised to "
+                        f"{self.capacity[key]} -- re-run the step (or set GOLIATH_STRICT_CAPACITY=1).")
+                if worst * 1.25 > capacity:  # grow early, before it overflows
+                    self.set(key, worst)
+            else:
+                still.append((ev, host, capacity, key))
+        self.pending = still
+
+
+PLANNER = CapacityPlanner()
+
+
+class _Workspace:
+    """Scratch + intermediate buffers of one forward call (kept alive by the autograd node)."""
+
+    def __init__(self, B, N, T, capacity, device):
+        self.capacity = capacity
+        self.tile_count = torch.zeros(B, T, dtype=torch.int32, device=device)
+        self.tile_bins = torch.empty(B, T, 2, dtype=torch.int32, device=device)
+        self.keys = torch.empty(B, max(capacity, 1), dtype=torch.int64, device=device)
+        self.sorted_ids = torch.empty(B, max(capacity, 1), dtype=torch.int32, device=device)
+        self.n_isect = torch.empty(B, dtype=torch.int32, device=device)
+
+
+def _bin_sort(B, N, xys, depths, radii, img_h, img_w, ws, count_done):
+    _lib.call("gol_bin_sort", c_int(B), c_int(N), fptr(xys), fptr(depths), iptr(radii), c_int(img_h),
+              c_int(img_w), c_int(BLOCK), c_i64(ws.capacity), iptr(ws.tile_count), c_int(1 if count_done else 0),
+              iptr(ws.tile_bins), ptr(ws.keys, torch.int64), iptr(ws.sorted_ids), iptr(ws.n_isect),
+              stream_ptr())
+
+
+def _project_fwd(B, N, means, scales, glob_scale, quats, viewmats, intrins, img_h, img_w, clip,
+                 opacities=None, tile_count=None):
+    dev = means.device
+    f = dict(dtype=torch.float32, device=dev)
+    cov3d = torch.empty(B, N, 6, **f)
+    xys = torch.empty(B, N, 2, **f)
+    depths = torch.empty(B, N, **f)
+    radii = torch.empty(B, N, dtype=torch.int32, device=dev)
+    conics = torch.empty(B, N, 3, **f)
+    comp = torch.empty(B, N, **f)
+    nth = torch.empty(B, N, dtype=torch.int32, device=dev)
+    opac_eff = torch.empty(B, N, **f) if opacities is not None else None
+    _lib.call("gol_project_fwd", c_int(B), c_int(N), fptr(means, "means3d"), fptr(scales, "scales"),
+              c_float(glob_scale), fptr(quats, "quats"), fptr(viewmats, "viewmat"), fptr(intrins, "intrins"),
+              c_int(img_h), c_int(img_w), c_int(BLOCK), c_float(clip), fptr(cov3d), fptr(xys), fptr(depths),
+              iptr(radii), fptr(conics), fptr(comp), iptr(nth), fptr(opacities, "opacity"), fptr(opac_eff),
+              iptr(tile_count), stream_ptr())
+    return cov3d, xys, depths, radii, conics, comp, nth, opac_eff
+
+
+def _f32c(t):
+    return t.to(torch.float32).contiguous()
+
+
+# --------------------------------------------------------------------------------------------
+# gsplat-0.1.11-compatible operators
+# --------------------------------------------------------------------------------------------
+class _ProjectGaussians(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, means3d, scales, glob_scale, quats, viewmat, fx, fy, cx, cy, img_height, img_width,
+                block_width, clip_thresh):
+        if block_width != BLOCK:
+            raise NotImplementedError("goliath_amd implements block_width=16 (the reference's value)")
+        N = means3d.shape[0]
+        dev = means3d.device
+        means3d, scales, quats = _f32c(means3d), _f32c(scales), _f32c(quats)
+        vm = _f32c(viewmat).reshape(-1)[:12].contiguous().view(1, 12)
+        intr = torch.tensor([[fx, fy, cx, cy]], dtype=torch.float32).to(dev, non_blocking=True)
+        with torch.cuda.device(dev):
+            cov3d, xys, depths, radii, conics, comp, nth, _ = _project_fwd(
+                1, N, means3d, scales, float(glob_scale), quats, vm, intr, img_height, img_width,
+                float(clip_thresh))
+        ctx.save_for_backward(means3d, scales, quats, vm, intr, cov3d[0], radii[0], conics[0], comp[0])
+        ctx.glob_scale = float(glob_scale)
+        ctx.set_materialize_grads(False)
+        outs = (xys[0], depths[0], radii[0], conics[0], comp[0], nth[0], cov3d[0])
+        ctx.mark_non_differentiable(outs[2], outs[5])
+        return outs
+
+    @staticmethod
+    def backward(ctx, v_xys, v_depths, v_radii, v_conics, v_compensation, v_num_tiles_hit, v_cov3d):
+        means3d, scales, quats, vm, intr, cov3d, radii, conics, comp = ctx.saved_tensors
+        N = means3d.shape[0]
+        v_mean = torch.empty_like(means3d)
+        v_scale = torch.empty_like(scales)
+        v_quat = torch.empty_like(quats)
+        c = lambda t: None if t is None else _f32c(t)
+        with torch.cuda.device(means3d.device):
+            _lib.call("gol_project_bwd", c_int(1), c_int(N), fptr(means3d), fptr(scales), c_float(ctx.glob_scale),
+                      fptr(quats), fptr(vm), fptr(intr), fptr(cov3d), iptr(radii), fptr(conics), fptr(comp),
+                      fptr(c(v_xys)), fptr(c(v_depths)), fptr(c(v_conics)), fptr(c(v_compensation)),
+                      fptr(None), fptr(None), fptr(v_mean), fptr(v_scale), fptr(v_quat), fptr(None), stream_ptr())
+        return (v_mean, v_scale, None, v_quat) + (None,) * 9
+
+
+
+def project_gaussians(means3d, scales, glob_scale, quats, viewmat, fx, fy, cx, cy, img_height, img_width,
+                      block_width, clip_thresh=0.01):
+    """gsplat.project_gaussians (0.1.11): returns (xys, depths, radii, conics, compensation,
+    num_tiles_hit, cov3d); gradients flow to means3d, scales, quats."""
+    if means3d.dim() != 2 or means3d.shape[1] != 3:
+        raise ValueError("means3d must have dimensions (N, 3)")
+    return _ProjectGaussians.apply(means3d, scales, glob_scale, quats, viewmat, fx, fy, cx, cy, img_height,
+                                   img_width, block_width, clip_thresh)
+
+
+class _RasterizeGaussians(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, xys, depths, radii, conics, num_tiles_hit, colors, opacity, img_height, img_width,
+                block_width, background, return_alpha):
+        dev = xys.device
+        N = xys.shape[0]
+        xys, depths, conics, colors = _f32c(xys), _f32c(depths), _f32c(conics), _f32c(colors)
+        opacity = _f32c(opacity).reshape(-1)
+        radii = radii.to(torch.int32).contiguous()
+        background = _f32c(background)
+        # gsplat semantics: host sync on the intersection count (rasterize.py)
+        n_isect = int(num_tiles_hit.to(torch.int64).sum().item()) if N > 0 else 0
+        ctx.n_isect = n_isect
+        ctx.dims = (img_height, img_width)
+        if n_isect < 1:
+            # background-only image and final_T = 0 (alpha = 1)
+            out_img = torch.ones(img_height, img_width, 3, device=dev) * background
+            final_Ts = torch.zeros(img_height, img_width, device=dev)
+            ctx.save_for_backward(xys, conics, colors, opacity, background)
+        else:
+            T = _tiles(img_height, img_width)
+            ws = _Workspace(1, N, T, n_isect, dev)
+            out_img = torch.empty(1, img_height, img_width, 3, device=dev)
+            final_Ts = torch.empty(1, img_height, img_width, device=dev)
+            final_idx = torch.empty(1, img_height, img_width, dtype=torch.int32, device=dev)
+            with torch.cuda.device(dev):
+                _bin_sort(1, N, xys, depths, radii, img_height, img_width, ws, count_done=False)
+                _lib.call("gol_rasterize_fwd", c_int(1), c_int(N), c_int(img_height), c_int(img_width),
+                          c_int(BLOCK), iptr(ws.tile_bins), iptr(ws.sorted_ids), c_i64(ws.capacity), fptr(xys),
+                          fptr(conics), fptr(colors), fptr(None), fptr(opacity), fptr(background),
+                          fptr(out_img), fptr(None), fptr(final_Ts), iptr(final_idx), stream_ptr())
+            ctx.ws = ws
+            ctx.save_for_backward(xys, conics, colors, opacity, background, final_Ts, final_idx)
+            out_img, final_Ts = out_img[0], final_Ts[0]
+        if return_alpha:
+            return out_img, 1 - final_Ts
+        return out_img
+
+    @staticmethod
+    def backward(ctx, v_out_img, v_out_alpha=None):
+        saved = ctx.saved_tensors
+        xys, conics, colors, opacity, background = saved[:5]
+        N = xys.shape[0]
+        v_xy = torch.zeros_like(xys)
+        v_conic = torch.zeros_like(conics)
+        v_colors = torch.zeros_like(colors)
+        v_opacity = torch.zeros(N, device=xys.device)
+        if ctx.n_isect >= 1 and v_out_img is not None:
+            final_Ts, final_idx = saved[5], saved[6]
+            H, W = ctx.dims
+            ws = ctx.ws
+            va = None if v_out_alpha is None else _f32c(v_out_alpha)
+            with torch.cuda.device(xys.device):
+                _lib.call("gol_rasterize_bwd", c_int(1), c_int(N), c_int(H), c_int(W), c_int(BLOCK),
+                          iptr(ws.tile_bins), iptr(ws.sorted_ids), c_i64(ws.capacity), fptr(xys), fptr(conics),
+                          fptr(colors), fptr(None), fptr(opacity), fptr(background), fptr(final_Ts),
+                          iptr(final_idx), fptr(_f32c(v_out_img)), fptr(None), fptr(va), fptr(v_xy),
+                          fptr(v_conic), fptr(v_colors), fptr(None), fptr(v_opacity), stream_ptr())
+        return (v_xy, None, None, v_conic, None, v_colors, v_opacity[:, None]) + (None,) * 5
+
+
+def rasterize_gaussians(xys, depths, radii, conics, num_tiles_hit, colors, opacity, img_height, img_width,
+                        block_width, background=None, return_alpha=False):
+    """gsplat.rasterize_gaussians (0.1.11).  Only the 3-channel specialisation exists here: the
+    reference never calls the N-D variant (render_gsplat.py:65-104 passes 3-channel colours)."""
+    assert block_width > 1 and block_width <= 16, "block_width must be between 2 and 16"
+    if block_width != BLOCK:
+        raise NotImplementedError("goliath_amd implements block_width=16 (the reference's value)")
+    if colors.dtype == torch.uint8:
+        colors = colors.float() / 255
+    if xys.ndimension() != 2 or xys.size(1) != 2:
+        raise ValueError("xys must have dimensions (N, 2)")
+    if colors.ndimension() != 2:
+        raise ValueError("colors must have dimensions (N, D)")
+    if colors.shape[-1] != 3:
+        raise NotImplementedError("only 3-channel colours are implemented (no N-D call site in the reference)")
+    if background is not None:
+        assert background.shape[0] == colors.shape[-1], "incorrect shape of background color tensor"
+    else:
+        background = torch.ones(colors.shape[-1], dtype=torch.float32, device=colors.device)
+    if opacity.ndimension() != 2 or opacity.shape[1] != 1:
+        opacity = opacity.reshape(-1, 1)
+    return _RasterizeGaussians.apply(xys.contiguous(), depths.contiguous(), radii.contiguous(),
+                                     conics.contiguous(), num_tiles_hit.contiguous(), colors.contiguous(),
+                                     opacity.contiguous(), img_height, img_width, block_width,
+                                     background.contiguous(), return_alpha)
+
+
+# --------------------------------------------------------------------------------------------
+# Fused, batched, sync-free path
+# --------------------------------------------------------------------------------------------
+class _RenderViews(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, means, scales, quats, opacity, colors, viewmats, intrins, background, img_h, img_w,
+                glob_scale, clip_thresh, with_depth, capacity):
+        B, N = means.shape[:2]
+        dev = means.device
+        T = _tiles(img_h, img_w)
+        ws = _Workspace(B, N, T, capacity, dev)
+        with torch.cuda.device(dev):
+            cov3d, xys, depths, radii, conics, comp, nth, opac_eff = _project_fwd(
+                B, N, means, scales, glob_scale, quats, viewmats, intrins, img_h, img_w, clip_thresh,
+                opacities=opacity, tile_count=ws.tile_count)
+            _bin_sort(B, N, xys, depths, radii, img_h, img_w, ws, count_done=True)
+            out_img = torch.empty(B, img_h, img_w, 3, device=dev)
+            out_depth = torch.empty(B, img_h, img_w, device=dev) if with_depth else None
+            final_Ts = torch.empty(B, img_h, img_w, device=dev)
+            final_idx = torch.empty(B, img_h, img_w, dtype=torch.int32, device=dev)
+            _lib.call("gol_rasterize_fwd", c_int(B), c_int(N), c_int(img_h), c_int(img_w), c_int(BLOCK),
+                      iptr(ws.tile_bins), iptr(ws.sorted_ids), c_i64(ws.capacity), fptr(xys), fptr(conics),
+                      fptr(colors), fptr(depths if with_depth else None), fptr(opac_eff), fptr(background),
+                      fptr(out_img), fptr(out_depth), fptr(final_Ts), iptr(final_idx), stream_ptr())
+        ctx.ws = ws
+        ctx.cfg = (img_h, img_w, glob_scale, with_depth)
+        ctx.save_for_backward(means, scales, quats, opacity, colors, viewmats, intrins, background, cov3d, xys,
+                              depths, radii, conics, comp, opac_eff, final_Ts, final_idx)
+        ctx.mark_non_differentiable(radii, ws.n_isect)
+        ctx.set_materialize_grads(False)
+        alpha = 1 - final_Ts
+        if with_depth:
+            return out_img, alpha, out_depth, radii, ws.n_isect
+        return out_img, alpha, None, radii, ws.n_isect
+
+    @staticmethod
+    def backward(ctx, v_img, v_alpha, v_depth, _v_radii, _v_n):
+        (means, scales, quats, opacity, colors, viewmats, intrins, background, cov3d, xys, depths, radii,
+         conics, comp, opac_eff, final_Ts, final_idx) = ctx.saved_tensors
+        img_h, img_w, glob_scale, with_depth = ctx.cfg
+        B, N = means.shape[:2]
+        dev = means.device
+        ws = ctx.ws
+        if v_img is None and v_alpha is None and v_depth is None:
+            return (None,) * 14
+        if v_img is None:
+            v_img = torch.zeros(B, img_h, img_w, 3, device=dev)
+        use_depth = with_depth and v_depth is not None
+        v_xy = torch.zeros(B, N, 2, device=dev)
+        v_conic = torch.zeros(B, N, 3, device=dev)
+        v_colors = torch.zeros(B, N, 3, device=dev)
+        v_opac_eff = torch.zeros(B, N, device=dev)
+        v_depths = torch.zeros(B, N, device=dev) if use_depth else None
+        v_mean = torch.empty_like(means)
+        v_scale = torch.empty_like(scales)
+        v_quat = torch.empty_like(quats)
+        v_opacity = torch.empty_like(opacity)
+        with torch.cuda.device(dev):
+            _lib.call("gol_rasterize_bwd", c_int(B), c_int(N), c_int(img_h), c_int(img_w), c_int(BLOCK),
+                      iptr(ws.tile_bins), iptr(ws.sorted_ids), c_i64(ws.capacity), fptr(xys), fptr(conics),
+                      fptr(colors), fptr(depths if use_depth else None), fptr(opac_eff), fptr(background),
+                      fptr(final_Ts), iptr(final_idx), fptr(_f32c(v_img)),
+                      fptr(_f32c(v_depth) if use_depth else None),
+                      fptr(None if v_alpha is None else _f32c(v_alpha)), fptr(v_xy), fptr(v_conic),
+                      fptr(v_colors), fptr(v_depths), fptr(v_opac_eff), stream_ptr())
+            _lib.call("gol_project_bwd", c_int(B), c_int(N), fptr(means), fptr(scales), c_float(glob_scale),
+                      fptr(quats), fptr(viewmats), fptr(intrins), fptr(cov3d), iptr(radii), fptr(conics),
+                      fptr(comp), fptr(v_xy), fptr(v_depths), fptr(v_conic), fptr(None), fptr(opacity),
+                      fptr(v_opac_eff), fptr(v_mean), fptr(v_scale), fptr(v_quat), fptr(v_opacity), stream_ptr())
+        return (v_mean, v_scale, v_quat, v_opacity, v_colors) + (None,) * 9
+
+
+def render_views(means, scales, quats, opacity, colors, viewmats, intrins, img_h, img_w,
+                 background=None, glob_scale=1.0, clip_thresh=0.1, with_depth=True, capacity=None):
+    """Render B views in one launch sequence.
+
+    means[B,N,3] scales[B,N,3] quats[B,N,4] opacity[B,N] or [B,N,1] colors[B,N,3]  (fp32, GPU)
+    viewmats[B,3,4] (or [B,12]; world->camera, row-major), intrins[B,4] = (fx, fy, cx, cy)
+    Returns dict(render[B,3,H,W], alpha[B,1,H,W] (= 1 - final_T), depth[B,1,H,W] (un-normalised,
+    like render_gsplat.py:105-106), radii[B,N] int32, n_isect[B] int32).
+    """
+    B, N = means.shape[:2]
+    dev = means.device
+    if not means.is_cuda:
+        raise _lib.GoliathHipError("render_views needs CUDA(HIP) tensors; there is no CPU path")
+    means, scales, quats, colors = _f32c(means), _f32c(scales), _f32c(quats), _f32c(colors)
+    opacity = _f32c(opacity).reshape(B, N)
+    viewmats = _f32c(viewmats).reshape(B, -1)[:, :12].contiguous()
+    intrins = _f32c(intrins).reshape(B, 4)
+    if background is None:
+        background = torch.zeros(3, device=dev)  # render_gsplat.py:38-39
+    background = _f32c(background)
+    T = _tiles(img_h, img_w)
+    key = (B, N, img_h, img_w, dev.index)
+    calibrate = False
+    if capacity is None:
+        PLANNER.poll()
+        capacity = PLANNER.get(key, N)
+        if capacity is None:
+            capacity, calibrate = PLANNER.initial(N, T), True
+    out = _RenderViews.apply(means, scales, quats, opacity, colors, viewmats, intrins, background, img_h,
+                             img_w, float(glob_scale), float(clip_thresh), bool(with_depth), int(capacity))
+    img, alpha, depth, radii, n_isect = out
+    if calibrate or PLANNER.strict():
+        worst = int(n_isect.max().item()) if B > 0 else 0  # one blocking read per new shape
+        if calibrate:
+            PLANNER.set(key, worst)
+        if worst > capacity:
+            new_cap = PLANNER.capacity.get(key) or PLANNER.set(key, worst)
+            return render_views(means, scales, quats, opacity, colors, viewmats, intrins, img_h, img_w,
+                                background, glob_scale, clip_thresh, with_depth, capacity=new_cap)
+    elif key in PLANNER.capacity:
+        PLANNER.note(key, n_isect, capacity)
+    res = {"render": img.permute(0, 3, 1, 2), "alpha": alpha[:, None], "final_T": (1 - alpha)[:, None],
+           "radii": radii, "n_isect": n_isect}
+    if with_depth:
+        res["depth"] = depth[:, None]
+    return res

@@ -1,0 +1,127 @@
+/*
+ * goliath_hip.h -- C ABI of libgoliath_hip.so, the MI355X (gfx950) implementation of the
+ * Relightable-Gaussian-Codec-Avatar render hot path of facebookresearch/goliath.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer to contiguous fp32 / int32 data unless it says "host";
+ *   - `stream` is a hipStream_t passed as void* (NULL = the legacy default stream);
+ *   - functions only enqueue work (no allocation, no host sync) and return GOL_OK or a negative
+ *     gol_status; outputs are caller-owned and pre-allocated, exactly like the reference's
+ *     pybind entry points (sg.cu:177-283, mvpraymarch.cpp:107-409, utils.cpp:46-137);
+ *   - "[B,N,3]" = row-major, B views (batch elements) x N Gaussians;
+ *   - re-entrant given distinct streams and distinct output/scratch buffers; no global state.
+ *
+ * Each entry cites the reference interface it replaces (paths relative to /root/reference,
+ * "gsplat:" = the third-party gsplat==0.1.11 the reference calls).
+ */
+#ifndef GOLIATH_HIP_H
+#define GOLIATH_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+  GOL_OK = 0,
+  GOL_ERR_INVALID_ARG = -1,   /* bad size / null pointer / unsupported option */
+  GOL_ERR_LAUNCH = -2,        /* hipGetLastError() != hipSuccess after a launch */
+  GOL_ERR_UNSUPPORTED = -3
+} gol_status;
+
+/* Library / build identification ("goliath_hip <ver> gfx950"). */
+const char* gol_version(void);
+/* Text of the last error on this thread (static storage). */
+const char* gol_last_error(void);
+
+/* ------------------------------------------------------------------------------------------
+ * sgutils -- spherical-Gaussian specular lobe evaluation.
+ * Replaces sgutilslib.evaluate_gaussian_fwd / _bwd (extensions/sgutils/sg.cu:177-226, 228-278;
+ * kernels sg.cu:27-76, 78-175), called from extensions/sgutils/sgutils.py:27-29, 50-62.
+ *   lobe_dirs[N,D,3] lobe_sigmas[N,D] light_values[N,L,3] light_pts[N,L,3] prim_pts[N,D,3]
+ *   n_lights[N] int32, w_type in {0,1,2,3}.
+ * fwd writes integral[N,D,3] (every element).  bwd writes grad_dirs[N,D,3], grad_sigmas[N,D]
+ * and, when grad_light_values != NULL, ACCUMULATES into grad_light_values[N,L,3] (caller zeroes).
+ * ---------------------------------------------------------------------------------------- */
+int gol_sg_eval_fwd(int N, int D, int L, const float* lobe_dirs, const float* lobe_sigmas,
+                    const float* light_values, const float* light_pts, const float* prim_pts,
+                    const int32_t* n_lights, float* integral, int w_type, void* stream);
+int gol_sg_eval_bwd(int N, int D, int L, const float* lobe_dirs, const float* lobe_sigmas,
+                    const float* light_values, const float* light_pts, const float* prim_pts,
+                    const int32_t* n_lights, const float* grad_integral, float* grad_dirs,
+                    float* grad_sigmas, float* grad_light_values, int w_type, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Gaussian projection (EWA).  Replaces gsplat: project_gaussians forward/backward
+ * (call site ca_code/utils/render_gsplat.py:49-63; semantics SURVEY.md A.1, A.5).
+ * Batched over B views: viewmats[B,12] (row-major 3x4 world->camera), intrins[B,4]=(fx,fy,cx,cy)
+ * live on the device so no host sync is needed to read K (cf. rgca.py:123-126 .item() x4).
+ * Outputs for culled Gaussians are zero (radii = num_tiles_hit = 0).
+ * Optional fused extras (pass NULL to skip):
+ *   opacities[B,N] -> opac_eff[B,N] = opacity * compensation   (render_gsplat.py:72)
+ *   tile_count[B,T] int32 (zeroed by caller) += 1 per covered tile (feeds gol_bin_*)
+ * ---------------------------------------------------------------------------------------- */
+int gol_project_fwd(int B, int N, const float* means3d, const float* scales, float glob_scale,
+                    const float* quats, const float* viewmats, const float* intrins, int img_h,
+                    int img_w, int block, float clip_thresh, float* cov3d, float* xys,
+                    float* depths, int32_t* radii, float* conics, float* compensation,
+                    int32_t* num_tiles_hit, const float* opacities, float* opac_eff,
+                    int32_t* tile_count, void* stream);
+/* v_* inputs may be NULL (treated as zero).  If opacities != NULL the op also differentiates
+ * opac_eff = opacity*compensation: v_opac_eff[B,N] in, v_opacity[B,N] out. */
+int gol_project_bwd(int B, int N, const float* means3d, const float* scales, float glob_scale,
+                    const float* quats, const float* viewmats, const float* intrins,
+                    const float* cov3d, const int32_t* radii, const float* conics,
+                    const float* compensation, const float* v_xy, const float* v_depth,
+                    const float* v_conic, const float* v_compensation, const float* opacities,
+                    const float* v_opac_eff, float* v_mean3d, float* v_scale, float* v_quat,
+                    float* v_opacity, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Tile binning + per-tile depth sort.  Replaces gsplat: cumsum + map_gaussian_to_intersects +
+ * torch.sort(int64) + get_tile_bin_edges without the host sync on the
+ * intersection count.  Order inside a tile: ascending (depth bits, gaussian id) -- a
+ * deterministic instance of gsplat's unspecified tie order.
+ *   capacity        max intersections stored per view
+ *   tile_count[B,T] int32 scratch.  count_done=0: zeroed and filled here; 1: already filled
+ *                   by gol_project_fwd
+ *   tile_bins[B,T,2] out: [start,end) into the view's segment of sorted_ids
+ *   isect_keys[B,capacity] uint64 scratch
+ *   sorted_ids[B,capacity] out: Gaussian ids, tile by tile, front to back
+ *   n_isect[B] out: true number of intersections (> capacity means overflow: the excess
+ *                   intersections were dropped and the render is incomplete)
+ * ---------------------------------------------------------------------------------------- */
+int gol_bin_sort(int B, int N, const float* xys, const float* depths, const int32_t* radii,
+                 int img_h, int img_w, int block, int64_t capacity, int32_t* tile_count,
+                 int count_done, int32_t* tile_bins, uint64_t* isect_keys, int32_t* sorted_ids,
+                 int32_t* n_isect, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Tile rasterizer.  Replaces gsplat: rasterize_forward / rasterize_backward, 3-channel
+ * specialisation (call sites render_gsplat.py:65-78, 91-104; semantics SURVEY.md A.3, A.4).
+ * One launch composites colours[B,N,3] and, when extra != NULL, a 4th channel extra[B,N]
+ * (the depth pass of render_gsplat.py:91-104 fused into the colour pass; its background is 0).
+ *   background[3]; out_img[B,H,W,3]; out_extra[B,H,W]; final_Ts[B,H,W]; final_idx[B,H,W] int32
+ *   (index into the view's sorted_ids segment of the last contributing Gaussian, 0 if none).
+ * bwd ACCUMULATES into v_xy[B,N,2] v_conic[B,N,3] v_colors[B,N,3] v_opacity[B,N]
+ * (and v_extra[B,N]) which the caller zeroes; v_out_alpha / v_out_extra may be NULL.
+ * ---------------------------------------------------------------------------------------- */
+int gol_rasterize_fwd(int B, int N, int img_h, int img_w, int block, const int32_t* tile_bins,
+                      const int32_t* sorted_ids, int64_t capacity, const float* xys,
+                      const float* conics, const float* colors, const float* extra,
+                      const float* opacities, const float* background, float* out_img,
+                      float* out_extra, float* final_Ts, int32_t* final_idx, void* stream);
+int gol_rasterize_bwd(int B, int N, int img_h, int img_w, int block, const int32_t* tile_bins,
+                      const int32_t* sorted_ids, int64_t capacity, const float* xys,
+                      const float* conics, const float* colors, const float* extra,
+                      const float* opacities, const float* background, const float* final_Ts,
+                      const int32_t* final_idx, const float* v_out_img, const float* v_out_extra,
+                      const float* v_out_alpha, float* v_xy, float* v_conic, float* v_colors,
+                      float* v_extra, float* v_opacity, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GOLIATH_HIP_H */
