@@ -1,0 +1,680 @@
+// shade.hip -- fused RGCA shading tail (SH diffuse + Gaussian activations + SG / env-map specular),
+// forward + backward, gfx950.
+//
+// Replaces the chain of ATen kernels of PrimDecoder.forward after the decoders
+// (/root/reference/ca_code/models/rgca.py:505-588, training extra :590-618) including the specular
+// term (extensions/sgutils/sg.cu:27-175 with w_type 0, or ca_code/utils/envmap.py:284-292 +
+// ca_code/utils/mipmap_sampler.py:13-69).  This is THE HBM-bound stage of the frame: 129 decoder
+// channels (516 B) per Gaussian in, 34 floats out.  Design:
+//   * the decoder tensors are consumed in their native planar [B,C,N] layout: each channel plane is
+//     read once with 16-byte-per-lane coalesced loads (V = 4 consecutive Gaussians per lane), the SH
+//     dot products are streaming FMAs against wave-uniform light coefficients (scalar loads);
+//   * outputs are written in the [B,N,k] layout the reference's preds/losses use, as float4 stores
+//     (4 Gaussians x k floats are contiguous);
+//   * backward never re-reads the 113 SH channels: d(loss)/d(f_vnocond) of an SH channel is just
+//     upstream x light coefficient, so it is write-only (452 B) -- the re-read the PyTorch graph
+//     would do (another 452 B) is gone.  Only the 12 geometry channels + f_vcond are re-read.
+#include "gol_common.h"
+
+namespace {
+
+constexpr float kPi = 3.14159265358979323846f;
+constexpr float kSqrt2Pi23 = 3.03352966508f;     // sg.cu:20
+constexpr float kInvSqrt2Pi23 = 0.32964899322f;  // sg.cu:21
+constexpr float kNormEps = 1e-12f;               // torch F.normalize default eps
+
+template <int V>
+__device__ __forceinline__ void ldv(const float* __restrict__ p, float (&x)[V]) {
+  if constexpr (V == 4) {
+    const float4 t = *reinterpret_cast<const float4*>(p);
+    x[0] = t.x; x[1] = t.y; x[2] = t.z; x[3] = t.w;
+  } else {
+#pragma unroll
+    for (int v = 0; v < V; ++v) x[v] = p[v];
+  }
+}
+template <int V>
+__device__ __forceinline__ void stv(float* __restrict__ p, const float (&x)[V]) {
+  if constexpr (V == 4) {
+    *reinterpret_cast<float4*>(p) = make_float4(x[0], x[1], x[2], x[3]);
+  } else {
+#pragma unroll
+    for (int v = 0; v < V; ++v) p[v] = x[v];
+  }
+}
+// [.,N,K] row-major: the K values of V consecutive Gaussians are V*K contiguous floats
+template <int V, int K>
+__device__ __forceinline__ void ld_aos(const float* __restrict__ base, size_t g0, float (&x)[K][V]) {
+  float buf[V * K];
+  const float* p = base + g0 * K;
+  if constexpr ((V * K) % 4 == 0 && V == 4) {
+#pragma unroll
+    for (int j = 0; j < V * K / 4; ++j) {
+      const float4 t = reinterpret_cast<const float4*>(p)[j];
+      buf[4 * j] = t.x; buf[4 * j + 1] = t.y; buf[4 * j + 2] = t.z; buf[4 * j + 3] = t.w;
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < V * K; ++j) buf[j] = p[j];
+  }
+#pragma unroll
+  for (int v = 0; v < V; ++v)
+#pragma unroll
+    for (int k = 0; k < K; ++k) x[k][v] = buf[v * K + k];
+}
+template <int V, int K>
+__device__ __forceinline__ void st_aos(float* __restrict__ base, size_t g0, const float (&x)[K][V]) {
+  float buf[V * K];
+#pragma unroll
+  for (int v = 0; v < V; ++v)
+#pragma unroll
+    for (int k = 0; k < K; ++k) buf[v * K + k] = x[k][v];
+  float* p = base + g0 * K;
+  if constexpr ((V * K) % 4 == 0 && V == 4) {
+#pragma unroll
+    for (int j = 0; j < V * K / 4; ++j)
+      reinterpret_cast<float4*>(p)[j] = make_float4(buf[4 * j], buf[4 * j + 1], buf[4 * j + 2], buf[4 * j + 3]);
+  } else {
+#pragma unroll
+    for (int j = 0; j < V * K; ++j) p[j] = buf[j];
+  }
+}
+// optional upstream gradient: NULL pointer = zeros
+template <int V, int K>
+__device__ __forceinline__ void ld_aos_opt(const float* __restrict__ base, size_t g0, float (&x)[K][V]) {
+  if (base) {
+    ld_aos<V, K>(base, g0, x);
+  } else {
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+#pragma unroll
+      for (int v = 0; v < V; ++v) x[k][v] = 0.f;
+  }
+}
+
+__device__ __forceinline__ float sigmoidf(float x) { return 1.f / (1.f + expf(-x)); }
+__device__ __forceinline__ float softplusf(float x) { return x > 20.f ? x : log1pf(expf(x)); }  // torch threshold=20
+
+// ---- environment lookup ---------------------------------------------------------------------
+struct Bilinear {
+  float val[3];
+  float d_ix[3], d_iy[3];  // d val / d (unnormalised pixel coordinate), 0 outside the clamp range
+  float mx, my;            // coordinate-clamp gradient masks (torch clip_coordinates_set_grad)
+};
+
+// F.grid_sample(mode=bilinear, padding_mode=border, align_corners=False) of a [3,h,w] image at
+// normalised (u,v) in [-1,1]
+__device__ __forceinline__ Bilinear bilinear_border(const float* __restrict__ img, int h, int w, float u, float v) {
+  Bilinear r;
+  float ix = ((u + 1.f) * (float)w - 1.f) * 0.5f, iy = ((v + 1.f) * (float)h - 1.f) * 0.5f;
+  r.mx = (ix > 0.f && ix < (float)(w - 1)) ? 1.f : 0.f;
+  r.my = (iy > 0.f && iy < (float)(h - 1)) ? 1.f : 0.f;
+  ix = fminf(fmaxf(ix, 0.f), (float)(w - 1));
+  iy = fminf(fmaxf(iy, 0.f), (float)(h - 1));
+  const float fx0 = floorf(ix), fy0 = floorf(iy);
+  const int x0 = (int)fx0, y0 = (int)fy0, x1 = x0 + 1, y1 = y0 + 1;
+  const float wx1 = ix - fx0, wx0 = 1.f - wx1, wy1 = iy - fy0, wy0 = 1.f - wy1;
+  const bool bx = x1 < w, by = y1 < h;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const float* p = img + (size_t)c * h * w;
+    const float v00 = p[y0 * w + x0];
+    const float v01 = bx ? p[y0 * w + x1] : 0.f;
+    const float v10 = by ? p[y1 * w + x0] : 0.f;
+    const float v11 = (bx && by) ? p[y1 * w + x1] : 0.f;
+    r.val[c] = wy0 * (wx0 * v00 + wx1 * v01) + wy1 * (wx0 * v10 + wx1 * v11);
+    r.d_ix[c] = wy0 * (v01 - v00) + wy1 * (v11 - v10);
+    r.d_iy[c] = wx0 * (v10 - v00) + wx1 * (v11 - v01);
+  }
+  return r;
+}
+
+struct EnvSample {
+  float val[3];      // lerp of the two mip levels (before clamp(max=1))
+  float d_u[3], d_v[3];
+};
+
+// mipmap_grid_sample (mipmap_sampler.py:13-69): level selection has no gradient.
+__device__ __forceinline__ EnvSample env_lookup(const gol_shade_in& in, int b, float u, float v, float level) {
+  EnvSample e;
+  const int q = in.n_mips;
+  int d1 = 0;
+  float a = 0.f;
+  if (q > 1) {
+    const float lam = fminf(fmaxf(level, 0.f), (float)(q - 1) - 1e-6f);
+    const float fl = floorf(lam);
+    d1 = (int)fl;
+    a = lam - fl;
+  }
+  const int h0 = in.mip_h[d1], w0 = in.mip_w[d1];
+  const Bilinear s0 = bilinear_border(in.mips[d1] + (size_t)b * 3 * h0 * w0, h0, w0, u, v);
+  if (q > 1) {
+    const int d2 = min(d1 + 1, q - 1);
+    const int h1 = in.mip_h[d2], w1 = in.mip_w[d2];
+    const Bilinear s1 = bilinear_border(in.mips[d2] + (size_t)b * 3 * h1 * w1, h1, w1, u, v);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      e.val[c] = s0.val[c] + a * (s1.val[c] - s0.val[c]);  // th.lerp
+      const float du0 = s0.d_ix[c] * s0.mx * (0.5f * (float)w0), du1 = s1.d_ix[c] * s1.mx * (0.5f * (float)w1);
+      const float dv0 = s0.d_iy[c] * s0.my * (0.5f * (float)h0), dv1 = s1.d_iy[c] * s1.my * (0.5f * (float)h1);
+      e.d_u[c] = du0 + a * (du1 - du0);
+      e.d_v[c] = dv0 + a * (dv1 - dv0);
+    }
+  } else {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      e.val[c] = s0.val[c];
+      e.d_u[c] = s0.d_ix[c] * s0.mx * (0.5f * (float)w0);
+      e.d_v[c] = s0.d_iy[c] * s0.my * (0.5f * (float)h0);
+    }
+  }
+  return e;
+}
+
+// ---- per-Gaussian shading state shared by forward and backward --------------------------------
+struct Geo {
+  float pos[3], qn, q[4], sp[3], opac, sigma, e01;  // e01 = 0.1*exp(rough) before the 0.01 floor
+  float vis, m[3], mn, n[3];                         // m = dnml + nmlbase, mn = |m|
+  float dvec[3], dn, view[3], vdn, ref[3];           // dvec = pos - campos, dn = |dvec|
+};
+
+__device__ __forceinline__ Geo make_geo(const float (&g)[12], const float (&fc)[4], const float (&pb)[3],
+                                        const float (&nb)[3], const float* __restrict__ cam) {
+  Geo s;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) s.pos[k] = g[k] + pb[k];
+  s.qn = sqrtf(g[3] * g[3] + g[4] * g[4] + g[5] * g[5] + g[6] * g[6]);
+  const float iq = 1.f / fmaxf(s.qn, kNormEps);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) s.q[k] = g[3 + k] * iq;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) s.sp[k] = softplusf(g[7 + k]);
+  s.opac = sigmoidf(g[10]);
+  s.e01 = 0.1f * expf(g[11]);
+  s.sigma = fmaxf(s.e01, 0.01f);
+  s.vis = sigmoidf(fc[0]);
+#pragma unroll
+  for (int k = 0; k < 3; ++k) s.m[k] = fc[1 + k] + nb[k];
+  s.mn = sqrtf(s.m[0] * s.m[0] + s.m[1] * s.m[1] + s.m[2] * s.m[2]);
+  const float im = 1.f / fmaxf(s.mn, kNormEps);
+#pragma unroll
+  for (int k = 0; k < 3; ++k) s.n[k] = s.m[k] * im;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) s.dvec[k] = s.pos[k] - cam[k];
+  s.dn = sqrtf(s.dvec[0] * s.dvec[0] + s.dvec[1] * s.dvec[1] + s.dvec[2] * s.dvec[2]);
+  const float id = 1.f / fmaxf(s.dn, kNormEps);
+#pragma unroll
+  for (int k = 0; k < 3; ++k) s.view[k] = s.dvec[k] * id;
+  s.vdn = s.view[0] * s.n[0] + s.view[1] * s.n[1] + s.view[2] * s.n[2];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) s.ref[k] = s.view[k] - 2.f * s.vdn * s.n[k];
+  return s;
+}
+
+// specular radiance before the spec_vis factor; ENV: min(sample, 1) (rgca.py:556)
+template <bool ENV>
+__device__ __forceinline__ void spec_forward(const gol_shade_in& in, int b, const Geo& s, float (&spec)[3]) {
+  if constexpr (ENV) {
+    const float* R = in.lightrot + 9 * b;
+    const float rx = R[0] * s.ref[0] + R[1] * s.ref[1] + R[2] * s.ref[2];
+    const float ry = R[3] * s.ref[0] + R[4] * s.ref[1] + R[5] * s.ref[2];
+    const float rz = R[6] * s.ref[0] + R[7] * s.ref[1] + R[8] * s.ref[2];
+    const float u = atan2f(rx, rz) * (1.f / kPi);
+    const float v = 2.f * acosf(fminf(1.f, fmaxf(-1.f, ry))) * (1.f / kPi) - 1.f;
+    const EnvSample e = env_lookup(in, b, u, v, 5.f * s.sigma);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) spec[c] = fminf(e.val[c], 1.f);
+  } else {
+    // evaluate_gaussian(normalize(ref), sigma, ...), w_type 0 (sgutils.py:75-76, sg.cu:49-72)
+    const float rn = 1.f / fmaxf(sqrtf(s.ref[0] * s.ref[0] + s.ref[1] * s.ref[1] + s.ref[2] * s.ref[2]), kNormEps);
+    const float lx = s.ref[0] * rn, ly = s.ref[1] * rn, lz = s.ref[2] * rn;
+    const int nL = in.n_lights[b];
+    const float* lv = in.light_intensity + (size_t)b * in.L * 3;
+    const float* lp = in.light_pos + (size_t)b * in.L * 3;
+    const float inv_sigma = 1.f / s.sigma, norm = 1.f / (s.sigma * kSqrt2Pi23);
+    spec[0] = spec[1] = spec[2] = 0.f;
+    for (int l = 0; l < nL; ++l) {
+      const float dx = lp[3 * l] - s.pos[0], dy = lp[3 * l + 1] - s.pos[1], dz = lp[3 * l + 2] - s.pos[2];
+      const float r = rsqrtf(dx * dx + dy * dy + dz * dz);
+      const float c = fminf(1.f, fmaxf(-1.f, (dx * lx + dy * ly + dz * lz) * r));
+      const float ang = acosf(c) * inv_sigma;
+      const float w = __expf(-0.5f * ang * ang) * norm;
+      spec[0] += lv[3 * l] * w; spec[1] += lv[3 * l + 1] * w; spec[2] += lv[3 * l + 2] * w;
+    }
+  }
+}
+
+template <int V, bool ENV, bool RAND>
+__global__ __launch_bounds__(256) void shade_fwd_kernel(const gol_shade_in in, const gol_shade_out out) {
+  const int b = blockIdx.y;
+  const int i0 = (blockIdx.x * 256 + threadIdx.x) * V;
+  const int N = in.N;
+  if (i0 >= N) return;
+  const int ncol = in.n_color_coef, nmono = in.n_mono_coef, ncoef = ncol + nmono, nd = 3 * ncol + nmono;
+  const float* F = in.f_vnocond + (size_t)b * (nd + 12) * N + i0;
+  const float* Lsh = in.light_sh + (size_t)b * 3 * ncoef;
+  const float* Lr = RAND ? in.light_sh_rand + (size_t)b * 3 * ncoef : nullptr;
+
+  float D[3][V], Dr[3][V];
+#pragma unroll
+  for (int c = 0; c < 3; ++c)
+#pragma unroll
+    for (int v = 0; v < V; ++v) { D[c][v] = 0.f; Dr[c][v] = 0.f; }
+  // colour SH: channel c*ncol + k  (rgca.py:508-510)
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+#pragma unroll 8
+    for (int k = 0; k < ncol; ++k) {
+      float x[V];
+      ldv<V>(F + (size_t)(c * ncol + k) * N, x);
+      const float l = Lsh[c * ncoef + k];
+      const float lr = RAND ? Lr[c * ncoef + k] : 0.f;
+#pragma unroll
+      for (int v = 0; v < V; ++v) { D[c][v] += x[v] * l; if (RAND) Dr[c][v] += x[v] * lr; }
+    }
+  }
+  // monochrome SH shared by the three colour channels (rgca.py:511-514)
+#pragma unroll 8
+  for (int k = 0; k < nmono; ++k) {
+    float x[V];
+    ldv<V>(F + (size_t)(3 * ncol + k) * N, x);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float l = Lsh[c * ncoef + ncol + k];
+      const float lr = RAND ? Lr[c * ncoef + ncol + k] : 0.f;
+#pragma unroll
+      for (int v = 0; v < V; ++v) { D[c][v] += x[v] * l; if (RAND) Dr[c][v] += x[v] * lr; }
+    }
+  }
+  float g[12][V], fc[4][V], pb[3][V], nb[3][V], alb[3][V];
+#pragma unroll
+  for (int j = 0; j < 12; ++j) ldv<V>(F + (size_t)(nd + j) * N, g[j]);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) ldv<V>(in.f_vcond + ((size_t)b * 4 + j) * N + i0, fc[j]);
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    ldv<V>(in.postex + ((size_t)b * 3 + j) * N + i0, pb[j]);
+    ldv<V>(in.tn + ((size_t)b * 3 + j) * N + i0, nb[j]);
+  }
+  ld_aos<V, 3>(in.albedo, (size_t)i0, alb);
+
+  float o_color[3][V], o_op[1][V], o_pos[3][V], o_q[4][V], o_sc[3][V], o_sp[3][V], o_sig[1][V], o_vis[1][V];
+  float o_n[3][V], o_dn[3][V], o_diff[3][V], o_spec[3][V], o_nb[3][V], o_rand[3][V], o_D[3][V];
+  const float* cam = in.campos + 3 * b;
+#pragma unroll
+  for (int v = 0; v < V; ++v) {
+    float gg[12], ff[4], p3[3], n3[3];
+#pragma unroll
+    for (int j = 0; j < 12; ++j) gg[j] = g[j][v];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) ff[j] = fc[j][v];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) { p3[j] = pb[j][v]; n3[j] = nb[j][v]; }
+    const Geo s = make_geo(gg, ff, p3, n3, cam);
+    float spec[3];
+    spec_forward<ENV>(in, b, s, spec);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float diff = alb[c][v] * D[c][v];
+      const float sp = spec[c] * s.vis;
+      o_diff[c][v] = diff;
+      o_spec[c][v] = sp;
+      o_color[c][v] = fmaxf(fmaxf(diff, 0.f) + sp, 0.f);
+      o_pos[c][v] = s.pos[c];
+      o_sp[c][v] = s.sp[c];
+      o_sc[c][v] = fminf(fmaxf(s.sp[c], in.primscale_min), in.primscale_max);
+      o_n[c][v] = s.n[c];
+      o_dn[c][v] = ff[1 + c];
+      o_nb[c][v] = n3[c];
+      o_D[c][v] = D[c][v];
+      if (RAND) o_rand[c][v] = fmaxf(Dr[c][v], 0.f);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) o_q[k][v] = s.q[k];
+    o_op[0][v] = s.opac; o_sig[0][v] = s.sigma; o_vis[0][v] = s.vis;
+  }
+  const size_t g0 = (size_t)b * N + i0;
+  st_aos<V, 3>(out.color, g0, o_color);
+  st_aos<V, 1>(out.opacity, g0, o_op);
+  st_aos<V, 3>(out.primpos, g0, o_pos);
+  st_aos<V, 4>(out.primqvec, g0, o_q);
+  st_aos<V, 3>(out.primscale, g0, o_sc);
+  st_aos<V, 3>(out.primscale_preclip, g0, o_sp);
+  st_aos<V, 1>(out.sigma, g0, o_sig);
+  st_aos<V, 1>(out.spec_vis, g0, o_vis);
+  st_aos<V, 3>(out.spec_nml, g0, o_n);
+  st_aos<V, 3>(out.spec_dnml, g0, o_dn);
+  st_aos<V, 3>(out.diff_color, g0, o_diff);
+  st_aos<V, 3>(out.spec_color, g0, o_spec);
+  st_aos<V, 3>(out.primnmlbase, g0, o_nb);
+  st_aos<V, 3>(out.diff_sum, g0, o_D);
+  if (RAND) st_aos<V, 3>(out.color_rand, g0, o_rand);
+}
+
+// Backward, two phases per 256-Gaussian workgroup:
+//   phase 1  one lane per Gaussian: recompute the shading state, push the upstream gradients through
+//            it, write the 12 geometry / 4 f_vcond / base / albedo gradients, park d loss/d(SH sums)
+//            (6 floats per Gaussian) in LDS;
+//   phase 2  wave w owns SH channels w, w+4, ...: every lane turns 4 consecutive Gaussians' parked
+//            sums into one 16-byte store per channel plane (1 KiB contiguous per wave-instruction).
+// Phase 2 is 452 of the ~650 B written per Gaussian, so the bulk of the traffic is full-width.
+template <bool ENV, bool RAND, bool VEC4>
+__global__ __launch_bounds__(256) void shade_bwd_kernel(const gol_shade_in in, const gol_shade_out saved,
+                                                        const gol_shade_out_grad up, const gol_shade_in_grad gin) {
+  constexpr int V = 1;
+  __shared__ __attribute__((aligned(16))) float s_g[6][256];  // gD[3], gDr[3] per Gaussian of the block
+  const int b = blockIdx.y;
+  const int blk0 = blockIdx.x * 256;
+  const int i0 = blk0 + threadIdx.x;
+  const int N = in.N;
+  const int ncol = in.n_color_coef, nmono = in.n_mono_coef, ncoef = ncol + nmono, nd = 3 * ncol + nmono;
+  const size_t view0 = (size_t)b * (nd + 12) * N;
+  const float* Lsh = in.light_sh + (size_t)b * 3 * ncoef;
+  const float* Lr = RAND ? in.light_sh_rand + (size_t)b * 3 * ncoef : nullptr;
+  if (i0 < N) {
+    const float* F = in.f_vnocond + view0 + i0;
+    float* GF = gin.f_vnocond + view0 + i0;
+    const size_t g0 = (size_t)b * N + i0;
+
+    float g[12][V], fc[4][V], pb[3][V], nb[3][V], alb[3][V], Dsum[3][V], crand[3][V];
+#pragma unroll
+    for (int j = 0; j < 12; ++j) ldv<V>(F + (size_t)(nd + j) * N, g[j]);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) ldv<V>(in.f_vcond + ((size_t)b * 4 + j) * N + i0, fc[j]);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      ldv<V>(in.postex + ((size_t)b * 3 + j) * N + i0, pb[j]);
+      ldv<V>(in.tn + ((size_t)b * 3 + j) * N + i0, nb[j]);
+    }
+    ld_aos<V, 3>(in.albedo, (size_t)i0, alb);
+    ld_aos<V, 3>(saved.diff_sum, g0, Dsum);
+    if (RAND) ld_aos<V, 3>(saved.color_rand, g0, crand);
+
+    float u_color[3][V], u_op[1][V], u_pos[3][V], u_q[4][V], u_sc[3][V], u_sp[3][V], u_sig[1][V], u_vis[1][V];
+    float u_n[3][V], u_dn[3][V], u_diff[3][V], u_spec[3][V], u_nb[3][V], u_rand[3][V];
+    ld_aos_opt<V, 3>(up.color, g0, u_color);
+    ld_aos_opt<V, 1>(up.opacity, g0, u_op);
+    ld_aos_opt<V, 3>(up.primpos, g0, u_pos);
+    ld_aos_opt<V, 4>(up.primqvec, g0, u_q);
+    ld_aos_opt<V, 3>(up.primscale, g0, u_sc);
+    ld_aos_opt<V, 3>(up.primscale_preclip, g0, u_sp);
+    ld_aos_opt<V, 1>(up.sigma, g0, u_sig);
+    ld_aos_opt<V, 1>(up.spec_vis, g0, u_vis);
+    ld_aos_opt<V, 3>(up.spec_nml, g0, u_n);
+    ld_aos_opt<V, 3>(up.spec_dnml, g0, u_dn);
+    ld_aos_opt<V, 3>(up.diff_color, g0, u_diff);
+    ld_aos_opt<V, 3>(up.spec_color, g0, u_spec);
+    ld_aos_opt<V, 3>(up.primnmlbase, g0, u_nb);
+    ld_aos_opt<V, 3>(RAND ? up.color_rand : nullptr, g0, u_rand);
+
+    float gD[3][V], gDr[3][V];  // d loss / d (SH sum) for the light and the random light
+    float gg[12][V], gfc[4][V], gpb[3][V], gnb[3][V], galb[3][V];
+    const float* cam = in.campos + 3 * b;
+    constexpr int v = 0;
+    {
+      float g1[12], f1[4], p3[3], n3[3];
+#pragma unroll
+      for (int j = 0; j < 12; ++j) g1[j] = g[j][v];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) f1[j] = fc[j][v];
+#pragma unroll
+      for (int j = 0; j < 3; ++j) { p3[j] = pb[j][v]; n3[j] = nb[j][v]; }
+      const Geo s = make_geo(g1, f1, p3, n3, cam);
+      float spec[3];
+      spec_forward<ENV>(in, b, s, spec);  // recomputed: cheaper than saving/re-reading it
+
+      // colour composition (rgca.py:572-575): color_out = max(max(diff,0) + spec*vis, 0)
+      float g_spec[3], g_sraw[3], g_vis = u_vis[0][v];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const float diff = alb[c][v] * Dsum[c][v];
+        const float col = fmaxf(diff, 0.f) + spec[c] * s.vis;
+        const float gc = (col >= 0.f) ? u_color[c][v] : 0.f;
+        const float g_diff = u_diff[c][v] + ((diff >= 0.f) ? gc : 0.f);
+        g_spec[c] = u_spec[c][v] + gc;
+        g_vis += g_spec[c] * spec[c];
+        g_sraw[c] = g_spec[c] * s.vis;
+        gD[c][v] = g_diff * alb[c][v];
+        galb[c][v] = g_diff * Dsum[c][v];
+        gDr[c][v] = RAND ? ((crand[c][v] > 0.f) ? u_rand[c][v] : 0.f) : 0.f;
+      }
+      gfc[0][v] = g_vis * s.vis * (1.f - s.vis);
+
+      // specular -> reflection direction (and roughness for the SG lobe)
+      float g_ref[3] = {0.f, 0.f, 0.f}, g_sigma = u_sig[0][v];
+      if constexpr (ENV) {
+        const float* R = in.lightrot + 9 * b;
+        const float rx = R[0] * s.ref[0] + R[1] * s.ref[1] + R[2] * s.ref[2];
+        const float ry = R[3] * s.ref[0] + R[4] * s.ref[1] + R[5] * s.ref[2];
+        const float rz = R[6] * s.ref[0] + R[7] * s.ref[1] + R[8] * s.ref[2];
+        const float ryc = fminf(1.f, fmaxf(-1.f, ry));
+        const float uu = atan2f(rx, rz) * (1.f / kPi), vv = 2.f * acosf(ryc) * (1.f / kPi) - 1.f;
+        const EnvSample e = env_lookup(in, b, uu, vv, 5.f * s.sigma);
+        float g_u = 0.f, g_v = 0.f;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          const float gs = (e.val[c] <= 1.f) ? g_sraw[c] : 0.f;  // clamp(max=1)
+          g_u += gs * e.d_u[c];
+          g_v += gs * e.d_v[c];
+        }
+        const float den = rx * rx + rz * rz;
+        const float iden = den > 0.f ? 1.f / den : 0.f;
+        const float grx = g_u * (1.f / kPi) * rz * iden;
+        const float grz = -g_u * (1.f / kPi) * rx * iden;
+        const float gry = (ry > -1.f && ry < 1.f) ? g_v * (-2.f / kPi) * rsqrtf(1.f - ry * ry) : 0.f;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) g_ref[k] = R[k] * grx + R[3 + k] * gry + R[6 + k] * grz;
+      } else {
+        // evaluate_gaussian backward, w_type 0 (sg.cu:113-130,160-163), then F.normalize backward
+        const float rl = sqrtf(s.ref[0] * s.ref[0] + s.ref[1] * s.ref[1] + s.ref[2] * s.ref[2]);
+        const float rn = 1.f / fmaxf(rl, kNormEps);
+        const float lx = s.ref[0] * rn, ly = s.ref[1] * rn, lz = s.ref[2] * rn;
+        const int nL = in.n_lights[b];
+        const float* lv = in.light_intensity + (size_t)b * in.L * 3;
+        const float* lp = in.light_pos + (size_t)b * in.L * 3;
+        const float sg = s.sigma, s2 = sg * sg;
+        float gx = 0.f, gy = 0.f, gz = 0.f, gs = 0.f;
+        for (int l = 0; l < nL; ++l) {
+          float dx = lp[3 * l] - s.pos[0], dy = lp[3 * l + 1] - s.pos[1], dz = lp[3 * l + 2] - s.pos[2];
+          const float r = rsqrtf(dx * dx + dy * dy + dz * dz);
+          dx *= r; dy *= r; dz *= r;
+          const float c = dx * lx + dy * ly + dz * lz;
+          const float cc = fminf(1.f, fmaxf(-1.f, c));
+          const float angle = acosf(cc);
+          const float ex = __expf(-0.5f * (angle / sg) * (angle / sg));
+          const float dw = g_sraw[0] * lv[3 * l] + g_sraw[1] * lv[3 * l + 1] + g_sraw[2] * lv[3 * l + 2];
+          const float dacos = (c > -1.f && c < 1.f) ? (-1.f / sqrtf(1.f - c * c)) : -20.f;
+          gs += dw * ((ex * kInvSqrt2Pi23 * (angle * angle - s2)) / (s2 * s2));
+          const float dc = dw * -((kInvSqrt2Pi23 * angle * ex) / (s2 * sg)) * dacos;
+          gx += dc * dx; gy += dc * dy; gz += dc * dz;
+        }
+        g_sigma += gs;
+        const float dotl = gx * lx + gy * ly + gz * lz;
+        g_ref[0] = (gx - lx * dotl) * rn; g_ref[1] = (gy - ly * dotl) * rn; g_ref[2] = (gz - lz * dotl) * rn;
+      }
+      // ref = view - 2 (view.n) n
+      const float ndg = s.n[0] * g_ref[0] + s.n[1] * g_ref[1] + s.n[2] * g_ref[2];
+      float g_view[3], g_n[3];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        g_view[k] = g_ref[k] - 2.f * s.n[k] * ndg;
+        g_n[k] = u_n[k][v] - 2.f * (s.view[k] * ndg + s.vdn * g_ref[k]);
+      }
+      // view = normalize(pos - cam)
+      const float vdg = s.view[0] * g_view[0] + s.view[1] * g_view[1] + s.view[2] * g_view[2];
+      const float idn = 1.f / fmaxf(s.dn, kNormEps);
+      // spec_nml = normalize(dnml + nmlbase)
+      const float ndn = s.n[0] * g_n[0] + s.n[1] * g_n[1] + s.n[2] * g_n[2];
+      const float imn = 1.f / fmaxf(s.mn, kNormEps);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const float gp = u_pos[k][v] + (g_view[k] - s.view[k] * vdg) * idn;
+        gg[k][v] = gp;
+        gpb[k][v] = gp;
+        const float gm = (g_n[k] - s.n[k] * ndn) * imn;
+        gfc[1 + k][v] = u_dn[k][v] + gm;
+        gnb[k][v] = u_nb[k][v] + gm;
+      }
+      // qvec = normalize(f)
+      const float qdg = s.q[0] * u_q[0][v] + s.q[1] * u_q[1][v] + s.q[2] * u_q[2][v] + s.q[3] * u_q[3][v];
+      const float iq = 1.f / fmaxf(s.qn, kNormEps);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) gg[3 + k][v] = (u_q[k][v] - s.q[k] * qdg) * iq;
+      // scale = clamp(softplus(x), min, max); preclip = softplus(x)
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const float pre = s.sp[k];
+        const float gpre = u_sp[k][v] + ((pre >= in.primscale_min && pre <= in.primscale_max) ? u_sc[k][v] : 0.f);
+        const float x = g1[7 + k];
+        gg[7 + k][v] = gpre * (x > 20.f ? 1.f : sigmoidf(x));
+      }
+      gg[10][v] = u_op[0][v] * s.opac * (1.f - s.opac);
+      gg[11][v] = (s.e01 >= 0.01f) ? g_sigma * s.e01 : 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < 12; ++j) stv<V>(GF + (size_t)(nd + j) * N, gg[j]);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) stv<V>(gin.f_vcond + ((size_t)b * 4 + j) * N + i0, gfc[j]);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      stv<V>(gin.postex + ((size_t)b * 3 + j) * N + i0, gpb[j]);
+      stv<V>(gin.tn + ((size_t)b * 3 + j) * N + i0, gnb[j]);
+    }
+    st_aos<V, 3>(gin.albedo_per_view, g0, galb);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { s_g[c][threadIdx.x] = gD[c][0]; s_g[3 + c][threadIdx.x] = gDr[c][0]; }
+  } else {
+#pragma unroll
+    for (int c = 0; c < 6; ++c) s_g[c][threadIdx.x] = 0.f;
+  }
+  __syncthreads();
+
+  // phase 2: write-only gradients of the SH channels = upstream x light coefficient
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int j0 = blk0 + 4 * lane;  // first of this lane's 4 Gaussians
+  if (j0 >= N) return;
+  float gD4[3][4], gR4[3][4];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const float4 a = *reinterpret_cast<const float4*>(&s_g[c][4 * lane]);
+    gD4[c][0] = a.x; gD4[c][1] = a.y; gD4[c][2] = a.z; gD4[c][3] = a.w;
+    if (RAND) {
+      const float4 r = *reinterpret_cast<const float4*>(&s_g[3 + c][4 * lane]);
+      gR4[c][0] = r.x; gR4[c][1] = r.y; gR4[c][2] = r.z; gR4[c][3] = r.w;
+    }
+  }
+  float* GP = gin.f_vnocond + view0 + j0;
+  const int nvalid = min(4, N - j0);
+  for (int ch = wave; ch < nd; ch += 4) {
+    float x[4] = {0.f, 0.f, 0.f, 0.f};
+    if (ch < 3 * ncol) {
+      const int c = ch / ncol, k = ch - c * ncol;
+      const float l = Lsh[c * ncoef + k];
+      const float lr = RAND ? Lr[c * ncoef + k] : 0.f;
+      // c is wave-uniform but not a compile-time constant: select the row without dynamic indexing
+#pragma unroll
+      for (int cc = 0; cc < 3; ++cc)
+        if (cc == c) {
+#pragma unroll
+          for (int v = 0; v < 4; ++v) x[v] = gD4[cc][v] * l + (RAND ? gR4[cc][v] * lr : 0.f);
+        }
+    } else {
+      const int k = ch - 3 * ncol;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const float l = Lsh[c * ncoef + ncol + k];
+        const float lr = RAND ? Lr[c * ncoef + ncol + k] : 0.f;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) x[v] += gD4[c][v] * l + (RAND ? gR4[c][v] * lr : 0.f);
+      }
+    }
+    float* dst = GP + (size_t)ch * N;
+    if (VEC4) {
+      *reinterpret_cast<float4*>(dst) = make_float4(x[0], x[1], x[2], x[3]);
+    } else {
+      for (int v = 0; v < nvalid; ++v) dst[v] = x[v];
+    }
+  }
+}
+
+int check_in(const gol_shade_in* in) {
+  GOL_REQUIRE(in != nullptr, "null gol_shade_in");
+  GOL_REQUIRE(in->B >= 0 && in->N >= 0, "negative size");
+  GOL_REQUIRE(in->B <= 65535, "B > 65535");
+  GOL_REQUIRE(in->n_color_coef > 0 && in->n_mono_coef >= 0, "bad SH sizes");
+  if (in->B == 0 || in->N == 0) return GOL_OK;
+  GOL_REQUIRE(in->f_vnocond && in->f_vcond && in->postex && in->tn && in->albedo && in->light_sh && in->campos,
+              "null input");
+  GOL_REQUIRE(in->n_mips >= 0 && in->n_mips <= GOL_MAX_MIPS, "n_mips out of range");
+  if (in->n_mips > 0) {
+    GOL_REQUIRE(in->lightrot != nullptr, "env map needs lightrot");
+    for (int i = 0; i < in->n_mips; ++i)
+      GOL_REQUIRE(in->mips[i] && in->mip_h[i] > 0 && in->mip_w[i] > 0, "bad mip level");
+  } else {
+    GOL_REQUIRE(in->L >= 0 && in->n_lights != nullptr, "point lights need n_lights");
+    GOL_REQUIRE(in->L == 0 || (in->light_intensity && in->light_pos), "null light arrays");
+  }
+  return GOL_OK;
+}
+
+}  // namespace
+
+#define GOL_SHADE_FWD_DISPATCH(...)                                                                \
+  do {                                                                                           \
+    const bool env = in->n_mips > 0, rnd = in->light_sh_rand != nullptr;                         \
+    if (in->N % 4 == 0) {                                                                        \
+      dim3 grid(gol_cdiv(in->N / 4, 256), in->B);                                                \
+      if (env && rnd) shade_fwd_kernel<4, true, true><<<grid, 256, 0, s>>>(__VA_ARGS__);         \
+      else if (env) shade_fwd_kernel<4, true, false><<<grid, 256, 0, s>>>(__VA_ARGS__);          \
+      else if (rnd) shade_fwd_kernel<4, false, true><<<grid, 256, 0, s>>>(__VA_ARGS__);          \
+      else shade_fwd_kernel<4, false, false><<<grid, 256, 0, s>>>(__VA_ARGS__);                  \
+    } else {                                                                                     \
+      dim3 grid(gol_cdiv(in->N, 256), in->B);                                                    \
+      if (env && rnd) shade_fwd_kernel<1, true, true><<<grid, 256, 0, s>>>(__VA_ARGS__);         \
+      else if (env) shade_fwd_kernel<1, true, false><<<grid, 256, 0, s>>>(__VA_ARGS__);          \
+      else if (rnd) shade_fwd_kernel<1, false, true><<<grid, 256, 0, s>>>(__VA_ARGS__);          \
+      else shade_fwd_kernel<1, false, false><<<grid, 256, 0, s>>>(__VA_ARGS__);                  \
+    }                                                                                            \
+  } while (0)
+
+#define GOL_SHADE_BWD_CASE(E, R)                                                                 \
+  do {                                                                                           \
+    if (in->N % 4 == 0) shade_bwd_kernel<E, R, true><<<grid, 256, 0, s>>>(*in, *saved, *g, *gin); \
+    else shade_bwd_kernel<E, R, false><<<grid, 256, 0, s>>>(*in, *saved, *g, *gin);              \
+  } while (0)
+
+extern "C" int gol_shade_fwd(const gol_shade_in* in, const gol_shade_out* out, void* stream) {
+  int rc = check_in(in);
+  if (rc != GOL_OK) return rc;
+  if (in->B == 0 || in->N == 0) return GOL_OK;
+  GOL_REQUIRE(out != nullptr, "null gol_shade_out");
+  GOL_REQUIRE(out->color && out->opacity && out->primpos && out->primqvec && out->primscale &&
+                  out->primscale_preclip && out->sigma && out->spec_vis && out->spec_nml && out->spec_dnml &&
+                  out->diff_color && out->spec_color && out->primnmlbase && out->diff_sum,
+              "null output");
+  GOL_REQUIRE((in->light_sh_rand == nullptr) || out->color_rand, "color_rand output missing");
+  hipStream_t s = (hipStream_t)stream;
+  GOL_SHADE_FWD_DISPATCH(*in, *out);
+  GOL_CHECK_LAUNCH();
+  return GOL_OK;
+}
+
+extern "C" int gol_shade_bwd(const gol_shade_in* in, const gol_shade_out* saved, const gol_shade_out_grad* g,
+                             const gol_shade_in_grad* gin, void* stream) {
+  int rc = check_in(in);
+  if (rc != GOL_OK) return rc;
+  if (in->B == 0 || in->N == 0) return GOL_OK;
+  GOL_REQUIRE(saved && g && gin, "null struct");
+  GOL_REQUIRE(saved->diff_sum != nullptr, "saved diff_sum missing");
+  GOL_REQUIRE((in->light_sh_rand == nullptr) || saved->color_rand, "saved color_rand missing");
+  GOL_REQUIRE(gin->f_vnocond && gin->f_vcond && gin->postex && gin->tn && gin->albedo_per_view, "null gradient output");
+  hipStream_t s = (hipStream_t)stream;
+  dim3 grid(gol_cdiv(in->N, 256), in->B);
+  const bool env = in->n_mips > 0, rnd = in->light_sh_rand != nullptr;
+  if (env && rnd) GOL_SHADE_BWD_CASE(true, true);
+  else if (env) GOL_SHADE_BWD_CASE(true, false);
+  else if (rnd) GOL_SHADE_BWD_CASE(false, true);
+  else GOL_SHADE_BWD_CASE(false, false);
+  GOL_CHECK_LAUNCH();
+  return GOL_OK;
+}

@@ -1,0 +1,169 @@
+"""Fused RGCA shading tail (host side) on top of the C ABI (gol_shade_fwd / gol_shade_bwd).
+
+Drop-in for the part of `PrimDecoder.forward` that follows the two transposed-conv decoders
+(/root/reference/ca_code/models/rgca.py:505-588, training extra :590-618): same inputs, same keys and
+shapes in the returned dict, gradients to f_vnocond, f_vcond, the uv position / normal maps and the
+albedo parameter.  The decoder outputs are consumed in their native NCHW layout (no permute copies).
+"""
+import ctypes
+
+import torch
+import torch.nn.functional as F
+
+from . import _lib
+from ._lib import stream_ptr
+
+MAX_MIPS = 8
+PRIMSCALE_RANGE = (0.1, 20.0)  # rgca.py:47
+
+_fp = ctypes.c_void_p
+
+
+class ShadeIn(ctypes.Structure):
+    _fields_ = [("B", ctypes.c_int32), ("N", ctypes.c_int32), ("n_color_coef", ctypes.c_int32),
+                ("n_mono_coef", ctypes.c_int32), ("f_vnocond", _fp), ("f_vcond", _fp), ("postex", _fp),
+                ("tn", _fp), ("albedo", _fp), ("light_sh", _fp), ("light_sh_rand", _fp), ("campos", _fp),
+                ("L", ctypes.c_int32), ("light_intensity", _fp), ("light_pos", _fp), ("n_lights", _fp),
+                ("n_mips", ctypes.c_int32), ("mips", _fp * MAX_MIPS), ("mip_h", ctypes.c_int32 * MAX_MIPS),
+                ("mip_w", ctypes.c_int32 * MAX_MIPS), ("lightrot", _fp), ("primscale_min", ctypes.c_float),
+                ("primscale_max", ctypes.c_float)]
+
+
+OUT_FIELDS = [("color", 3), ("opacity", 1), ("primpos", 3), ("primqvec", 4), ("primscale", 3),
+              ("primscale_preclip", 3), ("sigma", 1), ("spec_vis", 1), ("spec_nml", 3), ("spec_dnml", 3),
+              ("diff_color", 3), ("spec_color", 3), ("primnmlbase", 3), ("color_rand", 3), ("diff_sum", 3)]
+GRAD_FIELDS = [n for n, _ in OUT_FIELDS if n != "diff_sum"]
+
+
+class ShadeOut(ctypes.Structure):
+    _fields_ = [(n, _fp) for n, _ in OUT_FIELDS]
+
+
+class ShadeOutGrad(ctypes.Structure):
+    _fields_ = [(n, _fp) for n in GRAD_FIELDS]
+
+
+class ShadeInGrad(ctypes.Structure):
+    _fields_ = [("f_vnocond", _fp), ("f_vcond", _fp), ("postex", _fp), ("tn", _fp), ("albedo_per_view", _fp)]
+
+
+def _p(t, dtype=torch.float32):
+    return _lib.ptr(t, dtype).value if t is not None else None
+
+
+def _make_in(f_vnocond, f_vcond, postex, tn, albedo, light_sh, light_sh_rand, campos, light_intensity,
+             light_pos, n_lights, mips, lightrot, ncol, nmono):
+    B, C = f_vnocond.shape[:2]
+    N = f_vnocond[0, 0].numel()
+    s = ShadeIn()
+    s.B, s.N, s.n_color_coef, s.n_mono_coef = B, N, ncol, nmono
+    s.f_vnocond, s.f_vcond, s.postex, s.tn = _p(f_vnocond), _p(f_vcond), _p(postex), _p(tn)
+    s.albedo, s.light_sh, s.light_sh_rand, s.campos = _p(albedo), _p(light_sh), _p(light_sh_rand), _p(campos)
+    if mips:
+        s.n_mips = len(mips)
+        for i, m in enumerate(mips):
+            s.mips[i] = _p(m)
+            s.mip_h[i], s.mip_w[i] = m.shape[-2], m.shape[-1]
+        s.lightrot = _p(lightrot)
+    else:
+        s.n_mips = 0
+        s.L = light_intensity.shape[1]
+        s.light_intensity, s.light_pos = _p(light_intensity), _p(light_pos)
+        s.n_lights = _p(n_lights, torch.int32)
+    s.primscale_min, s.primscale_max = PRIMSCALE_RANGE
+    return s
+
+
+class _Shade(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, f_vnocond, f_vcond, postex, tn, albedo, light_sh, light_sh_rand, campos, light_intensity,
+                light_pos, n_lights, lightrot, ncol, nmono, *mips):
+        B = f_vnocond.shape[0]
+        N = f_vnocond[0, 0].numel()
+        dev = f_vnocond.device
+        rand = light_sh_rand is not None
+        outs = {n: torch.empty(B, N, k, device=dev) for n, k in OUT_FIELDS if rand or n != "color_rand"}
+        sin = _make_in(f_vnocond, f_vcond, postex, tn, albedo, light_sh, light_sh_rand, campos,
+                       light_intensity, light_pos, n_lights, list(mips), lightrot, ncol, nmono)
+        sout = ShadeOut()
+        for n, t in outs.items():
+            setattr(sout, n, _p(t))
+        with torch.cuda.device(dev):
+            _lib.call("gol_shade_fwd", ctypes.byref(sin), ctypes.byref(sout), stream_ptr())
+        ctx.cfg = (ncol, nmono, len(mips), rand)
+        ctx.save_for_backward(f_vnocond, f_vcond, postex, tn, albedo, light_sh, light_sh_rand, campos,
+                              light_intensity, light_pos, n_lights, lightrot, outs["diff_sum"],
+                              outs.get("color_rand"), *mips)
+        ctx.set_materialize_grads(False)
+        names = [n for n in GRAD_FIELDS if n in outs]
+        ctx.names = names
+        return tuple(outs[n] for n in names)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        ncol, nmono, n_mips, rand = ctx.cfg
+        sv = ctx.saved_tensors
+        (f_vnocond, f_vcond, postex, tn, albedo, light_sh, light_sh_rand, campos, light_intensity, light_pos,
+         n_lights, lightrot, diff_sum, color_rand) = sv[:14]
+        mips = list(sv[14:])
+        B = f_vnocond.shape[0]
+        N = f_vnocond[0, 0].numel()
+        dev = f_vnocond.device
+        sin = _make_in(f_vnocond, f_vcond, postex, tn, albedo, light_sh, light_sh_rand, campos,
+                       light_intensity, light_pos, n_lights, mips, lightrot, ncol, nmono)
+        saved = ShadeOut()
+        saved.diff_sum = _p(diff_sum)
+        saved.color_rand = _p(color_rand)
+        up = ShadeOutGrad()
+        keep = []
+        for n, g in zip(ctx.names, grads):
+            if g is not None:
+                g = g.to(torch.float32).contiguous()
+                keep.append(g)
+                setattr(up, n, _p(g))
+        g_vn, g_vc = torch.empty_like(f_vnocond), torch.empty_like(f_vcond)
+        g_pt, g_tn = torch.empty_like(postex), torch.empty_like(tn)
+        g_alb = torch.empty(B, N, 3, device=dev)
+        gin = ShadeInGrad()
+        gin.f_vnocond, gin.f_vcond, gin.postex, gin.tn = _p(g_vn), _p(g_vc), _p(g_pt), _p(g_tn)
+        gin.albedo_per_view = _p(g_alb)
+        with torch.cuda.device(dev):
+            _lib.call("gol_shade_bwd", ctypes.byref(sin), ctypes.byref(saved), ctypes.byref(up), ctypes.byref(gin),
+                      stream_ptr())
+        g_albedo = g_alb.sum(0).reshape(albedo.shape) if ctx.needs_input_grad[4] else None
+        return (g_vn, g_vc, g_pt, g_tn, g_albedo) + (None,) * (9 + n_mips)
+
+
+def shading_tail(f_vnocond, f_vcond, postex, tn, albedo, headrel_light_sh, headrel_campos,
+                 light_intensity=None, headrel_light_pos=None, n_lights=None, preconv_envmap=None,
+                 lightrot=None, light_sh_rand=None, n_color_sh=3, n_diff_sh=8):
+    """f_vnocond[B,125,S,S], f_vcond[B,4,S,S] (decoder outputs, NCHW), postex[B,3,S,S]
+    (geo_fn.to_uv(geom)), tn[B,3,S,S] (normalised uv normal map), albedo[1,N,3] -> dict with the keys
+    and [B,N,k] shapes of rgca.py:574-588 (+ "color_rand" when light_sh_rand[B,3,81] is given)."""
+    if not f_vnocond.is_cuda:
+        raise _lib.GoliathHipError("shading_tail needs CUDA(HIP) tensors; there is no CPU path")
+    ncol = (n_color_sh + 1) ** 2
+    nmono = (n_diff_sh + 1) ** 2 - ncol
+    B, C = f_vnocond.shape[:2]
+    if C != 3 * ncol + nmono + 12:
+        raise ValueError(f"f_vnocond has {C} channels, expected {3 * ncol + nmono + 12}")
+    c = lambda t: None if t is None else t.to(torch.float32).contiguous()
+    N = f_vnocond[0, 0].numel()
+    mips = []
+    if preconv_envmap is not None:
+        mips = [c(m) for m in (preconv_envmap if isinstance(preconv_envmap, (list, tuple)) else [preconv_envmap])]
+        if len(mips) > MAX_MIPS:
+            raise ValueError("too many mip levels")
+        lightrot = c(lightrot)
+        li = lp = nl = None
+    else:
+        li, lp = c(light_intensity.expand(-1, -1, 3)), c(headrel_light_pos)
+        nl = n_lights.to(torch.int32).contiguous()
+        lightrot = None
+    outs = _Shade.apply(c(f_vnocond), c(f_vcond), c(postex), c(tn), c(albedo).reshape(N, 3),
+                        c(headrel_light_sh), c(light_sh_rand), c(headrel_campos), li, lp, nl, lightrot,
+                        ncol, nmono, *mips)
+    names = [n for n in GRAD_FIELDS if light_sh_rand is not None or n != "color_rand"]
+    preds = dict(zip(names, outs))
+    preds["sigma"] = preds["sigma"][..., 0]  # [B,N] like rgca.py:526
+    return preds

@@ -121,6 +121,78 @@ int gol_rasterize_bwd(int B, int N, int img_h, int img_w, int block, const int32
                       const float* v_out_alpha, float* v_xy, float* v_conic, float* v_colors,
                       float* v_extra, float* v_opacity, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Fused RGCA shading tail.  Replaces the chain of ATen kernels in PrimDecoder.forward after the
+ * two transposed-conv decoders (ca_code/models/rgca.py:505-588, training extra :590-618), incl.
+ * the specular term: point lights = evaluate_gaussian w_type 0 (extensions/sgutils/sg.cu:27-175,
+ * rgca.py:559-570) or environment = dir2uv + mipmap_grid_sample (ca_code/utils/envmap.py:284-292,
+ * ca_code/utils/mipmap_sampler.py:13-69, rgca.py:548-556).
+ * The decoder outputs are read ONCE in their native planar NCHW layout (coalesced per channel
+ * plane): no permute().view() copies of the 125-channel tensor.
+ * All pointers device memory; structs themselves are host memory, read before the call returns.
+ * ---------------------------------------------------------------------------------------- */
+#define GOL_MAX_MIPS 8
+typedef struct {
+  int32_t B, N;              /* views, Gaussians per view (N = S*S)                              */
+  int32_t n_color_coef;      /* SH coefficients carried per colour channel: (n_color_sh+1)^2 = 16 */
+  int32_t n_mono_coef;       /* monochrome SH coefficients: (n_diff_sh+1)^2 - n_color_coef = 65   */
+  const float* f_vnocond;    /* [B, 3*n_color_coef + n_mono_coef + 12, N]  (rgca.py:494-495)      */
+  const float* f_vcond;      /* [B, 4, N]                                   (rgca.py:498-503)      */
+  const float* postex;       /* [B, 3, N] uv position map                   (rgca.py:483-484)      */
+  const float* tn;           /* [B, 3, N] normalised uv normal map          (rgca.py:488-491)      */
+  const float* albedo;       /* [N, 3]                                      (rgca.py:462-464)      */
+  const float* light_sh;     /* [B, 3, n_color_coef + n_mono_coef]          (rgca.py:187-191)      */
+  const float* light_sh_rand;/* same shape or NULL: training-only random light (rgca.py:590-616)  */
+  const float* campos;       /* [B, 3] head-relative camera position                              */
+  /* specular, point lights (used when n_mips == 0) */
+  int32_t L;
+  const float* light_intensity; /* [B, L, 3] */
+  const float* light_pos;       /* [B, L, 3] */
+  const int32_t* n_lights;      /* [B]       */
+  /* specular, prefiltered environment (n_mips > 0) */
+  int32_t n_mips;
+  const float* mips[GOL_MAX_MIPS];  /* level i: [B, 3, mip_h[i], mip_w[i]] */
+  int32_t mip_h[GOL_MAX_MIPS], mip_w[GOL_MAX_MIPS];
+  const float* lightrot;        /* [B, 3, 3] */
+  float primscale_min, primscale_max; /* rgca.py:47 (0.1, 20) */
+} gol_shade_in;
+
+typedef struct {  /* every field [B,N,k] row-major like the reference's preds (rgca.py:574-588) */
+  float* color;            /* 3 */
+  float* opacity;          /* 1 */
+  float* primpos;          /* 3 */
+  float* primqvec;         /* 4 */
+  float* primscale;        /* 3 clamped */
+  float* primscale_preclip;/* 3 */
+  float* sigma;            /* 1 */
+  float* spec_vis;         /* 1 */
+  float* spec_nml;         /* 3 */
+  float* spec_dnml;        /* 3 */
+  float* diff_color;       /* 3 */
+  float* spec_color;       /* 3 */
+  float* primnmlbase;      /* 3 */
+  float* color_rand;       /* 3, or NULL when light_sh_rand == NULL */
+  float* diff_sum;         /* 3: sum_k sh_k * L_k before albedo (saved for the backward) */
+} gol_shade_out;
+
+typedef struct {  /* upstream gradients, same shapes as gol_shade_out; any may be NULL (= 0) */
+  const float *color, *opacity, *primpos, *primqvec, *primscale, *primscale_preclip, *sigma, *spec_vis,
+      *spec_nml, *spec_dnml, *diff_color, *spec_color, *primnmlbase, *color_rand;
+} gol_shade_out_grad;
+
+typedef struct {  /* written in full */
+  float* f_vnocond;        /* [B, C, N] */
+  float* f_vcond;          /* [B, 4, N] */
+  float* postex;           /* [B, 3, N] */
+  float* tn;               /* [B, 3, N] */
+  float* albedo_per_view;  /* [B, N, 3]  (sum over B = gradient of the shared albedo) */
+} gol_shade_in_grad;
+
+int gol_shade_fwd(const gol_shade_in* in, const gol_shade_out* out, void* stream);
+/* `saved` = the gol_shade_out of the forward (reads color_rand, diff_sum). */
+int gol_shade_bwd(const gol_shade_in* in, const gol_shade_out* saved, const gol_shade_out_grad* g,
+                  const gol_shade_in_grad* gin, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
