@@ -1,0 +1,262 @@
+#!/usr/bin/env python
+"""bench.py -- relit views/sec (forward + backward) of the RGCA render hot path on MI355X.
+
+Metric (BASELINE.json): "relit views/sec (fwd+bwd) at 2048x1334, 250k Gaussians; 1/2/4/8 GPU".
+Workload = BASELINE config 2: RGCA head, 250,000 Gaussians, 8 views x 2048x1334 per
+GPU, single env-map relight.  One "step" = one batch of 8 views through the whole hot path with the
+decoder outputs already resident in HBM (SURVEY 8d mode A):
+    fused shading tail (SH diffuse + activations + env-map specular)      gol_shade_fwd
+    EWA projection (+ tile counts)                                        gol_project_fwd
+    tile binning + per-tile depth sort                                    gol_bin_sort
+    colour + depth tile raster                                            gol_rasterize_fwd
+    L1 loss vs a fixed random target image (torch elementwise)
+    raster / projection / shading backward                                gol_*_bwd
+Multi-GPU: views are independent units -> each rank renders its own 8 views (weak scaling); the only
+parameter on this path, the albedo map, has its gradient all-reduced over RCCL every step.
+
+Prints ONE JSON line (rank 0).  Per-ABI-call durations come from HIP events recorded on the launch
+stream inside the timed region; `roofline` describes the longest one.
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch
+import torch.nn.functional as F
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+
+CFG = dict(workload="rgca_config2_envrelight", gaussians=250_000, slab=500, height=2048, width=1334,
+           views_per_gpu=8, focal=3000.0, cam_radius_mm=700.0, n_mips=4, seed=1234)
+
+
+def make_inputs(cfg, device, rank=0):
+    """SURVEY.md 8d config-2 synthetic inputs (decoder-output surrogates + cameras + env map)."""
+    g = torch.Generator().manual_seed(cfg["seed"] + 1000 * rank)
+    B, S = cfg["views_per_gpu"], cfg["slab"]
+    N = S * S
+    f_vn = 0.3 * torch.randn(B, 125, S, S, generator=g)
+    # Gaussian parameter channels so that the activations reproduce the 8d statistics
+    d = torch.randn(N, 3, generator=g)
+    d = d / d.norm(dim=-1, keepdim=True)
+    pos = d * torch.rand(N, 1, generator=g) ** (1 / 3) * torch.tensor([90.0, 120.0, 100.0])
+    postex = pos.t().reshape(1, 3, S, S).expand(B, -1, -1, -1).contiguous()
+    tn = F.normalize(pos, dim=-1).t().reshape(1, 3, S, S).expand(B, -1, -1, -1).contiguous()
+    scale = torch.exp(math.log(0.3) + (math.log(3.0) - math.log(0.3)) * torch.rand(B, 3, S, S, generator=g))
+    f_vn[:, 113 + 7:113 + 10] = torch.log(torch.expm1(scale))           # softplus^-1
+    f_vn[:, 113 + 3:113 + 7] = torch.randn(B, 4, S, S, generator=g)      # quaternion
+    f_vn[:, 113 + 10] = 1.5 * torch.randn(B, S, S, generator=g)          # opacity logit
+    f_vn[:, 113 + 11] = -1.0 + 0.5 * torch.randn(B, S, S, generator=g)   # roughness: sigma ~ 0.04
+    f_vc = 0.3 * torch.randn(B, 4, S, S, generator=g)
+    albedo = 0.2 + 0.6 * torch.rand(1, N, 3, generator=g)
+    light_sh = 0.3 * torch.randn(B, 3, 81, generator=g) / (1 + torch.arange(81.0)) ** 0.5
+    light_sh[:, :, 0] = 1.5
+    mips = [torch.exp(0.5 * torch.randn(B, 3, 512 >> i, 1024 >> i, generator=g)) * 0.5 for i in range(cfg["n_mips"])]
+    K = torch.zeros(B, 3, 3)
+    K[:, 0, 0] = K[:, 1, 1] = cfg["focal"]
+    K[:, 0, 2], K[:, 1, 2], K[:, 2, 2] = cfg["width"] / 2.0, cfg["height"] / 2.0, 1.0
+    Rt, campos, rots = [], [], []
+    for b in range(B):
+        ang = 2 * math.pi * (b + 8 * rank) / 64.0 - 0.35
+        eye = torch.tensor([cfg["cam_radius_mm"] * math.sin(ang), 0.0, -cfg["cam_radius_mm"] * math.cos(ang)])
+        fwd = -eye / eye.norm()
+        right = torch.linalg.cross(torch.tensor([0.0, 1.0, 0.0]), fwd)
+        right = right / right.norm()
+        down = torch.linalg.cross(fwd, right)
+        R = torch.stack([right, down, fwd])
+        Rt.append(torch.cat([R, (-R @ eye)[:, None]], 1))
+        campos.append(eye)
+        a = 2 * math.pi * b / 256.0
+        rots.append(torch.tensor([[math.cos(a), 0, math.sin(a)], [0, 1, 0], [-math.sin(a), 0, math.cos(a)]]))
+    target = torch.rand(B, 3, cfg["height"], cfg["width"], generator=g)
+    t = dict(f_vn=f_vn, f_vc=f_vc, postex=postex, tn=tn, albedo=albedo, light_sh=light_sh, K=K,
+             Rt=torch.stack(Rt), campos=torch.stack(campos), lightrot=torch.stack(rots), target=target)
+    t = {k: v.to(device).contiguous() for k, v in t.items()}
+    t["mips"] = [m.to(device).contiguous() for m in mips]
+    for k in ("f_vn", "f_vc", "postex", "tn", "albedo"):
+        t[k].requires_grad_(True)
+    return t
+
+
+def step(t, cfg, world):
+    from goliath_amd import render_gs, shade
+
+    for k in ("f_vn", "f_vc", "postex", "tn", "albedo"):
+        t[k].grad = None
+    preds = shade.shading_tail(t["f_vn"], t["f_vc"], t["postex"], t["tn"], t["albedo"], t["light_sh"], t["campos"],
+                               preconv_envmap=t["mips"], lightrot=t["lightrot"])
+    rgb, alpha, depth = render_gs.render_batch(t["K"], t["Rt"], preds, cfg["height"], cfg["width"])
+    loss = (rgb - t["target"]).abs().mean()
+    loss.backward()
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.all_reduce(t["albedo"].grad)  # the path's only parameter (rgca.py:462-464)
+    return loss
+
+
+# algorithmic HBM bytes per view of each ABI call (DESIGN.md "Kernels and their rooflines").
+def algorithmic_bytes(name, N, I, P, n_mips_bytes):
+    return {
+        "gol_shade_fwd": (129 * 4 + 24 + 12) * N + 148 * N,
+        "gol_shade_bwd": (16 * 4 + 24 + 12 + 12) * N + 56 * N + (129 * 4 + 24 + 12) * N,
+        "gol_project_fwd": 44 * N + 92 * N,
+        "gol_project_bwd": (44 + 24 + 16 + 4 + 4) * N + 36 * N + 44 * N,
+        "gol_bin_sort": 16 * N + 8 * I + 8 * I + 4 * I,
+        "gol_rasterize_fwd": 4 * I + 44 * I + 24 * P,
+        "gol_rasterize_bwd": 4 * I + 44 * I + 20 * P + 36 * N,
+    }[name]
+
+
+def cpu_baseline(cfg):
+    """Times the CPU oracle (a PORT: there is no reference CPU path for gsplat/sgutils) on ONE view of
+    the same workload, forward + backward, on the host cores."""
+    from oracle import cref, shade_ref
+
+    threads = os.cpu_count() or 1
+    torch.set_num_threads(threads)
+    n_views, dt = 4, 0.0
+    for v in range(n_views):
+        t = make_inputs(dict(cfg, views_per_gpu=1), "cpu", rank=v)
+        t0 = time.perf_counter()
+        _cpu_view(t, cfg, cref, shade_ref)
+        dt += time.perf_counter() - t0
+    return {"value": n_views / dt, "unit": "views/s", "cores": threads, "kind": "port",
+            "sample": f"{n_views} full views (250k Gaussians, 2048x1334, env relight) fwd+bwd through oracle/ "
+                      f"(C + OpenMP projection/raster, torch shading tail) in {dt:.1f} s"}
+
+
+def _cpu_view(t, cfg, cref, shade_ref):
+    H, W = cfg["height"], cfg["width"]
+    preds = shade_ref.shade(t["f_vn"], t["f_vc"], t["postex"], t["tn"], t["albedo"], t["light_sh"], t["campos"],
+                            envmips=t["mips"], lightrot=t["lightrot"])
+    means, scales, quats = preds["primpos"][0].detach(), preds["primscale"][0].detach(), preds["primqvec"][0].detach()
+    K, vm = t["K"][0], t["Rt"][0]
+    fx, fy, cx, cy = float(K[0, 0]), float(K[1, 1]), float(K[0, 2]), float(K[1, 2])
+    xys, depths, radii, conics, comp, nth, cov3d = cref.project_gaussians(means, scales, 1.0, quats, vm, fx, fy, cx,
+                                                                           cy, H, W, 16, 0.1)
+    _, ids, bins = cref.bin_and_sort(xys, depths, radii, nth, H, W, 16)
+    opac = (preds["opacity"][0, :, 0].detach() * comp).contiguous()
+    col4 = torch.cat([preds["color"][0].detach(), depths[:, None]], 1).contiguous()  # colour + depth in one pass
+    bg = torch.zeros(4)
+    img, Ts, idx = cref.rasterize_forward(ids, bins, xys, conics, col4, opac, H, W, 16, bg)
+    v_out = torch.zeros(H, W, 4)
+    v_out[..., :3] = torch.sign(img[..., :3] - t["target"][0].permute(1, 2, 0)) / (3 * H * W)
+    v_xy, v_conic, v_col, v_op = cref.rasterize_backward(ids, bins, xys, conics, col4, opac, H, W, 16, bg, Ts, idx, v_out)
+    v_comp = v_op[:, 0] * preds["opacity"][0, :, 0].detach()
+    _, _, v_mean, v_scale, v_quat = cref.project_gaussians_backward(means, scales, 1.0, quats, vm, fx, fy, cov3d,
+                                                                    radii, conics, comp, v_xy, v_col[:, 3].contiguous(),
+                                                                    v_conic, v_comp)
+    (preds["primpos"][0] * v_mean).sum().add((preds["primscale"][0] * v_scale).sum()).add(
+        (preds["primqvec"][0] * v_quat).sum()).add((preds["color"][0] * v_col[:, :3]).sum()).add(
+        (preds["opacity"][0, :, 0] * v_op[:, 0] * comp).sum()).backward()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--views", type=int, default=CFG["views_per_gpu"])
+    args = ap.parse_args()
+    cfg = dict(CFG, views_per_gpu=args.views)
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+    from goliath_amd import _lib, splat
+
+    t = make_inputs(cfg, dev, rank)
+    B, N = cfg["views_per_gpu"], cfg["gaussians"]
+    P = cfg["height"] * cfg["width"]
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step(t, cfg, world)
+    barrier()
+    _lib.TIMING = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(t, cfg, world)
+    barrier()
+    dt = time.perf_counter() - t0
+    timing, _lib.TIMING = _lib.TIMING, None
+    splat.PLANNER.poll(block=True)  # raises if any step overflowed its intersection capacity
+
+    if world > 1:
+        import torch.distributed as dist
+
+        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax)
+    per_call = {}
+    for name, e0, e1 in timing:
+        per_call.setdefault(name, []).append(e0.elapsed_time(e1))
+    kernels_ms = {k: sum(v) / len(v) for k, v in per_call.items()}
+
+    if rank == 0:
+        # measured intersection count (determines the raster/sort work)
+        with torch.no_grad():
+            from goliath_amd import render_gs, shade
+
+            preds = shade.shading_tail(t["f_vn"], t["f_vc"], t["postex"], t["tn"], t["albedo"], t["light_sh"],
+                                       t["campos"], preconv_envmap=t["mips"], lightrot=t["lightrot"])
+            intr = torch.stack([t["K"][:, 0, 0], t["K"][:, 1, 1], t["K"][:, 0, 2], t["K"][:, 1, 2]], -1)
+            out = splat.render_views(preds["primpos"], preds["primscale"], preds["primqvec"], preds["opacity"],
+                                     preds["color"], t["Rt"], intr, cfg["height"], cfg["width"])
+            I = float(out["n_isect"].float().mean())
+            mean_alpha = float(out["alpha"].mean())
+        dom = max(kernels_ms, key=kernels_ms.get)
+        mip_bytes = sum(m[0].numel() * 4 for m in t["mips"])
+        ach = B * algorithmic_bytes(dom, N, I, P, mip_bytes) / (kernels_ms[dom] * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            traffic = json.load(open(tpath)).get(dom)
+        views = B * world * args.steps
+        res = {
+            "metric": "relit views/sec (fwd+bwd) at 2048x1334, 250k Gaussians",
+            "value": views / dt, "unit": "views/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": cfg["workload"], "gaussians": N, "image": [cfg["height"], cfg["width"]],
+                       "views_per_gpu": B, "relight": "envmap_4mips", "intersections_per_view": I,
+                       "mean_alpha": mean_alpha, "parallelism": f"view-parallel x{world}"},
+            "kernels_ms_per_call": kernels_ms,
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": ach / HBM_PEAK_GBS, "traffic": traffic},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(cfg)
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

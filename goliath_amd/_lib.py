@@ -77,9 +77,19 @@ def stream_ptr():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+TIMING = None  # set to a list to record (name, start_event, end_event) around every ABI call
+
+
 def call(fn_name, *args):
     lib = load()
-    rc = getattr(lib, fn_name)(*args)
+    if TIMING is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()  # current stream == the stream the kernels are launched on (stream_ptr())
+        rc = getattr(lib, fn_name)(*args)
+        e1.record()
+        TIMING.append((fn_name, e0, e1))
+    else:
+        rc = getattr(lib, fn_name)(*args)
     if rc != 0:
         raise GoliathHipError(f"{fn_name} failed ({rc}): {lib.gol_last_error().decode()}")
 

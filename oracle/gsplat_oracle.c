@@ -89,6 +89,7 @@ void orc_project_fwd(int N, const float* means, const float* scales, float glob_
                      float* compensation, int32_t* num_tiles_hit) {
   const int tiles_x = (img_w + block - 1) / block, tiles_y = (img_h + block - 1) / block;
   const float* V = viewmat;
+#pragma omp parallel for schedule(static)
   for (int i = 0; i < N; ++i) {
     radii[i] = 0;
     num_tiles_hit[i] = 0;
@@ -247,6 +248,7 @@ void orc_rasterize_bwd(int img_h, int img_w, int block, int C, int N, const int3
   double* aco = (double*)calloc((size_t)N * 3, sizeof(double));
   double* acl = (double*)calloc((size_t)N * C, sizeof(double));
   double* aop = (double*)calloc((size_t)N, sizeof(double));
+#pragma omp parallel for schedule(dynamic, 4)
   for (int i = 0; i < img_h; ++i) {
     float buffer[16];
     for (int j = 0; j < img_w; ++j) {
@@ -276,6 +278,8 @@ void orc_rasterize_bwd(int img_h, int img_w, int block, int C, int N, const int3
         float v_alpha = 0.f;
         for (int c = 0; c < C; ++c) {
           float col = colors[(size_t)C * g + c];
+          
+#pragma omp atomic
           acl[(size_t)C * g + c] += (double)(fac * vo[c]);
           v_alpha += (col * T - buffer[c] * ra) * vo[c];
           v_alpha += -T_final * ra * background[c] * vo[c];
@@ -283,12 +287,24 @@ void orc_rasterize_bwd(int img_h, int img_w, int block, int C, int N, const int3
         }
         v_alpha += T_final * ra * voa;
         float v_sigma = -opac * vis * v_alpha;
-        aco[3 * g + 0] += (double)(0.5f * v_sigma * dx * dx);
-        aco[3 * g + 1] += (double)(v_sigma * dx * dy);
-        aco[3 * g + 2] += (double)(0.5f * v_sigma * dy * dy);
-        axy[2 * g + 0] += (double)(v_sigma * (ca * dx + cb * dy));
-        axy[2 * g + 1] += (double)(v_sigma * (cb * dx + cc * dy));
-        aop[g] += (double)(vis * v_alpha);
+        
+#pragma omp atomic
+          aco[3 * g + 0] += (double)(0.5f * v_sigma * dx * dx);
+        
+#pragma omp atomic
+          aco[3 * g + 1] += (double)(v_sigma * dx * dy);
+        
+#pragma omp atomic
+          aco[3 * g + 2] += (double)(0.5f * v_sigma * dy * dy);
+        
+#pragma omp atomic
+          axy[2 * g + 0] += (double)(v_sigma * (ca * dx + cb * dy));
+        
+#pragma omp atomic
+          axy[2 * g + 1] += (double)(v_sigma * (cb * dx + cc * dy));
+        
+#pragma omp atomic
+          aop[g] += (double)(vis * v_alpha);
       }
     }
   }
@@ -314,6 +330,7 @@ void orc_project_bwd(int N, const float* means, const float* scales, float glob_
                      const float* v_conic, const float* v_compensation, float* v_cov2d,
                      float* v_cov3d, float* v_mean3d, float* v_scale, float* v_quat) {
   const float* V = viewmat;
+#pragma omp parallel for schedule(static)
   for (int i = 0; i < N; ++i) {
     if (radii[i] <= 0) continue;
     const float* p = means + 3 * i;
