@@ -8,6 +8,9 @@
 //     per-tile cursor), then every tile sorts ITS list inside LDS (one workgroup per tile);
 //   * the sort key is (depth bits << 32 | gaussian id): the same front-to-back order as gsplat's
 //     (tile << 32 | depth) global sort, with ties broken deterministically by Gaussian id.
+//   * (Gaussian, tile) pairs that cannot reach alpha >= 1/255 anywhere in the tile are dropped at
+//     binning time (output-preserving, see tile_box) and the per-tile counters live in LDS during
+//     the two walks over the Gaussians, so hot tiles do not serialise on global atomics.
 // Traffic: 8 B written + 8 B read + 4 B written per intersection, everything else stays in LDS.
 #include "gol_common.h"
 
@@ -15,32 +18,152 @@ namespace {
 
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return min(max(v, lo), hi); }
 
-__device__ __forceinline__ void tile_bbox(float cx, float cy, float radius, int tiles_x, int tiles_y,
-                                          float inv_block, int& x0, int& x1, int& y0, int& y1) {
-  const float tcx = cx * inv_block, tcy = cy * inv_block, tr = radius * inv_block;
-  x0 = clampi((int)(tcx - tr), 0, tiles_x);
-  x1 = clampi((int)(tcx + tr + 1.f), 0, tiles_x);
-  y0 = clampi((int)(tcy - tr), 0, tiles_y);
-  y1 = clampi((int)(tcy + tr + 1.f), 0, tiles_y);
+struct TileBox { int x0, x1, y0, y1; };  // [x0,x1) x [y0,y1) in tile units
+
+// gsplat's tile bbox (square of the 3-sigma radius, C (int) truncation), optionally
+// intersected with the tiles that the alpha >= 1/255 ellipse of the Gaussian can reach.  The
+// second test never changes an image or a gradient: a (Gaussian, tile) pair it removes would be
+// skipped for every pixel of the tile by the rasterizer's alpha < 1/255 test (A.3) -- it only
+// removes dead entries from the lists (about half of them for anisotropic splats).
+__device__ __forceinline__ TileBox tile_box(float gx, float gy, float radius, int tiles_x, int tiles_y,
+                                            float inv_block, float block, bool tight, float ca, float cb,
+                                            float cc, float op) {
+  TileBox t;
+  const float tcx = gx * inv_block, tcy = gy * inv_block, tr = radius * inv_block;
+  t.x0 = clampi((int)(tcx - tr), 0, tiles_x);
+  t.x1 = clampi((int)(tcx + tr + 1.f), 0, tiles_x);
+  t.y0 = clampi((int)(tcy - tr), 0, tiles_y);
+  t.y1 = clampi((int)(tcy + tr + 1.f), 0, tiles_y);
+  if (tight) {
+    const float k = 255.f * op;
+    if (!(k > 1.f)) { t.x1 = t.x0; return t; }  // alpha < 1/255 everywhere
+    const float det = ca * cc - cb * cb;
+    if (det > 0.f && ca > 0.f && cc > 0.f) {
+      const float tau2 = 2.f * (__logf(k) * 1.001f + 1e-3f);
+      const float hx = sqrtf(tau2 * cc / det) + 0.02f, hy = sqrtf(tau2 * ca / det) + 0.02f;
+      if (hx < 1e30f && hy < 1e30f) {
+        // tile tx holds pixel centres [block*tx + 0.5, block*tx + block - 0.5]
+        const float lo_x = ceilf((gx - hx - (block - 0.5f)) * inv_block), hi_x = floorf((gx + hx - 0.5f) * inv_block);
+        const float lo_y = ceilf((gy - hy - (block - 0.5f)) * inv_block), hi_y = floorf((gy + hy - 0.5f) * inv_block);
+        t.x0 = max(t.x0, (int)fmaxf(lo_x, 0.f));
+        t.y0 = max(t.y0, (int)fmaxf(lo_y, 0.f));
+        t.x1 = min(t.x1, (int)fminf(hi_x, (float)tiles_x) + 1);
+        t.y1 = min(t.y1, (int)fminf(hi_y, (float)tiles_y) + 1);
+        if (t.x1 < t.x0) t.x1 = t.x0;
+        if (t.y1 < t.y0) t.y1 = t.y0;
+      }
+    }
+  }
+  return t;
 }
 
-// pass 1: per-tile intersection counts
-__global__ __launch_bounds__(256) void count_kernel(int N, const float* __restrict__ xys,
-                                                     const int32_t* __restrict__ radii, int tiles_x,
-                                                     int tiles_y, float inv_block,
-                                                     int32_t* __restrict__ tile_count) {
+struct BinArgs {
+  int N, tiles_x, tiles_y, chunk;
+  float inv_block, block;
+  const float* xys; const float* depths; const int32_t* radii; const float* conics; const float* opacities;
+};
+
+__device__ __forceinline__ TileBox box_of(const BinArgs& a, size_t e) {
+  const int r = a.radii[e];
+  if (r <= 0) return TileBox{0, 0, 0, 0};
+  const float2 c = *reinterpret_cast<const float2*>(a.xys + 2 * e);
+  const bool tight = a.conics != nullptr;
+  float ca = 0.f, cb = 0.f, cc = 0.f, op = 1.f;
+  if (tight) { ca = a.conics[3 * e]; cb = a.conics[3 * e + 1]; cc = a.conics[3 * e + 2]; op = a.opacities[e]; }
+  return tile_box(c.x, c.y, (float)r, a.tiles_x, a.tiles_y, a.inv_block, a.block, tight, ca, cb, cc, op);
+}
+
+// ---- pass 1: per-tile intersection counts ------------------------------------------------------
+// One 1024-thread workgroup walks a chunk of Gaussians and histograms their tiles in LDS (one int
+// per tile of the view, ds_add_u32), then flushes the non-zero bins with ONE global atomic each:
+// same-address global atomics drop by the chunk's multiplicity (~20x at 4096 Gaussians/chunk).
+__global__ __launch_bounds__(1024) void count_lds_kernel(BinArgs a, int32_t* __restrict__ tile_count) {
+  extern __shared__ int32_t s_cnt[];
+  const int b = blockIdx.y, T = a.tiles_x * a.tiles_y;
+  for (int t = threadIdx.x; t < T; t += 1024) s_cnt[t] = 0;
+  __syncthreads();
+  const int i_end = min(a.N, (int)(blockIdx.x + 1) * a.chunk);
+  for (int i = blockIdx.x * a.chunk + threadIdx.x; i < i_end; i += 1024) {
+    const TileBox tb = box_of(a, (size_t)b * a.N + i);
+    for (int y = tb.y0; y < tb.y1; ++y)
+      for (int x = tb.x0; x < tb.x1; ++x) atomicAdd(&s_cnt[y * a.tiles_x + x], 1);
+  }
+  __syncthreads();
+  int32_t* tc = tile_count + (size_t)b * T;
+  for (int t = threadIdx.x; t < T; t += 1024) {
+    const int c = s_cnt[t];
+    if (c) atomicAdd(tc + t, c);
+  }
+}
+
+// ---- pass 3: scatter (depth bits, id) into the tile segments -----------------------------------
+// Same LDS histogram; each workgroup then reserves a contiguous range per tile with one returning
+// global atomic and hands out slots inside it with LDS atomics.
+__global__ __launch_bounds__(1024) void scatter_lds_kernel(BinArgs a, int64_t capacity,
+                                                           int32_t* __restrict__ tile_bins,
+                                                           uint64_t* __restrict__ isect_keys) {
+  extern __shared__ int32_t s_mem[];
+  const int b = blockIdx.y, T = a.tiles_x * a.tiles_y;
+  int32_t* s_cnt = s_mem;
+  int32_t* s_base = s_mem + T;
+  for (int t = threadIdx.x; t < T; t += 1024) s_cnt[t] = 0;
+  __syncthreads();
+  const int i_begin = blockIdx.x * a.chunk + threadIdx.x, i_end = min(a.N, (int)(blockIdx.x + 1) * a.chunk);
+  for (int i = i_begin; i < i_end; i += 1024) {
+    const TileBox tb = box_of(a, (size_t)b * a.N + i);
+    for (int y = tb.y0; y < tb.y1; ++y)
+      for (int x = tb.x0; x < tb.x1; ++x) atomicAdd(&s_cnt[y * a.tiles_x + x], 1);
+  }
+  __syncthreads();
+  int32_t* bins = tile_bins + (size_t)b * T * 2;
+  for (int t = threadIdx.x; t < T; t += 1024) {
+    const int c = s_cnt[t];
+    if (c) s_base[t] = atomicAdd(bins + 2 * t + 1, c);
+    s_cnt[t] = 0;
+  }
+  __syncthreads();
+  uint64_t* keys = isect_keys + (size_t)b * capacity;
+  for (int i = i_begin; i < i_end; i += 1024) {
+    const size_t e = (size_t)b * a.N + i;
+    const TileBox tb = box_of(a, e);
+    if (tb.x1 <= tb.x0 || tb.y1 <= tb.y0) continue;
+    const uint64_t key = ((uint64_t)__float_as_uint(a.depths[e]) << 32) | (uint32_t)i;
+    for (int y = tb.y0; y < tb.y1; ++y)
+      for (int x = tb.x0; x < tb.x1; ++x) {
+        const int t = y * a.tiles_x + x;
+        const int slot = s_base[t] + atomicAdd(&s_cnt[t], 1);
+        if (slot < capacity) keys[slot] = key;
+      }
+  }
+}
+
+// ---- fallbacks for images with more tiles than fit in LDS: direct global atomics ----------------
+__global__ __launch_bounds__(256) void count_kernel(BinArgs a, int32_t* __restrict__ tile_count) {
   const int b = blockIdx.y;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= N) return;
-  const size_t e = (size_t)b * N + i;
-  const int r = radii[e];
-  if (r <= 0) return;
-  const float2 c = *reinterpret_cast<const float2*>(xys + 2 * e);
-  int x0, x1, y0, y1;
-  tile_bbox(c.x, c.y, (float)r, tiles_x, tiles_y, inv_block, x0, x1, y0, y1);
-  int32_t* tc = tile_count + (size_t)b * tiles_x * tiles_y;
-  for (int y = y0; y < y1; ++y)
-    for (int x = x0; x < x1; ++x) atomicAdd(tc + y * tiles_x + x, 1);
+  if (i >= a.N) return;
+  const TileBox tb = box_of(a, (size_t)b * a.N + i);
+  int32_t* tc = tile_count + (size_t)b * a.tiles_x * a.tiles_y;
+  for (int y = tb.y0; y < tb.y1; ++y)
+    for (int x = tb.x0; x < tb.x1; ++x) atomicAdd(tc + y * a.tiles_x + x, 1);
+}
+
+__global__ __launch_bounds__(256) void scatter_kernel(BinArgs a, int64_t capacity, int32_t* __restrict__ tile_bins,
+                                                       uint64_t* __restrict__ isect_keys) {
+  const int b = blockIdx.y;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= a.N) return;
+  const size_t e = (size_t)b * a.N + i;
+  const TileBox tb = box_of(a, e);
+  if (tb.x1 <= tb.x0 || tb.y1 <= tb.y0) return;
+  const uint64_t key = ((uint64_t)__float_as_uint(a.depths[e]) << 32) | (uint32_t)i;
+  int32_t* bins = tile_bins + (size_t)b * a.tiles_x * a.tiles_y * 2;
+  uint64_t* keys = isect_keys + (size_t)b * capacity;
+  for (int y = tb.y0; y < tb.y1; ++y)
+    for (int x = tb.x0; x < tb.x1; ++x) {
+      const int slot = atomicAdd(bins + 2 * (y * a.tiles_x + x) + 1, 1);
+      if (slot < capacity) keys[slot] = key;
+    }
 }
 
 // pass 2: exclusive scan of the T tile counts of one view (one 1024-thread workgroup per view);
@@ -83,32 +206,6 @@ __global__ __launch_bounds__(1024) void scan_kernel(int T, const int32_t* __rest
     __syncthreads();
   }
   if (tid == 0) n_isect[b] = carry_s;
-}
-
-// pass 3: scatter (depth bits, id) into the tile segments
-__global__ __launch_bounds__(256) void scatter_kernel(int N, const float* __restrict__ xys,
-                                                       const float* __restrict__ depths,
-                                                       const int32_t* __restrict__ radii, int tiles_x,
-                                                       int tiles_y, float inv_block, int64_t capacity,
-                                                       int32_t* __restrict__ tile_bins,
-                                                       uint64_t* __restrict__ isect_keys) {
-  const int b = blockIdx.y;
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= N) return;
-  const size_t e = (size_t)b * N + i;
-  const int r = radii[e];
-  if (r <= 0) return;
-  const float2 c = *reinterpret_cast<const float2*>(xys + 2 * e);
-  int x0, x1, y0, y1;
-  tile_bbox(c.x, c.y, (float)r, tiles_x, tiles_y, inv_block, x0, x1, y0, y1);
-  const uint64_t key = ((uint64_t)__float_as_uint(depths[e]) << 32) | (uint32_t)i;
-  int32_t* bins = tile_bins + (size_t)b * tiles_x * tiles_y * 2;
-  uint64_t* keys = isect_keys + (size_t)b * capacity;
-  for (int y = y0; y < y1; ++y)
-    for (int x = x0; x < x1; ++x) {
-      const int slot = atomicAdd(bins + 2 * (y * tiles_x + x) + 1, 1);
-      if (slot < capacity) keys[slot] = key;
-    }
 }
 
 // pass 4: one workgroup per tile sorts its list.  Bitonic network in the "all-ascending" form
@@ -175,9 +272,9 @@ __global__ __launch_bounds__(256) void sort_kernel(int T, int64_t capacity, int3
 }  // namespace
 
 extern "C" int gol_bin_sort(int B, int N, const float* xys, const float* depths, const int32_t* radii,
-                            int img_h, int img_w, int block, int64_t capacity, int32_t* tile_count,
-                            int count_done, int32_t* tile_bins, uint64_t* isect_keys, int32_t* sorted_ids,
-                            int32_t* n_isect, void* stream) {
+                            const float* conics, const float* opacities, int img_h, int img_w, int block,
+                            int64_t capacity, int32_t* tile_count, int32_t* tile_bins, uint64_t* isect_keys,
+                            int32_t* sorted_ids, int32_t* n_isect, void* stream) {
   GOL_REQUIRE(B >= 0 && N >= 0, "negative size");
   GOL_REQUIRE(block > 1 && block <= 16, "block_width must be between 2 and 16");
   GOL_REQUIRE(img_h > 0 && img_w > 0, "empty image");
@@ -186,25 +283,46 @@ extern "C" int gol_bin_sort(int B, int N, const float* xys, const float* depths,
   GOL_REQUIRE(B <= 65535, "B > 65535");
   GOL_REQUIRE(tile_count && tile_bins && n_isect, "null workspace");
   GOL_REQUIRE(N == 0 || (xys && depths && radii), "null input");
+  GOL_REQUIRE((conics == nullptr) == (opacities == nullptr), "conics and opacities go together");
   GOL_REQUIRE(capacity == 0 || (isect_keys && sorted_ids), "null intersection buffers");
   hipStream_t s = (hipStream_t)stream;
-  const int tiles_x = (img_w + block - 1) / block, tiles_y = (img_h + block - 1) / block;
-  const int T = tiles_x * tiles_y;
-  const float inv_block = 1.f / (float)block;
-  dim3 ggrid(gol_cdiv(N > 0 ? N : 1, 256), B);
-  if (!count_done) {
-    if (hipMemsetAsync(tile_count, 0, sizeof(int32_t) * (size_t)B * T, s) != hipSuccess) {
-      gol_set_error("gol_bin_sort: hipMemsetAsync failed");
-      return GOL_ERR_LAUNCH;
+  BinArgs a;
+  a.N = N;
+  a.tiles_x = (img_w + block - 1) / block;
+  a.tiles_y = (img_h + block - 1) / block;
+  a.inv_block = 1.f / (float)block;
+  a.block = (float)block;
+  a.xys = xys; a.depths = depths; a.radii = radii; a.conics = conics; a.opacities = opacities;
+  const int T = a.tiles_x * a.tiles_y;
+  // chunk of Gaussians per 1024-thread workgroup: ~512 workgroups over all views, >= 1024 each
+  int per_view = gol_cdiv(512, B);
+  a.chunk = N > 0 ? gol_cdiv(N, per_view) : 1;
+  if (a.chunk < 1024) a.chunk = 1024;
+  const int nblk = N > 0 ? gol_cdiv(N, a.chunk) : 1;
+  const bool lds_path = (size_t)T * 8 <= 128 * 1024;
+  if (hipMemsetAsync(tile_count, 0, sizeof(int32_t) * (size_t)B * T, s) != hipSuccess) {
+    gol_set_error("gol_bin_sort: hipMemsetAsync failed");
+    return GOL_ERR_LAUNCH;
+  }
+  if (N > 0) {
+    if (lds_path) {
+      const size_t lds = sizeof(int32_t) * (size_t)T;
+      if (lds > 48 * 1024) hipFuncSetAttribute((const void*)count_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      count_lds_kernel<<<dim3(nblk, B), 1024, lds, s>>>(a, tile_count);
+    } else {
+      count_kernel<<<dim3(gol_cdiv(N, 256), B), 256, 0, s>>>(a, tile_count);
     }
-    if (N > 0) count_kernel<<<ggrid, 256, 0, s>>>(N, xys, radii, tiles_x, tiles_y, inv_block, tile_count);
   }
   scan_kernel<<<B, 1024, 0, s>>>(T, tile_count, tile_bins, n_isect);
   if (N > 0 && capacity > 0) {
-    scatter_kernel<<<ggrid, 256, 0, s>>>(N, xys, depths, radii, tiles_x, tiles_y, inv_block, capacity, tile_bins,
-                                         isect_keys);
-    dim3 sgrid(T, B);
-    sort_kernel<<<sgrid, 256, 0, s>>>(T, capacity, tile_bins, isect_keys, sorted_ids);
+    if (lds_path) {
+      const size_t lds = sizeof(int32_t) * (size_t)T * 2;
+      if (lds > 48 * 1024) hipFuncSetAttribute((const void*)scatter_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      scatter_lds_kernel<<<dim3(nblk, B), 1024, lds, s>>>(a, capacity, tile_bins, isect_keys);
+    } else {
+      scatter_kernel<<<dim3(gol_cdiv(N, 256), B), 256, 0, s>>>(a, capacity, tile_bins, isect_keys);
+    }
+    sort_kernel<<<dim3(T, B), 256, 0, s>>>(T, capacity, tile_bins, isect_keys, sorted_ids);
   }
   GOL_CHECK_LAUNCH();
   return GOL_OK;

@@ -50,6 +50,38 @@ __device__ __forceinline__ float gol_dpp_mov0(float v) {
       float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, BANK_MASK, false));
 }
 
+// sums of the four 16-lane rows, valid in lanes 15, 31, 47, 63 (4 fused v_add_f32_dpp)
+__device__ __forceinline__ float gol_row_sum_to_lane15(float v) {
+  v += gol_dpp_mov0<0x111>(v);  // row_shr:1
+  v += gol_dpp_mov0<0x112>(v);  // row_shr:2
+  v += gol_dpp_mov0<0x114>(v);  // row_shr:4
+  v += gol_dpp_mov0<0x118>(v);  // row_shr:8
+  return v;
+}
+
+// Four wave-wide sums for the price of ~1.5: gfx950's v_permlane32_swap / v_permlane16_swap fold
+// two registers into one per step (upper half of x <-> lower half of y, then odd rows <-> even
+// rows), so 64-lane sums of (a, b, c, d) cost 3 swaps + 3 adds + 4 DPP row adds = 10 instructions
+// instead of 4 x 6.  Results: lane 15 = sum(a), lane 31 = sum(b), lane 47 = sum(c), lane 63 = sum(d).
+__device__ __forceinline__ float gol_swap32_sum(float x, float y) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, x), __builtin_bit_cast(unsigned, y),
+                                                  false, false);
+  const unsigned r0 = r[0], r1 = r[1];  // (bit_cast straight from a vector element miscompiles)
+  return __uint_as_float(r0) + __uint_as_float(r1);  // [x_lo+x_hi | y_lo+y_hi]
+}
+__device__ __forceinline__ float gol_swap16_sum(float x, float y) {
+  const auto r = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, x), __builtin_bit_cast(unsigned, y),
+                                                  false, false);
+  const unsigned r0 = r[0], r1 = r[1];
+  return __uint_as_float(r0) + __uint_as_float(r1);  // rows [x01, y01, x23, y23]
+}
+__device__ __forceinline__ float gol_wave_sum4(float a, float b, float c, float d) {
+  const float ac = gol_swap32_sum(a, c);   // lower 32 lanes: a, upper 32: c
+  const float bd = gol_swap32_sum(b, d);   // lower: b, upper: d
+  const float q = gol_swap16_sum(ac, bd);  // rows: a, b, c, d
+  return gol_row_sum_to_lane15(q);
+}
+
 // returns the wave-wide sum in lane 63 (other lanes hold partial sums)
 __device__ __forceinline__ float gol_wave_sum_to_lane63(float v) {
   v += gol_dpp_mov0<0x111>(v);              // row_shr:1

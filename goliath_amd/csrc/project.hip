@@ -52,7 +52,7 @@ __global__ __launch_bounds__(256) void project_fwd_kernel(
     float* __restrict__ cov3d, float* __restrict__ xys, float* __restrict__ depths,
     int32_t* __restrict__ radii, float* __restrict__ conics, float* __restrict__ compensation,
     int32_t* __restrict__ num_tiles_hit, const float* __restrict__ opacities,
-    float* __restrict__ opac_eff, int32_t* __restrict__ tile_count) {
+    float* __restrict__ opac_eff) {
   const int b = blockIdx.y;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= N) return;
@@ -122,11 +122,6 @@ __global__ __launch_bounds__(256) void project_fwd_kernel(
   compensation[e] = o_comp;
   num_tiles_hit[e] = o_tiles;
   if (opac_eff) opac_eff[e] = opacities[e] * o_comp;
-  if (tile_count && o_tiles > 0) {
-    int32_t* tc = tile_count + (size_t)b * tiles_x * tiles_y;
-    for (int y = by0; y < by1; ++y)
-      for (int x = bx0; x < bx1; ++x) atomicAdd(tc + y * tiles_x + x, 1);
-  }
 }
 
 __global__ __launch_bounds__(256) void project_bwd_kernel(
@@ -250,8 +245,7 @@ extern "C" int gol_project_fwd(int B, int N, const float* means3d, const float* 
                                const float* quats, const float* viewmats, const float* intrins, int img_h,
                                int img_w, int block, float clip_thresh, float* cov3d, float* xys,
                                float* depths, int32_t* radii, float* conics, float* compensation,
-                               int32_t* num_tiles_hit, const float* opacities, float* opac_eff,
-                               int32_t* tile_count, void* stream) {
+                               int32_t* num_tiles_hit, const float* opacities, float* opac_eff, void* stream) {
   GOL_REQUIRE(B >= 0 && N >= 0, "negative size");
   GOL_REQUIRE(block > 1 && block <= 16, "block_width must be between 2 and 16");
   GOL_REQUIRE(img_h > 0 && img_w > 0, "empty image");
@@ -263,7 +257,7 @@ extern "C" int gol_project_fwd(int B, int N, const float* means3d, const float* 
   dim3 grid(gol_cdiv(N, 256), B);
   project_fwd_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(
       N, means3d, scales, glob_scale, quats, viewmats, intrins, img_h, img_w, block, clip_thresh, cov3d, xys,
-      depths, radii, conics, compensation, num_tiles_hit, opacities, opac_eff, tile_count);
+      depths, radii, conics, compensation, num_tiles_hit, opacities, opac_eff);
   GOL_CHECK_LAUNCH();
   return GOL_OK;
 }

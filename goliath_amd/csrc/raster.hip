@@ -12,8 +12,9 @@
 //     quadrant -- gsplat's 3-sigma tile bbox is far looser than the 1/255 cut;
 //   * colour and the optional 4th "extra" channel (depth) are composited in ONE pass instead of
 //     the reference's two rasterize calls (render_gsplat.py:65-104);
-//   * backward: per-Gaussian gradients are reduced over the 64 lanes with DPP row/bcast adds (no
-//     LDS), merged across the 4 waves with ds_add_f32 into a per-batch LDS accumulator, and leave
+//   * backward: per-Gaussian gradients are reduced over the 64 lanes four-at-a-time with
+//     v_permlane32_swap / v_permlane16_swap + DPP row adds (10 instructions per 4 sums, no LDS, no
+//     atomics), parked in per-wave LDS slots, merged across the 4 waves once per batch and leave
 //     the workgroup as ONE global atomic per Gaussian per tile per component (gsplat: one per
 //     32-lane warp => 8x more).
 //   * tile -> workgroup mapping is XCD-chunked (blockIdx % 8 selects an eighth of the image) so a
@@ -70,7 +71,8 @@ __global__ __launch_bounds__(256) void raster_fwd_kernel(
     float* __restrict__ out_extra, float* __restrict__ final_Ts, int32_t* __restrict__ final_idx) {
   __shared__ float4 s_a[kBatch];  // x, y, conic.a, conic.b
   __shared__ float4 s_b[kBatch];  // conic.c, opacity, r, g
-  __shared__ float4 s_c[kBatch];  // b, extra, quadrant mask (int bits), -
+  __shared__ float2 s_c[kBatch];  // b, extra
+  __shared__ int32_t s_mask[kBatch];  // quadrant mask
   const int T = tiles_x * tiles_y;
   const TileCoord tc = tile_of_block(blockIdx.x, T, tiles_x);
   if (!tc.ok) return;
@@ -105,31 +107,39 @@ __global__ __launch_bounds__(256) void raster_fwd_kernel(
       const int qm = quadrant_mask(xy.x, xy.y, ca, cb, cc, op, (float)(tc.tx * 16), (float)(tc.ty * 16));
       s_a[tid] = make_float4(xy.x, xy.y, ca, cb);
       s_b[tid] = make_float4(cc, op, r, gg);
-      s_c[tid] = make_float4(bl, ex, __int_as_float(qm), 0.f);
+      s_c[tid] = make_float2(bl, ex);
+      s_mask[tid] = qm;
+    } else {
+      s_mask[tid] = 0;
     }
     __syncthreads();
     const int batch_size = min(kBatch, range.y - batch_start);
-    for (int t = 0; t < batch_size; ++t) {
-      if (__ballot(!done) == 0ull) break;  // this wave's quadrant is finished
-      const float4 c4 = s_c[t];
-      const int qm = __builtin_amdgcn_readfirstlane(__float_as_int(c4.z));
-      if (!((qm >> wave) & 1)) continue;  // wave-uniform cull
-      const float4 a4 = s_a[t];
-      const float4 b4 = s_b[t];
-      if (!done) {
-        const float dx = a4.x - px, dy = a4.y - py;
-        const float sigma = 0.5f * (a4.z * dx * dx + b4.x * dy * dy) + a4.w * dx * dy;
-        const float alpha = fminf(GOL_ALPHA_CAP_FWD, b4.y * __expf(-sigma));
-        if (!(sigma < 0.f || alpha < GOL_ALPHA_FLOOR)) {
-          const float next_T = T_cur * (1.f - alpha);
-          if (next_T <= GOL_T_STOP) {
-            done = true;
-          } else {
-            const float vis = alpha * T_cur;
-            acc0 += b4.z * vis; acc1 += b4.w * vis; acc2 += c4.x * vis;
-            if (EXTRA) acc3 += c4.y * vis;
-            T_cur = next_T;
-            cur_idx = batch_start + t;
+    // Each wave walks ONLY the entries whose alpha >= 1/255 box touches its quadrant: one ballot per
+    // 64 entries, then a scalar loop over the set bits (s_ff1) -- culled entries cost nothing.
+    for (int chunk = 0; chunk < batch_size; chunk += 64) {
+      unsigned long long bits = __ballot((s_mask[chunk + lane] >> wave) & 1);
+      while (bits) {
+        if (__ballot(!done) == 0ull) { chunk = batch_size; break; }  // this wave's quadrant is finished
+        const int t = chunk + __builtin_ctzll(bits);
+        bits &= bits - 1;
+        const float4 a4 = s_a[t];
+        const float4 b4 = s_b[t];
+        const float2 c2 = s_c[t];
+        if (!done) {
+          const float dx = a4.x - px, dy = a4.y - py;
+          const float sigma = 0.5f * (a4.z * dx * dx + b4.x * dy * dy) + a4.w * dx * dy;
+          const float alpha = fminf(GOL_ALPHA_CAP_FWD, b4.y * __expf(-sigma));
+          if (!(sigma < 0.f || alpha < GOL_ALPHA_FLOOR)) {
+            const float next_T = T_cur * (1.f - alpha);
+            if (next_T <= GOL_T_STOP) {
+              done = true;
+            } else {
+              const float vis = alpha * T_cur;
+              acc0 += b4.z * vis; acc1 += b4.w * vis; acc2 += c2.x * vis;
+              if (EXTRA) acc3 += c2.y * vis;
+              T_cur = next_T;
+              cur_idx = batch_start + t;
+            }
           }
         }
       }
@@ -147,7 +157,8 @@ __global__ __launch_bounds__(256) void raster_fwd_kernel(
   }
 }
 
-constexpr int kAcc = 10;  // r g b extra Sx Sy Sxx Sxy Syy v_opacity
+constexpr int kBatchB = 128;  // backward batch (smaller: per-wave gradient slots live in LDS)
+constexpr int kAcc = 12;      // r g b v_opacity | Sx Sy Sxx Sxy | Syy extra - -
 
 template <bool EXTRA>
 __global__ __launch_bounds__(256) void raster_bwd_kernel(
@@ -159,12 +170,13 @@ __global__ __launch_bounds__(256) void raster_bwd_kernel(
     const float* __restrict__ v_out_img, const float* __restrict__ v_out_extra,
     const float* __restrict__ v_out_alpha, float* __restrict__ v_xy, float* __restrict__ v_conic,
     float* __restrict__ v_colors, float* __restrict__ v_extra, float* __restrict__ v_opacity) {
-  __shared__ float4 s_a[kBatch];
-  __shared__ float4 s_b[kBatch];
-  __shared__ float4 s_c[kBatch];
-  __shared__ int32_t s_id[kBatch];
-  __shared__ float s_acc[kBatch * kAcc];
-  __shared__ int32_t s_touched[kBatch];
+  __shared__ float4 s_a[kBatchB];
+  __shared__ float4 s_b[kBatchB];
+  __shared__ float2 s_c[kBatchB];
+  __shared__ int32_t s_mask[kBatchB];
+  __shared__ int32_t s_id[kBatchB];
+  __shared__ __attribute__((aligned(16))) float s_acc[4][kBatchB][kAcc];  // per-wave partial sums (no atomics)
+  __shared__ int32_t s_touched[4][kBatchB];
   __shared__ int32_t s_wmax[4];
   const int T = tiles_x * tiles_y;
   const TileCoord tc = tile_of_block(blockIdx.x, T, tiles_x);
@@ -198,96 +210,115 @@ __global__ __launch_bounds__(256) void raster_bwd_kernel(
   int wmax = bin_final;
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) wmax = max(wmax, __shfl_xor(wmax, off, 64));
+  wmax = __builtin_amdgcn_readfirstlane(wmax);  // uniform by construction; tell the compiler
   if (lane == 0) s_wmax[wave] = wmax;
   __syncthreads();
   const int bmax = min(max(max(s_wmax[0], s_wmax[1]), max(s_wmax[2], s_wmax[3])), range.y - 1);
   if (bmax < range.x) return;
 
-  const int n_batches = (bmax - range.x + kBatch) / kBatch;
+  const int n_batches = (bmax - range.x + kBatchB) / kBatchB;
   for (int bb = 0; bb < n_batches; ++bb) {
     __syncthreads();  // previous batch fully consumed
-    const int batch_end = bmax - bb * kBatch;           // list index of slot 0 (furthest back)
-    const int batch_size = min(kBatch, batch_end + 1 - range.x);
-    const int idx = batch_end - tid;
-    if (tid < batch_size) {
-      const int gid = ids[idx];
-      const size_t g = goff + (size_t)gid;
-      const float2 xy = *reinterpret_cast<const float2*>(xys + 2 * g);
-      const float ca = conics[3 * g], cb = conics[3 * g + 1], cc = conics[3 * g + 2];
-      const float op = opacities[g];
-      const float r = colors[3 * g], gg = colors[3 * g + 1], bl = colors[3 * g + 2];
-      const float ex = EXTRA ? extra[g] : 0.f;
-      const int qm = quadrant_mask(xy.x, xy.y, ca, cb, cc, op, (float)(tc.tx * 16), (float)(tc.ty * 16));
-      s_a[tid] = make_float4(xy.x, xy.y, ca, cb);
-      s_b[tid] = make_float4(cc, op, r, gg);
-      s_c[tid] = make_float4(bl, ex, __int_as_float(qm), 0.f);
-      s_id[tid] = gid;
+    const int batch_end = bmax - bb * kBatchB;           // list index of slot 0 (furthest back)
+    const int batch_size = min(kBatchB, batch_end + 1 - range.x);
+    if (tid < kBatchB) {
+      if (tid < batch_size) {
+        const int gid = ids[batch_end - tid];
+        const size_t g = goff + (size_t)gid;
+        const float2 xy = *reinterpret_cast<const float2*>(xys + 2 * g);
+        const float ca = conics[3 * g], cb = conics[3 * g + 1], cc = conics[3 * g + 2];
+        const float op = opacities[g];
+        const float r = colors[3 * g], gg = colors[3 * g + 1], bl = colors[3 * g + 2];
+        const float ex = EXTRA ? extra[g] : 0.f;
+        s_a[tid] = make_float4(xy.x, xy.y, ca, cb);
+        s_b[tid] = make_float4(cc, op, r, gg);
+        s_c[tid] = make_float2(bl, ex);
+        s_mask[tid] = quadrant_mask(xy.x, xy.y, ca, cb, cc, op, (float)(tc.tx * 16), (float)(tc.ty * 16));
+        s_id[tid] = gid;
+      } else {
+        s_mask[tid] = 0;
+      }
     }
-#pragma unroll
-    for (int k = 0; k < kAcc; ++k) s_acc[tid * kAcc + k] = 0.f;
-    s_touched[tid] = 0;
+    if (tid < kBatchB) { s_touched[0][tid] = 0; s_touched[1][tid] = 0; }
+    else { s_touched[2][tid - kBatchB] = 0; s_touched[3][tid - kBatchB] = 0; }
     __syncthreads();
 
     const int t0 = max(0, batch_end - wmax);  // entries behind every pixel of this wave are skipped
-    for (int t = t0; t < batch_size; ++t) {
-      const float4 c4 = s_c[t];
-      const int qm = __builtin_amdgcn_readfirstlane(__float_as_int(c4.z));
-      if (!((qm >> wave) & 1)) continue;
-      const float4 a4 = s_a[t];
-      const float4 b4 = s_b[t];
-      bool valid = (batch_end - t) <= bin_final;
-      const float dx = a4.x - px, dy = a4.y - py;
-      const float sigma = 0.5f * (a4.z * dx * dx + b4.x * dy * dy) + a4.w * dx * dy;
-      const float vis = __expf(-sigma);
-      const float alpha = fminf(GOL_ALPHA_CAP_BWD, b4.y * vis);
-      valid = valid && !(sigma < 0.f || alpha < GOL_ALPHA_FLOOR);
-      if (__ballot(valid) == 0ull) continue;
-      float g0 = 0.f, g1 = 0.f, g2 = 0.f, g3 = 0.f, sx = 0.f, sy = 0.f, sxx = 0.f, sxy = 0.f, syy = 0.f, gop = 0.f;
-      if (valid) {
+    for (int chunk = t0 & ~63; chunk < batch_size; chunk += 64) {
+      unsigned long long bits = __ballot((s_mask[chunk + lane] >> wave) & 1);
+      if (chunk < t0) bits &= ~0ull << (t0 - chunk);
+      while (bits) {
+        const int t = chunk + __builtin_ctzll(bits);
+        bits &= bits - 1;
+        const float4 a4 = s_a[t];
+        const float4 b4 = s_b[t];
+        const float2 c2 = s_c[t];
+        bool valid = (batch_end - t) <= bin_final;
+        const float dx = a4.x - px, dy = a4.y - py;
+        const float sigma = 0.5f * (a4.z * dx * dx + b4.x * dy * dy) + a4.w * dx * dy;
+        const float vis = __expf(-sigma);
+        const float alpha = fminf(GOL_ALPHA_CAP_BWD, b4.y * vis);
+        valid = valid && !(sigma < 0.f || alpha < GOL_ALPHA_FLOOR);
+        if (__ballot(valid) == 0ull) continue;
+        // branch-free: lanes that do not see this Gaussian carry fac = 0 and keep their state
         const float ra = __builtin_amdgcn_rcpf(1.f - alpha);
-        T_cur *= ra;
-        const float fac = alpha * T_cur;
-        g0 = fac * vo0; g1 = fac * vo1; g2 = fac * vo2;
-        float v_alpha = (b4.z * T_cur - buf0 * ra) * vo0 + (b4.w * T_cur - buf1 * ra) * vo1 +
-                        (c4.x * T_cur - buf2 * ra) * vo2;
+        const float T_new = T_cur * ra;
+        const float fac = valid ? alpha * T_new : 0.f;
+        T_cur = valid ? T_new : T_cur;
+        float v_alpha = (b4.z * T_new - buf0 * ra) * vo0 + (b4.w * T_new - buf1 * ra) * vo1 +
+                        (c2.x * T_new - buf2 * ra) * vo2 + T_final * ra * (voa - bgdot);
+        const float g0 = fac * vo0, g1 = fac * vo1, g2 = fac * vo2;
+        float g3 = 0.f;
         if (EXTRA) {
           g3 = fac * vo3;
-          v_alpha += (c4.y * T_cur - buf3 * ra) * vo3;
-          buf3 += c4.y * fac;
+          v_alpha += (c2.y * T_new - buf3 * ra) * vo3;
+          buf3 += c2.y * fac;
         }
-        v_alpha += T_final * ra * (voa - bgdot);
-        buf0 += b4.z * fac; buf1 += b4.w * fac; buf2 += c4.x * fac;
-        const float v_sigma = -b4.y * vis * v_alpha;
-        sx = v_sigma * dx; sy = v_sigma * dy;
-        sxx = sx * dx; sxy = sx * dy; syy = sy * dy;
-        gop = vis * v_alpha;
-      }
-      g0 = gol_wave_sum_to_lane63(g0); g1 = gol_wave_sum_to_lane63(g1); g2 = gol_wave_sum_to_lane63(g2);
-      if (EXTRA) g3 = gol_wave_sum_to_lane63(g3);
-      sx = gol_wave_sum_to_lane63(sx); sy = gol_wave_sum_to_lane63(sy);
-      sxx = gol_wave_sum_to_lane63(sxx); sxy = gol_wave_sum_to_lane63(sxy); syy = gol_wave_sum_to_lane63(syy);
-      gop = gol_wave_sum_to_lane63(gop);
-      if (lane == 63) {
-        float* a = s_acc + t * kAcc;
-        atomicAdd(a + 0, g0); atomicAdd(a + 1, g1); atomicAdd(a + 2, g2);
-        if (EXTRA) atomicAdd(a + 3, g3);
-        atomicAdd(a + 4, sx); atomicAdd(a + 5, sy); atomicAdd(a + 6, sxx); atomicAdd(a + 7, sxy);
-        atomicAdd(a + 8, syy); atomicAdd(a + 9, gop);
-        s_touched[t] = 1;
+        buf0 += b4.z * fac; buf1 += b4.w * fac; buf2 += c2.x * fac;
+        const float gop = valid ? vis * v_alpha : 0.f;
+        const float v_sigma = -b4.y * gop;
+        const float sx = v_sigma * dx, sy = v_sigma * dy;
+        const float sxx = sx * dx, sxy = sx * dy, syy = sy * dy;
+        // three 4-way swap reductions: lanes 15/31/47/63 end up holding the 4 sums of each group
+        const float r0 = gol_wave_sum4(g0, g1, g2, gop);
+        const float r1 = gol_wave_sum4(sx, sy, sxx, sxy);
+        const float r2 = gol_wave_sum4(syy, g3, 0.f, 0.f);
+        if ((lane & 15) == 15) {
+          float* a = &s_acc[wave][t][lane >> 4];
+          a[0] = r0; a[4] = r1; a[8] = r2;
+          s_touched[wave][t] = 1;
+        }
       }
     }
     __syncthreads();
-    if (tid < batch_size && s_touched[tid]) {
-      const size_t g = goff + (size_t)s_id[tid];
-      const float* a = s_acc + tid * kAcc;
-      const float4 a4 = s_a[tid];
-      const float cc = s_b[tid].x;
-      atomicAdd(v_colors + 3 * g, a[0]); atomicAdd(v_colors + 3 * g + 1, a[1]); atomicAdd(v_colors + 3 * g + 2, a[2]);
-      if (EXTRA && v_extra) atomicAdd(v_extra + g, a[3]);
-      atomicAdd(v_xy + 2 * g, a4.z * a[4] + a4.w * a[5]);
-      atomicAdd(v_xy + 2 * g + 1, a4.w * a[4] + cc * a[5]);
-      atomicAdd(v_conic + 3 * g, 0.5f * a[6]); atomicAdd(v_conic + 3 * g + 1, a[7]); atomicAdd(v_conic + 3 * g + 2, 0.5f * a[8]);
-      atomicAdd(v_opacity + g, a[9]);
+    if (tid < batch_size) {
+      float a[kAcc];
+#pragma unroll
+      for (int k = 0; k < kAcc; ++k) a[k] = 0.f;
+      bool any = false;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        if (s_touched[w][tid]) {
+          any = true;
+          const float4* q = reinterpret_cast<const float4*>(&s_acc[w][tid][0]);
+          const float4 q0 = q[0], q1 = q[1], q2 = q[2];
+          a[0] += q0.x; a[1] += q0.y; a[2] += q0.z; a[3] += q0.w;
+          a[4] += q1.x; a[5] += q1.y; a[6] += q1.z; a[7] += q1.w;
+          a[8] += q2.x; a[9] += q2.y;
+        }
+      }
+      if (any) {
+        const size_t g = goff + (size_t)s_id[tid];
+        const float4 a4 = s_a[tid];
+        const float cc = s_b[tid].x;
+        atomicAdd(v_colors + 3 * g, a[0]); atomicAdd(v_colors + 3 * g + 1, a[1]); atomicAdd(v_colors + 3 * g + 2, a[2]);
+        atomicAdd(v_opacity + g, a[3]);
+        atomicAdd(v_xy + 2 * g, a4.z * a[4] + a4.w * a[5]);
+        atomicAdd(v_xy + 2 * g + 1, a4.w * a[4] + cc * a[5]);
+        atomicAdd(v_conic + 3 * g, 0.5f * a[6]); atomicAdd(v_conic + 3 * g + 1, a[7]);
+        atomicAdd(v_conic + 3 * g + 2, 0.5f * a[8]);
+        if (EXTRA && v_extra) atomicAdd(v_extra + g, a[9]);
+      }
     }
   }
 }

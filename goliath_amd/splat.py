@@ -98,15 +98,17 @@ class _Workspace:
         self.n_isect = torch.empty(B, dtype=torch.int32, device=device)
 
 
-def _bin_sort(B, N, xys, depths, radii, img_h, img_w, ws, count_done):
-    _lib.call("gol_bin_sort", c_int(B), c_int(N), fptr(xys), fptr(depths), iptr(radii), c_int(img_h),
-              c_int(img_w), c_int(BLOCK), c_i64(ws.capacity), iptr(ws.tile_count), c_int(1 if count_done else 0),
-              iptr(ws.tile_bins), ptr(ws.keys, torch.int64), iptr(ws.sorted_ids), iptr(ws.n_isect),
-              stream_ptr())
+def _bin_sort(B, N, xys, depths, radii, img_h, img_w, ws, conics=None, opacities=None):
+    """conics + opacities given -> (Gaussian, tile) pairs that cannot reach alpha >= 1/255 are pruned
+    (output-preserving); omitted -> gsplat's exact 3-sigma tile lists."""
+    _lib.call("gol_bin_sort", c_int(B), c_int(N), fptr(xys), fptr(depths), iptr(radii), fptr(conics),
+              fptr(opacities), c_int(img_h), c_int(img_w), c_int(BLOCK), c_i64(ws.capacity),
+              iptr(ws.tile_count), iptr(ws.tile_bins), ptr(ws.keys, torch.int64), iptr(ws.sorted_ids),
+              iptr(ws.n_isect), stream_ptr())
 
 
 def _project_fwd(B, N, means, scales, glob_scale, quats, viewmats, intrins, img_h, img_w, clip,
-                 opacities=None, tile_count=None):
+                 opacities=None):
     dev = means.device
     f = dict(dtype=torch.float32, device=dev)
     cov3d = torch.empty(B, N, 6, **f)
@@ -121,7 +123,7 @@ def _project_fwd(B, N, means, scales, glob_scale, quats, viewmats, intrins, img_
               c_float(glob_scale), fptr(quats, "quats"), fptr(viewmats, "viewmat"), fptr(intrins, "intrins"),
               c_int(img_h), c_int(img_w), c_int(BLOCK), c_float(clip), fptr(cov3d), fptr(xys), fptr(depths),
               iptr(radii), fptr(conics), fptr(comp), iptr(nth), fptr(opacities, "opacity"), fptr(opac_eff),
-              iptr(tile_count), stream_ptr())
+              stream_ptr())
     return cov3d, xys, depths, radii, conics, comp, nth, opac_eff
 
 
@@ -207,7 +209,7 @@ class _RasterizeGaussians(torch.autograd.Function):
             final_Ts = torch.empty(1, img_height, img_width, device=dev)
             final_idx = torch.empty(1, img_height, img_width, dtype=torch.int32, device=dev)
             with torch.cuda.device(dev):
-                _bin_sort(1, N, xys, depths, radii, img_height, img_width, ws, count_done=False)
+                _bin_sort(1, N, xys, depths, radii, img_height, img_width, ws, conics, opacity)
                 _lib.call("gol_rasterize_fwd", c_int(1), c_int(N), c_int(img_height), c_int(img_width),
                           c_int(BLOCK), iptr(ws.tile_bins), iptr(ws.sorted_ids), c_i64(ws.capacity), fptr(xys),
                           fptr(conics), fptr(colors), fptr(None), fptr(opacity), fptr(background),
@@ -283,8 +285,8 @@ class _RenderViews(torch.autograd.Function):
         with torch.cuda.device(dev):
             cov3d, xys, depths, radii, conics, comp, nth, opac_eff = _project_fwd(
                 B, N, means, scales, glob_scale, quats, viewmats, intrins, img_h, img_w, clip_thresh,
-                opacities=opacity, tile_count=ws.tile_count)
-            _bin_sort(B, N, xys, depths, radii, img_h, img_w, ws, count_done=True)
+                opacities=opacity)
+            _bin_sort(B, N, xys, depths, radii, img_h, img_w, ws, conics, opac_eff)
             out_img = torch.empty(B, img_h, img_w, 3, device=dev)
             out_depth = torch.empty(B, img_h, img_w, device=dev) if with_depth else None
             final_Ts = torch.empty(B, img_h, img_w, device=dev)

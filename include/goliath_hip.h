@@ -35,6 +35,10 @@ typedef enum {
 const char* gol_version(void);
 /* Text of the last error on this thread (static storage). */
 const char* gol_last_error(void);
+/* Self-test of the wave64 reduction primitives: in256 = 4 x 64 floats (a,b,c,d per lane);
+ * out128[0..63] = per-lane result of the 4-way swap reduction (lanes 15/31/47/63 = sums of
+ * a/b/c/d), out128[64..127] = per-lane result of the DPP ladder (lane 63 = sum of a). */
+int gol_selftest_wave_sum4(const float* in256, float* out128, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * sgutils -- spherical-Gaussian specular lobe evaluation.
@@ -59,16 +63,14 @@ int gol_sg_eval_bwd(int N, int D, int L, const float* lobe_dirs, const float* lo
  * Batched over B views: viewmats[B,12] (row-major 3x4 world->camera), intrins[B,4]=(fx,fy,cx,cy)
  * live on the device so no host sync is needed to read K (cf. rgca.py:123-126 .item() x4).
  * Outputs for culled Gaussians are zero (radii = num_tiles_hit = 0).
- * Optional fused extras (pass NULL to skip):
+ * Optional fused extra (pass NULL to skip):
  *   opacities[B,N] -> opac_eff[B,N] = opacity * compensation   (render_gsplat.py:72)
- *   tile_count[B,T] int32 (zeroed by caller) += 1 per covered tile (feeds gol_bin_*)
  * ---------------------------------------------------------------------------------------- */
 int gol_project_fwd(int B, int N, const float* means3d, const float* scales, float glob_scale,
                     const float* quats, const float* viewmats, const float* intrins, int img_h,
                     int img_w, int block, float clip_thresh, float* cov3d, float* xys,
                     float* depths, int32_t* radii, float* conics, float* compensation,
-                    int32_t* num_tiles_hit, const float* opacities, float* opac_eff,
-                    int32_t* tile_count, void* stream);
+                    int32_t* num_tiles_hit, const float* opacities, float* opac_eff, void* stream);
 /* v_* inputs may be NULL (treated as zero).  If opacities != NULL the op also differentiates
  * opac_eff = opacity*compensation: v_opac_eff[B,N] in, v_opacity[B,N] out. */
 int gol_project_bwd(int B, int N, const float* means3d, const float* scales, float glob_scale,
@@ -84,19 +86,21 @@ int gol_project_bwd(int B, int N, const float* means3d, const float* scales, flo
  * torch.sort(int64) + get_tile_bin_edges without the host sync on the
  * intersection count.  Order inside a tile: ascending (depth bits, gaussian id) -- a
  * deterministic instance of gsplat's unspecified tie order.
+ *   conics[B,N,3], opacities[B,N]  optional (both or neither): when given, (Gaussian, tile) pairs
+ *                   whose alpha >= 1/255 ellipse cannot reach the tile are not stored.  This is
+ *                   output-preserving (the rasterizer would skip them at every pixel, A.3).
  *   capacity        max intersections stored per view
- *   tile_count[B,T] int32 scratch.  count_done=0: zeroed and filled here; 1: already filled
- *                   by gol_project_fwd
+ *   tile_count[B,T] int32 scratch
  *   tile_bins[B,T,2] out: [start,end) into the view's segment of sorted_ids
  *   isect_keys[B,capacity] uint64 scratch
  *   sorted_ids[B,capacity] out: Gaussian ids, tile by tile, front to back
- *   n_isect[B] out: true number of intersections (> capacity means overflow: the excess
+ *   n_isect[B] out: number of intersections found (> capacity means overflow: the excess
  *                   intersections were dropped and the render is incomplete)
  * ---------------------------------------------------------------------------------------- */
 int gol_bin_sort(int B, int N, const float* xys, const float* depths, const int32_t* radii,
-                 int img_h, int img_w, int block, int64_t capacity, int32_t* tile_count,
-                 int count_done, int32_t* tile_bins, uint64_t* isect_keys, int32_t* sorted_ids,
-                 int32_t* n_isect, void* stream);
+                 const float* conics, const float* opacities, int img_h, int img_w, int block,
+                 int64_t capacity, int32_t* tile_count, int32_t* tile_bins, uint64_t* isect_keys,
+                 int32_t* sorted_ids, int32_t* n_isect, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Tile rasterizer.  Replaces gsplat: rasterize_forward / rasterize_backward, 3-channel

@@ -75,7 +75,7 @@ def test_bin_sort_matches_oracle_exactly():
     T = splat._tiles(s["H"], s["W"])
     ws = splat._Workspace(1, xys.shape[0], T, I, "cuda")
     splat._bin_sort(1, xys.shape[0], hip[0].contiguous(), hip[1].contiguous(), hip[2].contiguous(), s["H"],
-                    s["W"], ws, count_done=False)
+                    s["W"], ws)
     assert int(ws.n_isect[0]) == I
     assert torch.equal(ws.tile_bins[0].cpu(), bins) or torch.equal(
         (ws.tile_bins[0, :, 1] - ws.tile_bins[0, :, 0]).cpu(), bins[:, 1] - bins[:, 0])
@@ -83,9 +83,23 @@ def test_bin_sort_matches_oracle_exactly():
     # capacity overflow: the count is still exact, the bins stay inside the buffer
     ws2 = splat._Workspace(1, xys.shape[0], T, I // 3, "cuda")
     splat._bin_sort(1, xys.shape[0], hip[0].contiguous(), hip[1].contiguous(), hip[2].contiguous(), s["H"],
-                    s["W"], ws2, count_done=False)
+                    s["W"], ws2)
     assert int(ws2.n_isect[0]) == I
     assert int(ws2.tile_bins.max()) <= I // 3
+    # pruned lists (conics + opacity given): every tile list is a subsequence of gsplat's list and
+    # contains every Gaussian that can reach alpha >= 1/255 somewhere in the tile
+    opac = (s["opacity"][:, 0] * comp).cuda().contiguous()
+    ws3 = splat._Workspace(1, xys.shape[0], T, I, "cuda")
+    splat._bin_sort(1, xys.shape[0], hip[0].contiguous(), hip[1].contiguous(), hip[2].contiguous(), s["H"],
+                    s["W"], ws3, hip[3].contiguous(), opac)
+    I3 = int(ws3.n_isect[0])
+    assert 0 < I3 < I
+    b3, ids3 = ws3.tile_bins[0].cpu(), ws3.sorted_ids[0].cpu()
+    for t in range(0, T, 7):
+        full = ids[bins[t, 0]:bins[t, 1]].tolist()
+        sub = ids3[b3[t, 0]:b3[t, 1]].tolist()
+        it = iter(full)
+        assert all(g in it for g in sub), t  # order-preserving subsequence
 
 
 def test_bin_sort_long_list_global_path():
@@ -102,7 +116,7 @@ def test_bin_sort_long_list_global_path():
     nth = torch.ones(N, dtype=torch.int32)
     _, ids, bins = cref.bin_and_sort(xys.cpu(), depths.cpu(), radii.cpu(), nth, 64, 64, 16)
     ws = splat._Workspace(1, N, 16, N, "cuda")
-    splat._bin_sort(1, N, xys, depths, radii, 64, 64, ws, count_done=False)
+    splat._bin_sort(1, N, xys, depths, radii, 64, 64, ws)
     assert torch.equal(ws.sorted_ids[0, :N].cpu(), ids)
 
 
