@@ -35,11 +35,11 @@ __device__ __forceinline__ TileBox tile_box(float gx, float gy, float radius, in
   t.y0 = clampi((int)(tcy - tr), 0, tiles_y);
   t.y1 = clampi((int)(tcy + tr + 1.f), 0, tiles_y);
   if (tight) {
-    const float k = 255.f * op;
-    if (!(k > 1.f)) { t.x1 = t.x0; return t; }  // alpha < 1/255 everywhere
+    const float tau = gol_alpha_tau(op);
+    if (!(tau >= 0.f)) { t.x1 = t.x0; return t; }  // alpha < 1/255 everywhere
     const float det = ca * cc - cb * cb;
     if (det > 0.f && ca > 0.f && cc > 0.f) {
-      const float tau2 = 2.f * (__logf(k) * 1.001f + 1e-3f);
+      const float tau2 = 2.f * tau;
       const float hx = sqrtf(tau2 * cc / det) + 0.02f, hy = sqrtf(tau2 * ca / det) + 0.02f;
       if (hx < 1e30f && hy < 1e30f) {
         // tile tx holds pixel centres [block*tx + 0.5, block*tx + block - 0.5]
@@ -57,19 +57,33 @@ __device__ __forceinline__ TileBox tile_box(float gx, float gy, float radius, in
   return t;
 }
 
+// exact per-tile test used inside the tile loops (only when the conic is well formed)
+struct Reach { float gx, gy, a, b, c, tau; bool exact; };
+
+__device__ __forceinline__ bool tile_reached(const Reach& r, int x, int y, float block) {
+  if (!r.exact) return true;
+  const float x0 = (float)x * block + 0.5f, y0 = (float)y * block + 0.5f;
+  return gol_min_sigma_rect(r.gx, r.gy, r.a, r.b, r.c, x0, x0 + block - 1.f, y0, y0 + block - 1.f) <= r.tau;
+}
+
 struct BinArgs {
   int N, tiles_x, tiles_y, chunk;
   float inv_block, block;
   const float* xys; const float* depths; const int32_t* radii; const float* conics; const float* opacities;
 };
 
-__device__ __forceinline__ TileBox box_of(const BinArgs& a, size_t e) {
+__device__ __forceinline__ TileBox box_of(const BinArgs& a, size_t e, Reach& rc) {
   const int r = a.radii[e];
+  rc.exact = false;
   if (r <= 0) return TileBox{0, 0, 0, 0};
   const float2 c = *reinterpret_cast<const float2*>(a.xys + 2 * e);
   const bool tight = a.conics != nullptr;
   float ca = 0.f, cb = 0.f, cc = 0.f, op = 1.f;
-  if (tight) { ca = a.conics[3 * e]; cb = a.conics[3 * e + 1]; cc = a.conics[3 * e + 2]; op = a.opacities[e]; }
+  if (tight) {
+    ca = a.conics[3 * e]; cb = a.conics[3 * e + 1]; cc = a.conics[3 * e + 2]; op = a.opacities[e];
+    rc.gx = c.x; rc.gy = c.y; rc.a = ca; rc.b = cb; rc.c = cc; rc.tau = gol_alpha_tau(op);
+    rc.exact = (ca * cc - cb * cb > 0.f) && ca > 0.f && cc > 0.f;
+  }
   return tile_box(c.x, c.y, (float)r, a.tiles_x, a.tiles_y, a.inv_block, a.block, tight, ca, cb, cc, op);
 }
 
@@ -84,9 +98,11 @@ __global__ __launch_bounds__(1024) void count_lds_kernel(BinArgs a, int32_t* __r
   __syncthreads();
   const int i_end = min(a.N, (int)(blockIdx.x + 1) * a.chunk);
   for (int i = blockIdx.x * a.chunk + threadIdx.x; i < i_end; i += 1024) {
-    const TileBox tb = box_of(a, (size_t)b * a.N + i);
+    Reach rc;
+    const TileBox tb = box_of(a, (size_t)b * a.N + i, rc);
     for (int y = tb.y0; y < tb.y1; ++y)
-      for (int x = tb.x0; x < tb.x1; ++x) atomicAdd(&s_cnt[y * a.tiles_x + x], 1);
+      for (int x = tb.x0; x < tb.x1; ++x)
+        if (tile_reached(rc, x, y, a.block)) atomicAdd(&s_cnt[y * a.tiles_x + x], 1);
   }
   __syncthreads();
   int32_t* tc = tile_count + (size_t)b * T;
@@ -110,9 +126,11 @@ __global__ __launch_bounds__(1024) void scatter_lds_kernel(BinArgs a, int64_t ca
   __syncthreads();
   const int i_begin = blockIdx.x * a.chunk + threadIdx.x, i_end = min(a.N, (int)(blockIdx.x + 1) * a.chunk);
   for (int i = i_begin; i < i_end; i += 1024) {
-    const TileBox tb = box_of(a, (size_t)b * a.N + i);
+    Reach rc;
+    const TileBox tb = box_of(a, (size_t)b * a.N + i, rc);
     for (int y = tb.y0; y < tb.y1; ++y)
-      for (int x = tb.x0; x < tb.x1; ++x) atomicAdd(&s_cnt[y * a.tiles_x + x], 1);
+      for (int x = tb.x0; x < tb.x1; ++x)
+        if (tile_reached(rc, x, y, a.block)) atomicAdd(&s_cnt[y * a.tiles_x + x], 1);
   }
   __syncthreads();
   int32_t* bins = tile_bins + (size_t)b * T * 2;
@@ -125,11 +143,13 @@ __global__ __launch_bounds__(1024) void scatter_lds_kernel(BinArgs a, int64_t ca
   uint64_t* keys = isect_keys + (size_t)b * capacity;
   for (int i = i_begin; i < i_end; i += 1024) {
     const size_t e = (size_t)b * a.N + i;
-    const TileBox tb = box_of(a, e);
+    Reach rc;
+    const TileBox tb = box_of(a, e, rc);
     if (tb.x1 <= tb.x0 || tb.y1 <= tb.y0) continue;
     const uint64_t key = ((uint64_t)__float_as_uint(a.depths[e]) << 32) | (uint32_t)i;
     for (int y = tb.y0; y < tb.y1; ++y)
       for (int x = tb.x0; x < tb.x1; ++x) {
+        if (!tile_reached(rc, x, y, a.block)) continue;
         const int t = y * a.tiles_x + x;
         const int slot = s_base[t] + atomicAdd(&s_cnt[t], 1);
         if (slot < capacity) keys[slot] = key;
@@ -142,10 +162,12 @@ __global__ __launch_bounds__(256) void count_kernel(BinArgs a, int32_t* __restri
   const int b = blockIdx.y;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= a.N) return;
-  const TileBox tb = box_of(a, (size_t)b * a.N + i);
+  Reach rc;
+  const TileBox tb = box_of(a, (size_t)b * a.N + i, rc);
   int32_t* tc = tile_count + (size_t)b * a.tiles_x * a.tiles_y;
   for (int y = tb.y0; y < tb.y1; ++y)
-    for (int x = tb.x0; x < tb.x1; ++x) atomicAdd(tc + y * a.tiles_x + x, 1);
+    for (int x = tb.x0; x < tb.x1; ++x)
+      if (tile_reached(rc, x, y, a.block)) atomicAdd(tc + y * a.tiles_x + x, 1);
 }
 
 __global__ __launch_bounds__(256) void scatter_kernel(BinArgs a, int64_t capacity, int32_t* __restrict__ tile_bins,
@@ -154,13 +176,15 @@ __global__ __launch_bounds__(256) void scatter_kernel(BinArgs a, int64_t capacit
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= a.N) return;
   const size_t e = (size_t)b * a.N + i;
-  const TileBox tb = box_of(a, e);
+  Reach rc;
+  const TileBox tb = box_of(a, e, rc);
   if (tb.x1 <= tb.x0 || tb.y1 <= tb.y0) return;
   const uint64_t key = ((uint64_t)__float_as_uint(a.depths[e]) << 32) | (uint32_t)i;
   int32_t* bins = tile_bins + (size_t)b * a.tiles_x * a.tiles_y * 2;
   uint64_t* keys = isect_keys + (size_t)b * capacity;
   for (int y = tb.y0; y < tb.y1; ++y)
     for (int x = tb.x0; x < tb.x1; ++x) {
+      if (!tile_reached(rc, x, y, a.block)) continue;
       const int slot = atomicAdd(bins + 2 * (y * a.tiles_x + x) + 1, 1);
       if (slot < capacity) keys[slot] = key;
     }

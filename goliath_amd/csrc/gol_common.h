@@ -97,5 +97,32 @@ __device__ __forceinline__ float gol_readlane63(float v) {
   return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 
+// ---- alpha >= 1/255 reach test (shared by binning and raster) -----------------------------------
+// A Gaussian (centre g, conic a,b,c, opacity op) contributes at pixel p only if
+//   op * exp(-sigma(p)) >= 1/255  <=>  sigma(p) = 0.5 d^T C d <= ln(255 op) =: tau     
+// gol_alpha_tau returns a slightly inflated tau (conservative against rounding; < 0 means "never").
+__device__ __forceinline__ float gol_alpha_tau(float op) {
+  const float k = 255.f * op;
+  return (k > 1.f) ? __logf(k) * 1.001f + 1e-3f : -1.f;
+}
+// minimum of sigma over the axis-aligned rectangle [x0,x1] x [y0,y1] (exact: the quadratic is convex,
+// so the minimum is 0 inside or lies on one of the four edges)
+__device__ __forceinline__ float gol_min_sigma_rect(float gx, float gy, float a, float b, float c, float x0,
+                                                    float x1, float y0, float y1) {
+  if (gx >= x0 && gx <= x1 && gy >= y0 && gy <= y1) return 0.f;
+  const float ia = 1.f / a, ic = 1.f / c;
+  float m = 3.0e38f;
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    const float dx = (e ? x1 : x0) - gx;
+    const float dy = fminf(fmaxf(-b * dx * ic, y0 - gy), y1 - gy);
+    m = fminf(m, 0.5f * (a * dx * dx + c * dy * dy) + b * dx * dy);
+    const float ey = (e ? y1 : y0) - gy;
+    const float ex = fminf(fmaxf(-b * ey * ia, x0 - gx), x1 - gx);
+    m = fminf(m, 0.5f * (a * ex * ex + c * ey * ey) + b * ex * ey);
+  }
+  return m;
+}
+
 __device__ __forceinline__ float gol_fast_exp(float x) { return __expf(x); }
 __device__ __forceinline__ float gol_rcp(float x) { return __frcp_rn(x); }

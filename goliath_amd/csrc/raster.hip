@@ -40,24 +40,21 @@ __device__ __forceinline__ TileCoord tile_of_block(int bid, int T, int tiles_x) 
   return tc;
 }
 
-// 4-bit mask of the 8x8 quadrants (bit q = qy*2+qx) that the alpha >= 1/255 region of a
-// Gaussian can reach.  Conservative (axis-aligned box of the ellipse sigma <= ln(255*opacity),
-// with margin); degenerate conics fall back to "all quadrants".
+// 4-bit mask of the 8x8 quadrants (bit q = qy*2+qx) that the alpha >= 1/255 region of a Gaussian
+// can reach: exact ellipse-vs-rectangle test (minimum of sigma over the quadrant's pixel centres
+// against ln(255*opacity)), conservative only by a rounding margin; degenerate conics -> all.
 __device__ __forceinline__ int quadrant_mask(float gx, float gy, float ca, float cb, float cc, float op,
                                              float tile_x0, float tile_y0) {
-  const float k = 255.f * op;
-  if (!(k > 1.f)) return 0;  // alpha < 1/255 everywhere (also catches NaN opacity -> skipped by gsplat too)
+  const float tau = gol_alpha_tau(op);
+  if (!(tau >= 0.f)) return 0;  // alpha < 1/255 everywhere (also NaN opacity: skipped by gsplat too)
   const float det = ca * cc - cb * cb;
   if (!(det > 0.f) || !(ca > 0.f) || !(cc > 0.f)) return 0xf;
-  const float tau2 = 2.f * (__logf(k) * 1.001f + 1e-3f);
-  const float hx = sqrtf(tau2 * cc / det) + 0.02f, hy = sqrtf(tau2 * ca / det) + 0.02f;
-  if (!(hx < 1e30f) || !(hy < 1e30f)) return 0xf;
   int m = 0;
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     const float x0 = tile_x0 + (float)((q & 1) * 8) + 0.5f, y0 = tile_y0 + (float)((q >> 1) * 8) + 0.5f;
-    const bool hit = (gx + hx >= x0) && (gx - hx <= x0 + 7.f) && (gy + hy >= y0) && (gy - hy <= y0 + 7.f);
-    m |= hit ? (1 << q) : 0;
+    const float ms = gol_min_sigma_rect(gx, gy, ca, cb, cc, x0, x0 + 7.f, y0, y0 + 7.f);
+    m |= (ms <= tau) ? (1 << q) : 0;
   }
   return m;
 }
