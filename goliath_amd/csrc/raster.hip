@@ -122,23 +122,20 @@ __global__ __launch_bounds__(256) void raster_fwd_kernel(
         const float4 a4 = s_a[t];
         const float4 b4 = s_b[t];
         const float2 c2 = s_c[t];
-        if (!done) {
-          const float dx = a4.x - px, dy = a4.y - py;
-          const float sigma = 0.5f * (a4.z * dx * dx + b4.x * dy * dy) + a4.w * dx * dy;
-          const float alpha = fminf(GOL_ALPHA_CAP_FWD, b4.y * __expf(-sigma));
-          if (!(sigma < 0.f || alpha < GOL_ALPHA_FLOOR)) {
-            const float next_T = T_cur * (1.f - alpha);
-            if (next_T <= GOL_T_STOP) {
-              done = true;
-            } else {
-              const float vis = alpha * T_cur;
-              acc0 += b4.z * vis; acc1 += b4.w * vis; acc2 += c2.x * vis;
-              if (EXTRA) acc3 += c2.y * vis;
-              T_cur = next_T;
-              cur_idx = batch_start + t;
-            }
-          }
-        }
+        // branch-free pixel update: selects instead of exec-mask regions (the loop is issue-bound)
+        const float dx = a4.x - px, dy = a4.y - py;
+        const float sigma = 0.5f * (a4.z * dx * dx + b4.x * dy * dy) + a4.w * dx * dy;
+        const float alpha = fminf(GOL_ALPHA_CAP_FWD, b4.y * __expf(-sigma));
+        const bool contrib = !done && !(sigma < 0.f || alpha < GOL_ALPHA_FLOOR);
+        const float next_T = T_cur * (1.f - alpha);
+        const bool stop = contrib && (next_T <= GOL_T_STOP);
+        const bool take = contrib && !stop;
+        done = done || stop;
+        const float vis = take ? alpha * T_cur : 0.f;
+        acc0 += b4.z * vis; acc1 += b4.w * vis; acc2 += c2.x * vis;
+        if (EXTRA) acc3 += c2.y * vis;
+        T_cur = take ? next_T : T_cur;
+        cur_idx = take ? (batch_start + t) : cur_idx;
       }
     }
   }
@@ -154,7 +151,7 @@ __global__ __launch_bounds__(256) void raster_fwd_kernel(
   }
 }
 
-constexpr int kBatchB = 128;  // backward batch (smaller: per-wave gradient slots live in LDS)
+constexpr int kBatchB = 64;   // backward batch (smaller: per-wave gradient slots live in LDS)
 constexpr int kAcc = 12;      // r g b v_opacity | Sx Sy Sxx Sxy | Syy extra - -
 
 template <bool EXTRA>
@@ -236,8 +233,7 @@ __global__ __launch_bounds__(256) void raster_bwd_kernel(
         s_mask[tid] = 0;
       }
     }
-    if (tid < kBatchB) { s_touched[0][tid] = 0; s_touched[1][tid] = 0; }
-    else { s_touched[2][tid - kBatchB] = 0; s_touched[3][tid - kBatchB] = 0; }
+    for (int k = tid; k < 4 * kBatchB; k += 256) (&s_touched[0][0])[k] = 0;
     __syncthreads();
 
     const int t0 = max(0, batch_end - wmax);  // entries behind every pixel of this wave are skipped
