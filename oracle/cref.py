@@ -198,3 +198,59 @@ def evaluate_gaussian_bwd(lobe_dirs, lobe_sigmas, light_values, light_pts, prim_
                      _p(light_pts), _p(prim_pts), _p(n_lights.to(torch.int32).contiguous().cpu()),
                      _p(grad_integral), c_int(w_type), _p(gd), _p(gs), _p(gl))
     return gd, gs, gl
+
+
+# --------------------------------------------------------------------------- mvpraymarch / raydirs
+def mvp_forward(raypos, raydir, stepsize, tminmax, primpos, primrot, primscale, template, fadescale=8.0,
+                fadeexp=8.0, want_raysat=True, with_shadow=False):
+    """mvpraymarchlib.raymarch_forward semantics (algo 0, chlast).  template[N,K,TD,TH,TW,4].
+    Returns rayrgba[N,H,W,4], raysat[N,H,W,3] (or None), shadow[N,K,TD,TH,TW,2] (or None)."""
+    raypos, raydir, tminmax, primpos, primrot, primscale, template = map(
+        _f, (raypos, raydir, tminmax, primpos, primrot, primscale, template))
+    N, H, W = raypos.shape[:3]
+    K, TD, TH, TW = template.shape[1:5]
+    out = torch.empty(N, H, W, 4)
+    sat = torch.empty(N, H, W, 3) if want_raysat else None
+    shadow = torch.zeros(N, K, TD, TH, TW, 2) if with_shadow else None
+    lib().orc_mvp_fwd(c_int(N), c_int(H), c_int(W), c_int(K), _p(raypos), _p(raydir), c_float(stepsize), _p(tminmax),
+                      _p(primpos), _p(primrot), _p(primscale), _p(template), c_int(TD), c_int(TH), c_int(TW),
+                      c_float(fadescale), c_float(fadeexp), _p(out), _p(sat), _p(shadow))
+    return out, sat, shadow
+
+
+def mvp_backward(raypos, raydir, stepsize, tminmax, primpos, primrot, primscale, template, raysat, grad_rayrgba,
+                 fadescale=8.0, fadeexp=8.0):
+    """mvpraymarchlib.raymarch_backward semantics; returns grads (primpos, primrot, primscale, template)."""
+    raypos, raydir, tminmax, primpos, primrot, primscale, template, raysat, grad_rayrgba = map(
+        _f, (raypos, raydir, tminmax, primpos, primrot, primscale, template, raysat, grad_rayrgba))
+    N, H, W = raypos.shape[:3]
+    K, TD, TH, TW = template.shape[1:5]
+    gp, gr, gs, gt = torch.zeros_like(primpos), torch.zeros_like(primrot), torch.zeros_like(primscale), torch.zeros_like(template)
+    lib().orc_mvp_bwd(c_int(N), c_int(H), c_int(W), c_int(K), _p(raypos), _p(raydir), c_float(stepsize), _p(tminmax),
+                      _p(primpos), _p(primrot), _p(primscale), _p(template), c_int(TD), c_int(TH), c_int(TW),
+                      c_float(fadescale), c_float(fadeexp), _p(raysat), _p(grad_rayrgba), _p(gp), _p(gr), _p(gs), _p(gt))
+    return gp, gr, gs, gt
+
+
+def mvp_aabb(primpos, primrot, primscale):
+    primpos, primrot, primscale = map(_f, (primpos, primrot, primscale))
+    N, K = primpos.shape[:2]
+    out = torch.empty(N, 2 * K - 1, 2, 3)
+    lib().orc_mvp_aabb(c_int(N), c_int(K), _p(primpos), _p(primrot), _p(primscale), _p(out))
+    return out
+
+
+def compute_raydirs(viewpos, viewrot, focal, princpt, pixelcoords, volradius):
+    """utilslib.compute_raydirs_forward; pixelcoords a [N,H,W,2] tensor or a (W, H) tuple."""
+    viewpos, viewrot, focal, princpt = map(_f, (viewpos, viewrot, focal, princpt))
+    N = viewpos.shape[0]
+    if isinstance(pixelcoords, tuple):
+        W, H = pixelcoords
+        pc = None
+    else:
+        pc = _f(pixelcoords)
+        H, W = pc.shape[1:3]
+    rp, rd, tm = torch.empty(N, H, W, 3), torch.empty(N, H, W, 3), torch.empty(N, H, W, 2)
+    lib().orc_raydirs(c_int(N), c_int(H), c_int(W), _p(viewpos), _p(viewrot), _p(focal), _p(princpt), _p(pc),
+                      c_float(volradius), _p(rp), _p(rd), _p(tm))
+    return rp, rd, tm
