@@ -1,0 +1,545 @@
+// mvp.hip -- Mixture-of-Volumetric-Primitives ray marcher (forward + backward), leaf/node AABBs and
+// camera ray generation for gfx950.
+//
+// Replaces (/root/reference/extensions):
+//   utils/utils_kernel.cu:11-51                         compute_raydirs_forward_kernel
+//   mvpraymarch/bvh.cu:157-201, primtransf.h:12-63      compute_aabb_kernel (fixed-order tree)
+//   mvpraymarch/mvpraymarch_subset_kernel.h:7-228       raymarch_subset_{forward,backward}_kernel with
+//       PrimTransfSRT (primtransf.h:99-179), PrimSamplerTW<false, GridSamplerChlast> (primsampler.h,
+//       utils.h:523-770), PrimAccumAdditive (primaccum.h:63-98), PrimSplatterTW (primsplatter.h),
+//       RaySubsetFixedBVH<false,512,true> (utils.h:949-1045)
+// The reference is written around 32-lane warps (8x4-pixel footprints, __any_sync / __shfl_down_sync
+// with literal 32s).  This is a wave64 redesign:
+//   * a wave owns an 8x8-pixel footprint and builds ONE hit list for it (512 entries, in LDS) with a
+//     wave-synchronous, stackless walk of the implicit heap: node AABBs and box transforms are
+//     wave-uniform (scalar loads), only the ray tests are per lane;
+//   * the list is annotated with the range of march iterations in which ANY lane of the wave can be
+//     inside the box.  The reference re-tests every hit box at every step (steps x boxes transform
+//     evaluations); here a box costs work only while some ray of the wave is inside it (~20x fewer
+//     evaluations at the BASELINE config) -- output-preserving, because a skipped evaluation is one
+//     whose valid() test fails for every lane;
+//   * backward: the 15 primitive-transform gradients are reduced over the wave four-at-a-time with
+//     the v_permlane*_swap ladder (one atomic per wave per scalar, like the reference's
+//     fastAtomicAdd per warp); template gradients are scattered with hardware f32 atomics.
+#include "gol_common.h"
+
+namespace {
+
+constexpr int kMaxHits = 512;  // per wave (reference: per 32-lane warp, utils.h:993-1012)
+
+struct V3 { float x, y, z; };
+__device__ __forceinline__ V3 v3(float x, float y, float z) { return V3{x, y, z}; }
+__device__ __forceinline__ V3 ld3(const float* __restrict__ p) { return V3{p[0], p[1], p[2]}; }
+__device__ __forceinline__ V3 operator+(V3 a, V3 b) { return V3{a.x + b.x, a.y + b.y, a.z + b.z}; }
+__device__ __forceinline__ V3 operator-(V3 a, V3 b) { return V3{a.x - b.x, a.y - b.y, a.z - b.z}; }
+__device__ __forceinline__ V3 operator*(V3 a, V3 b) { return V3{a.x * b.x, a.y * b.y, a.z * b.z}; }
+__device__ __forceinline__ V3 operator*(V3 a, float s) { return V3{a.x * s, a.y * s, a.z * s}; }
+__device__ __forceinline__ float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ float min3(V3 a) { return fminf(fminf(a.x, a.y), a.z); }
+__device__ __forceinline__ float max3(V3 a) { return fmaxf(fmaxf(a.x, a.y), a.z); }
+__device__ __forceinline__ V3 vmin(V3 a, V3 b) { return V3{fminf(a.x, b.x), fminf(a.y, b.y), fminf(a.z, b.z)}; }
+__device__ __forceinline__ V3 vmax(V3 a, V3 b) { return V3{fmaxf(a.x, b.x), fmaxf(a.y, b.y), fmaxf(a.z, b.z)}; }
+
+// ---- compute_raydirs ------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void raydirs_kernel(int N, int H, int W, const float* __restrict__ viewpos,
+                                                      const float* __restrict__ viewrot,
+                                                      const float* __restrict__ focal,
+                                                      const float* __restrict__ princpt,
+                                                      const float* __restrict__ pixelcoords, float volradius,
+                                                      float* __restrict__ rayposim, float* __restrict__ raydirim,
+                                                      float* __restrict__ tminmaxim) {
+  const int n = blockIdx.y;
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= H * W) return;
+  const int h = p / W, w = p - h * W;
+  const size_t r = (size_t)n * H * W + p;
+  const V3 rp = ld3(viewpos + 3 * n) * (1.f / volradius);
+  const V3 v0 = ld3(viewrot + 9 * n), v1 = ld3(viewrot + 9 * n + 3), v2 = ld3(viewrot + 9 * n + 6);
+  float px = (float)w, py = (float)h;
+  if (pixelcoords) { px = pixelcoords[2 * r]; py = pixelcoords[2 * r + 1]; }
+  const float u = (px - princpt[2 * n]) / focal[2 * n], v = (py - princpt[2 * n + 1]) / focal[2 * n + 1];
+  V3 d = v0 * u + v1 * v + v2;
+  d = d * (1.f / sqrtf(dot(d, d)));
+  const V3 t1 = v3((-1.f - rp.x) / d.x, (-1.f - rp.y) / d.y, (-1.f - rp.z) / d.z);
+  const V3 t2 = v3((1.f - rp.x) / d.x, (1.f - rp.y) / d.y, (1.f - rp.z) / d.z);
+  const float tmin = max3(vmin(t1, t2)), tmax = min3(vmax(t1, t2));
+  rayposim[3 * r] = rp.x; rayposim[3 * r + 1] = rp.y; rayposim[3 * r + 2] = rp.z;
+  raydirim[3 * r] = d.x; raydirim[3 * r + 1] = d.y; raydirim[3 * r + 2] = d.z;
+  *reinterpret_cast<float2*>(tminmaxim + 2 * r) = make_float2(fmaxf(tmin, 0.f), tmax);
+}
+
+// ---- AABBs of the fixed-order tree ------------------------------------------------------------------
+// Leaves: one lane per primitive.  Inner nodes: level by level, bottom-up, inside ONE workgroup per
+// view (the tree of a view is tiny: 2K-1 nodes), so no atomics, flags or cudaMalloc (cf. bvh.cu:261-293).
+__global__ __launch_bounds__(1024) void aabb_kernel(int K, const float* __restrict__ primpos,
+                                                    const float* __restrict__ primrot,
+                                                    const float* __restrict__ primscale,
+                                                    float* __restrict__ nodeaabb) {
+  const int n = blockIdx.x;
+  float* A = nodeaabb + (size_t)n * (2 * K - 1) * 6;
+  for (int k = threadIdx.x; k < K; k += blockDim.x) {
+    const size_t e = (size_t)n * K + k;
+    const V3 pt = ld3(primpos + 3 * e), pr0 = ld3(primrot + 9 * e), pr1 = ld3(primrot + 9 * e + 3),
+             pr2 = ld3(primrot + 9 * e + 6), ps = ld3(primscale + 3 * e);
+    V3 mn = v3(INFINITY, INFINITY, INFINITY), mx = v3(-INFINITY, -INFINITY, -INFINITY);
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      V3 p = v3(((c & 1) ? 1.f : -1.f) / ps.x, ((c & 2) ? 1.f : -1.f) / ps.y, ((c & 4) ? 1.f : -1.f) / ps.z);
+      p = v3(dot(p, pr0), dot(p, pr1), dot(p, pr2)) + pt;
+      mn = vmin(mn, p); mx = vmax(mx, p);
+    }
+    float* a = A + (size_t)(K - 1 + k) * 6;
+    a[0] = mn.x; a[1] = mn.y; a[2] = mn.z; a[3] = mx.x; a[4] = mx.y; a[5] = mx.z;
+  }
+  // heap levels bottom-up: nodes [lo, hi) of a level only depend on deeper levels
+  int hi = K - 1;  // inner nodes are 0 .. K-2
+  while (hi > 0) {
+    __syncthreads();
+    // deepest unfinished level: nodes whose children are both >= hi
+    const int lo = (hi - 1 + 1) / 2;  // smallest node with 2*node+1 >= hi  <=>  node >= (hi-1)/2 rounded up
+    for (int node = lo + threadIdx.x; node < hi; node += blockDim.x) {
+      const float* l = A + (size_t)(2 * node + 1) * 6;
+      const float* r = A + (size_t)(2 * node + 2) * 6;
+      float* a = A + (size_t)node * 6;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) { a[c] = fminf(l[c], r[c]); a[3 + c] = fmaxf(l[3 + c], r[3 + c]); }
+    }
+    hi = lo;
+  }
+}
+
+// ---- shared march machinery ---------------------------------------------------------------------------
+struct Xform { V3 xmt, pr0, pr1, pr2, rxmt, ps; };
+
+__device__ __forceinline__ V3 xform_fwd(Xform& t, const float* __restrict__ primpos, const float* __restrict__ primrot,
+                                        const float* __restrict__ primscale, int k, V3 x) {
+  const V3 pt = ld3(primpos + 3 * k);
+  t.pr0 = ld3(primrot + 9 * k); t.pr1 = ld3(primrot + 9 * k + 3); t.pr2 = ld3(primrot + 9 * k + 6);
+  t.ps = ld3(primscale + 3 * k);
+  t.xmt = x - pt;
+  t.rxmt = t.pr0 * t.xmt.x + t.pr1 * t.xmt.y + t.pr2 * t.xmt.z;
+  return t.rxmt * t.ps;
+}
+
+__device__ __forceinline__ bool valid_pos(V3 p) {
+  return p.x > -1.f && p.x < 1.f && p.y > -1.f && p.y < 1.f && p.z > -1.f && p.z < 1.f;
+}
+
+// ray vs oriented unit box (utils.h:976-993): parametric entry/exit
+__device__ __forceinline__ bool box_hit(const float* __restrict__ primpos, const float* __restrict__ primrot,
+                                        const float* __restrict__ primscale, int k, V3 raypos, V3 raydir,
+                                        float& trmin, float& trmax) {
+  const V3 pt = ld3(primpos + 3 * k), pr0 = ld3(primrot + 9 * k), pr1 = ld3(primrot + 9 * k + 3),
+           pr2 = ld3(primrot + 9 * k + 6), ps = ld3(primscale + 3 * k);
+  const V3 xmt = raypos - pt;
+  const V3 r0 = (pr0 * xmt.x + pr1 * xmt.y + pr2 * xmt.z) * ps;
+  const V3 rd = (pr0 * raydir.x + pr1 * raydir.y + pr2 * raydir.z) * ps;
+  const V3 ird = v3(1.f / rd.x, 1.f / rd.y, 1.f / rd.z);
+  const V3 t0 = (v3(-1.f, -1.f, -1.f) - r0) * ird, t1 = (v3(1.f, 1.f, 1.f) - r0) * ird;
+  trmin = max3(vmin(t0, t1));
+  trmax = min3(vmax(t0, t1));
+  return trmin <= trmax;
+}
+
+__device__ __forceinline__ bool aabb_hit(const float* __restrict__ a, V3 raypos, V3 ird) {
+  const V3 t0 = (ld3(a) - raypos) * ird, t1 = (ld3(a + 3) - raypos) * ird;
+  return max3(vmin(t0, t1)) <= min3(vmax(t0, t1));
+}
+
+// next node of a left-first DFS of the implicit heap after finishing the subtree of `node`
+__device__ __forceinline__ int heap_next(int node) {
+  while (node != 0 && !(node & 1)) node = (node - 1) >> 1;  // climb while we are a right child
+  return node == 0 ? -1 : node + 1;                           // right sibling
+}
+
+__device__ __forceinline__ int sat_floor_to_int(float v) {
+  const float f = floorf(v);
+  if (!(f == f)) return 0;
+  if (f >= 2147483520.f) return 2147483647;
+  if (f <= -2147483648.f) return -2147483647 - 1;
+  return (int)f;
+}
+
+__device__ __forceinline__ int wave_min_i(int v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = min(v, __shfl_xor(v, off, 64));
+  return __builtin_amdgcn_readfirstlane(v);
+}
+__device__ __forceinline__ int wave_max_i(int v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = max(v, __shfl_xor(v, off, 64));
+  return __builtin_amdgcn_readfirstlane(v);
+}
+
+struct Ray {
+  V3 pos, dir;
+  float t, rt1;
+  bool live;
+};
+
+struct Tri { int idx[8]; float w[8]; float fx, fy, fz; int x0, y0, z0; };
+
+// utils.h:523-560 (align_corners=True coordinates, zero padding): corner indices (-1 = outside) + weights
+__device__ __forceinline__ void tri_setup(Tri& q, int D, int H, int W, V3 pos) {
+  const float ix = fmaxf(-100.f, fminf(100.f, (pos.x + 1.f) * 0.5f)) * (float)(W - 1);
+  const float iy = fmaxf(-100.f, fminf(100.f, (pos.y + 1.f) * 0.5f)) * (float)(H - 1);
+  const float iz = fmaxf(-100.f, fminf(100.f, (pos.z + 1.f) * 0.5f)) * (float)(D - 1);
+  const float fx0 = floorf(ix), fy0 = floorf(iy), fz0 = floorf(iz);
+  const int x0 = (int)fx0, y0 = (int)fy0, z0 = (int)fz0;
+  q.fx = ix - fx0; q.fy = iy - fy0; q.fz = iz - fz0; q.x0 = x0; q.y0 = y0; q.z0 = z0;
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    const int dx = c & 1, dy = (c >> 1) & 1, dz = (c >> 2) & 1;
+    const int x = x0 + dx, y = y0 + dy, z = z0 + dz;
+    q.w[c] = (dx ? q.fx : 1.f - q.fx) * (dy ? q.fy : 1.f - q.fy) * (dz ? q.fz : 1.f - q.fz);
+    q.idx[c] = (x >= 0 && x < W && y >= 0 && y < H && z >= 0 && z < D) ? (z * H + y) * W + x : -1;
+  }
+}
+
+// Builds the wave's hit list (LDS) + per-box iteration windows, and positions the ray at its first
+// sample.  Returns the number of hit boxes (wave-uniform).
+__device__ __forceinline__ int build_hits(int K, const float* __restrict__ nodeaabb, const float* __restrict__ primpos,
+                                          const float* __restrict__ primrot, const float* __restrict__ primscale,
+                                          float stepsize, float tmin, float tmax, Ray& ray, int* __restrict__ s_list,
+                                          int* __restrict__ s_lo, int* __restrict__ s_hi) {
+  const V3 ird = v3(1.f / ray.dir.x, 1.f / ray.dir.y, 1.f / ray.dir.z);
+  float rt0 = INFINITY, rt1 = -INFINITY;
+  int num = 0;
+  int node = K > 1 ? 1 : 0;  // the reference never tests the root box itself (utils.h:1016-1021)
+  if (K == 1) node = 0;
+  while (node != -1) {
+    if (node >= K - 1) {
+      const int k = node - (K - 1);
+      float a, b;
+      const bool hit = ray.live && box_hit(primpos, primrot, primscale, k, ray.pos, ray.dir, a, b);
+      if (hit) { rt0 = fminf(rt0, a); rt1 = fmaxf(rt1, b); }
+      if (__ballot(hit) != 0ull && num < kMaxHits) {
+        if ((threadIdx.x & 63) == 0) s_list[num] = k;
+        ++num;
+      }
+      node = heap_next(node);
+    } else {
+      const bool hit = ray.live && aabb_hit(nodeaabb + (size_t)node * 6, ray.pos, ird);
+      node = (__ballot(hit) != 0ull) ? 2 * node + 1 : heap_next(node);
+    }
+  }
+  __builtin_amdgcn_wave_barrier();  // list written by lane 0, read by the whole wave below
+  rt0 = fmaxf(rt0, tmin);
+  ray.rt1 = fminf(rt1, tmax);
+  // first sample: whole steps from tmin up to just before the first box (subset_kernel.h:72-77)
+  ray.t = tmin;
+  ray.pos = ray.pos + ray.dir * tmin;
+  const int incs = sat_floor_to_int((rt0 - ray.t) / stepsize);
+  ray.t += (float)incs * stepsize;
+  ray.pos = ray.pos + ray.dir * (float)incs * stepsize;
+  // iteration windows: iteration i samples t_i ~ ray.t + i*stepsize; a lane can be inside box s only
+  // for t in [a, b] -> i in [floor((a - t)/step) - 1, ceil((b - t)/step) + 1] (margin covers the
+  // incremental float accumulation of t).  Window of the wave = union over its lanes.
+  const float inv_step = 1.f / stepsize;
+  const V3 p0 = ray.pos - ray.dir * ray.t;  // ray origin again (positions are affine in t)
+  for (int s = 0; s < num; ++s) {
+    const int k = __builtin_amdgcn_readfirstlane(s_list[s]);
+    float a, b;
+    int lo = 2147483647, hi = -2147483647;
+    if (ray.live && box_hit(primpos, primrot, primscale, k, p0, ray.dir, a, b)) {
+      const float fl = floorf((a - ray.t) * inv_step) - 1.f, fh = ceilf((b - ray.t) * inv_step) + 1.f;
+      if (fl < 2.0e9f && fh > -2.0e9f) {
+        lo = (int)fmaxf(fl, -2.0e9f);
+        hi = (int)fminf(fh, 2.0e9f);
+      }
+    }
+    lo = wave_min_i(lo);
+    hi = wave_max_i(hi);
+    if ((threadIdx.x & 63) == 0) { s_lo[s] = lo; s_hi[s] = hi; }
+  }
+  __builtin_amdgcn_wave_barrier();
+  return num;
+}
+
+struct MarchArgs {
+  int N, H, W, K, TD, TH, TW;
+  float stepsize, fadescale, fadeexp;
+  const float* raypos; const float* raydir; const float* tminmax; const float* nodeaabb;
+  const float* primpos; const float* primrot; const float* primscale; const float* tplate;
+};
+
+__device__ __forceinline__ bool load_ray(const MarchArgs& a, int n, Ray& ray, float& tmin, float& tmax, size_t& r,
+                                         int& wave) {
+  const int tid = threadIdx.x, lane = tid & 63;
+  wave = tid >> 6;
+  const int lx = ((wave & 1) << 3) + (lane & 7), ly = ((wave >> 1) << 3) + (lane >> 3);
+  const int w = blockIdx.x * 16 + lx, h = blockIdx.y * 16 + ly;
+  ray.live = (w < a.W) && (h < a.H);
+  r = ((size_t)n * a.H + min(h, a.H - 1)) * a.W + min(w, a.W - 1);
+  ray.pos = ld3(a.raypos + 3 * r);
+  ray.dir = ld3(a.raydir + 3 * r);
+  const float2 tm = *reinterpret_cast<const float2*>(a.tminmax + 2 * r);
+  tmin = tm.x; tmax = tm.y;
+  return ray.live;
+}
+
+template <bool SHADOW>
+__global__ __launch_bounds__(256) void march_fwd_kernel(MarchArgs a, float* __restrict__ rayrgba,
+                                                        float* __restrict__ raysat, float* __restrict__ shadow) {
+  __shared__ int s_list[4][kMaxHits];
+  __shared__ int s_lo[4][kMaxHits];
+  __shared__ int s_hi[4][kMaxHits];
+  const int n = blockIdx.z;
+  Ray ray; float tmin, tmax; size_t r; int wave;
+  load_ray(a, n, ray, tmin, tmax, r, wave);
+  const size_t vox = (size_t)a.TD * a.TH * a.TW;
+  const float* primpos = a.primpos + (size_t)n * a.K * 3;
+  const float* primrot = a.primrot + (size_t)n * a.K * 9;
+  const float* primscale = a.primscale + (size_t)n * a.K * 3;
+  const float4* tplate = reinterpret_cast<const float4*>(a.tplate) + (size_t)n * a.K * vox;
+  float* shadow_n = SHADOW ? shadow + (size_t)n * a.K * vox * 2 : nullptr;
+  const int num = build_hits(a.K, a.nodeaabb + (size_t)n * (2 * a.K - 1) * 6, primpos, primrot, primscale, a.stepsize,
+                             tmin, tmax, ray, s_list[wave], s_lo[wave], s_hi[wave]);
+
+  float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f, sat0 = -1.f, sat1 = -1.f, sat2 = -1.f;
+  bool sat = false;
+  int iter = 0;
+  // !__all(t > rt1 + 1e-5 || done)   (subset_kernel.h:81)
+  while (__ballot(ray.live && !(ray.t > ray.rt1 + 1e-5f || sat)) != 0ull) {
+    for (int s = 0; s < num; ++s) {
+      // wave-uniform LDS reads -> SGPRs, so the skip is a scalar branch and the box transform below
+      // comes through scalar loads
+      const int w_lo = __builtin_amdgcn_readfirstlane(s_lo[wave][s]);
+      const int w_hi = __builtin_amdgcn_readfirstlane(s_hi[wave][s]);
+      if (iter < w_lo || iter > w_hi) continue;  // no lane of the wave can be inside this box now
+      const int k = __builtin_amdgcn_readfirstlane(s_list[wave][s]);
+      Xform xf;
+      const V3 y0 = xform_fwd(xf, primpos, primrot, primscale, k, ray.pos);
+      const bool ev = ray.live && valid_pos(y0) && !sat && ray.t < ray.rt1 + 1e-5f;
+      if (ev) {
+        const float fade = __expf(-a.fadescale * (__powf(fabsf(y0.x), a.fadeexp) + __powf(fabsf(y0.y), a.fadeexp) +
+                                                  __powf(fabsf(y0.z), a.fadeexp)));
+        Tri q;
+        tri_setup(q, a.TD, a.TH, a.TW, y0);
+        const float4* tp = tplate + (size_t)k * vox;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+          if (q.idx[c] >= 0) {
+            const float4 v = tp[q.idx[c]];
+            s0 += v.x * q.w[c]; s1 += v.y * q.w[c]; s2 += v.z * q.w[c]; s3 += v.w * q.w[c];
+          }
+        }
+        s3 *= fade;
+        if (SHADOW) {
+          const float vis = 1.f - acc3;
+          float* sp = shadow_n + (size_t)k * vox * 2;
+#pragma unroll
+          for (int c = 0; c < 8; ++c) {
+            if (q.idx[c] >= 0) {
+              atomicAdd(sp + (size_t)q.idx[c] * 2, q.w[c] * vis);
+              atomicAdd(sp + (size_t)q.idx[c] * 2 + 1, q.w[c]);
+            }
+          }
+        }
+        // PrimAccumAdditive::forward_prim (primaccum.h:63-79)
+        const float newalpha = acc3 + s3 * a.stepsize;
+        const float contrib = fminf(newalpha, 1.f) - acc3;
+        acc0 += s0 * contrib; acc1 += s1 * contrib; acc2 += s2 * contrib; acc3 += contrib;
+        if (newalpha >= 1.f) {
+          if (!sat) { sat0 = s0; sat1 = s1; sat2 = s2; }
+          sat = true;
+        }
+      }
+    }
+    ray.t += a.stepsize;
+    ray.pos = ray.pos + ray.dir * a.stepsize;
+    ++iter;
+  }
+  if (ray.live) {
+    *reinterpret_cast<float4*>(rayrgba + 4 * r) = make_float4(acc0, acc1, acc2, acc3);
+    if (raysat) { raysat[3 * r] = sat0; raysat[3 * r + 1] = sat1; raysat[3 * r + 2] = sat2; }
+  }
+}
+
+__global__ __launch_bounds__(256) void march_bwd_kernel(MarchArgs a, const float* __restrict__ raysat_im,
+                                                        const float* __restrict__ grad_rayrgba,
+                                                        float* __restrict__ grad_primpos,
+                                                        float* __restrict__ grad_primrot,
+                                                        float* __restrict__ grad_primscale,
+                                                        float* __restrict__ grad_tplate) {
+  __shared__ int s_list[4][kMaxHits];
+  __shared__ int s_lo[4][kMaxHits];
+  __shared__ int s_hi[4][kMaxHits];
+  const int n = blockIdx.z;
+  const int lane = threadIdx.x & 63;
+  Ray ray; float tmin, tmax; size_t r; int wave;
+  load_ray(a, n, ray, tmin, tmax, r, wave);
+  const size_t vox = (size_t)a.TD * a.TH * a.TW;
+  const float* primpos = a.primpos + (size_t)n * a.K * 3;
+  const float* primrot = a.primrot + (size_t)n * a.K * 9;
+  const float* primscale = a.primscale + (size_t)n * a.K * 3;
+  const float4* tplate = reinterpret_cast<const float4*>(a.tplate) + (size_t)n * a.K * vox;
+  float* g_tplate = grad_tplate + (size_t)n * a.K * vox * 4;
+  float* g_pos = grad_primpos + (size_t)n * a.K * 3;
+  float* g_rot = grad_primrot + (size_t)n * a.K * 9;
+  float* g_scale = grad_primscale + (size_t)n * a.K * 3;
+  const int num = build_hits(a.K, a.nodeaabb + (size_t)n * (2 * a.K - 1) * 6, primpos, primrot, primscale, a.stepsize,
+                             tmin, tmax, ray, s_list[wave], s_lo[wave], s_hi[wave]);
+
+  // PrimAccumAdditive::read (primaccum.h:58-61)
+  const float4 dL = ray.live ? *reinterpret_cast<const float4*>(grad_rayrgba + 4 * r) : make_float4(0.f, 0.f, 0.f, 0.f);
+  float rs0 = 0.f, rs1 = 0.f, rs2 = 0.f, rs3 = 0.f;  // (raysat, 1) when the ray saturated, else 0
+  if (ray.live && raysat_im[3 * r] > -1.f) { rs0 = raysat_im[3 * r]; rs1 = raysat_im[3 * r + 1]; rs2 = raysat_im[3 * r + 2]; rs3 = 1.f; }
+  float accw = 0.f;
+  bool sat = false;
+  int iter = 0;
+  const float fe = a.fadeexp, fs = a.fadescale;
+  while (__ballot(ray.live && ray.t < ray.rt1 + 1e-5f && !sat) != 0ull) {
+    for (int s = 0; s < num; ++s) {
+      const int w_lo = __builtin_amdgcn_readfirstlane(s_lo[wave][s]);
+      const int w_hi = __builtin_amdgcn_readfirstlane(s_hi[wave][s]);
+      if (iter < w_lo || iter > w_hi) continue;
+      const int k = __builtin_amdgcn_readfirstlane(s_list[wave][s]);
+      Xform xf;
+      const V3 y0 = xform_fwd(xf, primpos, primrot, primscale, k, ray.pos);
+      const bool ev = ray.live && valid_pos(y0) && !sat && ray.t < ray.rt1 + 1e-5f;
+      if (__ballot(ev) == 0ull) continue;
+      V3 dLy = v3(0.f, 0.f, 0.f);
+      if (ev) {
+        const float ax = fabsf(y0.x), ay = fabsf(y0.y), az = fabsf(y0.z);
+        const float fade = __expf(-fs * (__powf(ax, fe) + __powf(ay, fe) + __powf(az, fe)));
+        Tri q;
+        tri_setup(q, a.TD, a.TH, a.TW, y0);
+        const float4* tp = tplate + (size_t)k * vox;
+        float4 cv[8];
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+          cv[c] = (q.idx[c] >= 0) ? tp[q.idx[c]] : make_float4(0.f, 0.f, 0.f, 0.f);
+          s0 += cv[c].x * q.w[c]; s1 += cv[c].y * q.w[c]; s2 += cv[c].z * q.w[c]; s3 += cv[c].w * q.w[c];
+        }
+        s3 *= fade;
+        // PrimAccumAdditive::forwardbackward_prim (primaccum.h:81-98)
+        const float al = s3 * a.stepsize;
+        sat = sat || (accw + al >= 1.f);
+        const float weight = sat ? (1.f - accw) : al;
+        float d0 = weight * dL.x, d1 = weight * dL.y, d2 = weight * dL.z;
+        float d3 = sat ? 0.f
+                       : a.stepsize * ((s0 - rs0) * dL.x + (s1 - rs1) * dL.y + (s2 - rs2) * dL.z + (1.f - rs3) * dL.w);
+        accw += weight;
+        // PrimSamplerTW::backward (primsampler.h:70-92)
+        const float kf = -(fs * fe);
+        dLy = v3(kf * __powf(ax, fe - 1.f) * (y0.x > 0.f ? 1.f : -1.f), kf * __powf(ay, fe - 1.f) * (y0.y > 0.f ? 1.f : -1.f),
+                 kf * __powf(az, fe - 1.f) * (y0.z > 0.f ? 1.f : -1.f)) * (s3 * d3);
+        d3 *= fade;
+        // trilinear backward (utils.h:619-770): template gradient scatter + position gradient
+        float* gt = g_tplate + (size_t)k * vox * 4;
+        float gix = 0.f, giy = 0.f, giz = 0.f;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+          if (q.idx[c] >= 0) {
+            float* g = gt + (size_t)q.idx[c] * 4;
+            atomicAdd(g, q.w[c] * d0); atomicAdd(g + 1, q.w[c] * d1); atomicAdd(g + 2, q.w[c] * d2);
+            atomicAdd(g + 3, q.w[c] * d3);
+            const float dp = cv[c].x * d0 + cv[c].y * d1 + cv[c].z * d2 + cv[c].w * d3;
+            const int dx = c & 1, dy = (c >> 1) & 1, dz = (c >> 2) & 1;
+            const float wx = dx ? q.fx : 1.f - q.fx, wy = dy ? q.fy : 1.f - q.fy, wz = dz ? q.fz : 1.f - q.fz;
+            gix += (dx ? dp : -dp) * wy * wz;
+            giy += (dy ? dp : -dp) * wx * wz;
+            giz += (dz ? dp : -dp) * wx * wy;
+          }
+        }
+        dLy = dLy + v3(gix * 0.5f * (float)(a.TW - 1), giy * 0.5f * (float)(a.TH - 1), giz * 0.5f * (float)(a.TD - 1));
+      }
+      // PrimTransfSRT::backward (primtransf.h:155-179): 15 wave sums, one atomic each
+      const V3 gs = ev ? xf.rxmt * dLy : v3(0.f, 0.f, 0.f);
+      const V3 d = ev ? dLy * xf.ps : v3(0.f, 0.f, 0.f);
+      const float gp0 = -dot(xf.pr0, d), gp1 = -dot(xf.pr1, d), gp2 = -dot(xf.pr2, d);
+      const float r0 = gol_wave_sum4(gs.x, gs.y, gs.z, gp0);
+      const float r1 = gol_wave_sum4(gp1, gp2, xf.xmt.x * d.x, xf.xmt.x * d.y);
+      const float r2 = gol_wave_sum4(xf.xmt.x * d.z, xf.xmt.y * d.x, xf.xmt.y * d.y, xf.xmt.y * d.z);
+      const float r3 = gol_wave_sum4(xf.xmt.z * d.x, xf.xmt.z * d.y, xf.xmt.z * d.z, 0.f);
+      if ((lane & 15) == 15) {
+        const int j = lane >> 4;  // 0..3: which of the four sums this lane holds
+        // r0: scale.x scale.y scale.z pos.x | r1: pos.y pos.z rot[0] rot[1] | r2: rot[2..5] | r3: rot[6..8]
+        float* p0 = (j < 3) ? (g_scale + 3 * k + j) : (g_pos + 3 * k);
+        atomicAdd(p0, r0);
+        float* p1 = (j < 2) ? (g_pos + 3 * k + 1 + j) : (g_rot + 9 * k + (j - 2));
+        atomicAdd(p1, r1);
+        atomicAdd(g_rot + 9 * k + 2 + j, r2);
+        if (j < 3) atomicAdd(g_rot + 9 * k + 6 + j, r3);
+      }
+    }
+    ray.t += a.stepsize;
+    ray.pos = ray.pos + ray.dir * a.stepsize;
+    ++iter;
+  }
+}
+
+int check_march(int N, int H, int W, int K, int TD, int TH, int TW, float stepsize) {
+  GOL_REQUIRE(N >= 0 && H >= 0 && W >= 0 && K >= 1, "bad sizes");
+  GOL_REQUIRE(TD > 0 && TH > 0 && TW > 0, "bad template size");
+  GOL_REQUIRE(stepsize > 0.f, "stepsize must be positive");
+  GOL_REQUIRE(N <= 65535, "N > 65535");
+  return GOL_OK;
+}
+
+}  // namespace
+
+extern "C" int gol_raydirs_fwd(int N, int H, int W, const float* viewpos, const float* viewrot, const float* focal,
+                               const float* princpt, const float* pixelcoords, float volradius, float* raypos,
+                               float* raydir, float* tminmax, void* stream) {
+  GOL_REQUIRE(N >= 0 && H >= 0 && W >= 0, "negative size");
+  if (N == 0 || H == 0 || W == 0) return GOL_OK;
+  GOL_REQUIRE(viewpos && viewrot && focal && princpt && raypos && raydir && tminmax, "null pointer");
+  GOL_REQUIRE(N <= 65535, "N > 65535");
+  raydirs_kernel<<<dim3(gol_cdiv((long long)H * W, 256), N), 256, 0, (hipStream_t)stream>>>(
+      N, H, W, viewpos, viewrot, focal, princpt, pixelcoords, volradius, raypos, raydir, tminmax);
+  GOL_CHECK_LAUNCH();
+  return GOL_OK;
+}
+
+extern "C" int gol_mvp_aabb(int N, int K, const float* primpos, const float* primrot, const float* primscale,
+                            float* nodeaabb, void* stream) {
+  GOL_REQUIRE(N >= 0 && K >= 1, "bad sizes");
+  if (N == 0) return GOL_OK;
+  GOL_REQUIRE(primpos && primrot && primscale && nodeaabb, "null pointer");
+  aabb_kernel<<<N, 1024, 0, (hipStream_t)stream>>>(K, primpos, primrot, primscale, nodeaabb);
+  GOL_CHECK_LAUNCH();
+  return GOL_OK;
+}
+
+extern "C" int gol_mvp_march_fwd(int N, int H, int W, int K, const float* raypos, const float* raydir, float stepsize,
+                                 const float* tminmax, const float* nodeaabb, const float* primpos,
+                                 const float* primrot, const float* primscale, const float* tplate, int TD, int TH,
+                                 int TW, float fadescale, float fadeexp, float* rayrgba, float* raysat, float* shadow,
+                                 void* stream) {
+  int rc = check_march(N, H, W, K, TD, TH, TW, stepsize);
+  if (rc != GOL_OK) return rc;
+  if (N == 0 || H == 0 || W == 0) return GOL_OK;
+  GOL_REQUIRE(raypos && raydir && tminmax && nodeaabb && primpos && primrot && primscale && tplate && rayrgba,
+              "null pointer");
+  MarchArgs a{N, H, W, K, TD, TH, TW, stepsize, fadescale, fadeexp, raypos, raydir, tminmax, nodeaabb,
+              primpos, primrot, primscale, tplate};
+  dim3 grid(gol_cdiv(W, 16), gol_cdiv(H, 16), N);
+  if (shadow) march_fwd_kernel<true><<<grid, 256, 0, (hipStream_t)stream>>>(a, rayrgba, raysat, shadow);
+  else march_fwd_kernel<false><<<grid, 256, 0, (hipStream_t)stream>>>(a, rayrgba, raysat, shadow);
+  GOL_CHECK_LAUNCH();
+  return GOL_OK;
+}
+
+extern "C" int gol_mvp_march_bwd(int N, int H, int W, int K, const float* raypos, const float* raydir, float stepsize,
+                                 const float* tminmax, const float* nodeaabb, const float* primpos,
+                                 const float* primrot, const float* primscale, const float* tplate, int TD, int TH,
+                                 int TW, float fadescale, float fadeexp, const float* raysat,
+                                 const float* grad_rayrgba, float* grad_primpos, float* grad_primrot,
+                                 float* grad_primscale, float* grad_tplate, void* stream) {
+  int rc = check_march(N, H, W, K, TD, TH, TW, stepsize);
+  if (rc != GOL_OK) return rc;
+  if (N == 0 || H == 0 || W == 0) return GOL_OK;
+  GOL_REQUIRE(raypos && raydir && tminmax && nodeaabb && primpos && primrot && primscale && tplate, "null pointer");
+  GOL_REQUIRE(raysat && grad_rayrgba && grad_primpos && grad_primrot && grad_primscale && grad_tplate, "null pointer");
+  MarchArgs a{N, H, W, K, TD, TH, TW, stepsize, fadescale, fadeexp, raypos, raydir, tminmax, nodeaabb,
+              primpos, primrot, primscale, tplate};
+  dim3 grid(gol_cdiv(W, 16), gol_cdiv(H, 16), N);
+  march_bwd_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(a, raysat, grad_rayrgba, grad_primpos, grad_primrot,
+                                                           grad_primscale, grad_tplate);
+  GOL_CHECK_LAUNCH();
+  return GOL_OK;
+}

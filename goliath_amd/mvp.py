@@ -1,0 +1,232 @@
+"""Mixture-of-Volumetric-Primitives ray marching (host side) on top of the C ABI.
+
+Drop-in for the reference operators (interfaces only; the work happens in libgoliath_hip.so):
+  mvpraymarch(...)                      <- extensions/mvpraymarch/mvpraymarch.py:313-418
+  mvpraymarchlib.compute_aabb / raymarch_forward / raymarch_backward
+                                        <- extensions/mvpraymarch/mvpraymarch.cpp:145-409 (pybind module)
+  compute_raydirs(...), utilslib.compute_raydirs_forward
+                                        <- extensions/utils/utils.py:26-54, utils.cpp:46-82
+  Raymarcher                            <- ca_code/utils/render_raymarcher.py:18-71
+Supported configuration = the one every model in the reference uses: algo 0 without a
+warp field, usebvh="fixedorder", channels-last template, additive accumulation.  The options the
+reference accepts but its kernels ignore (sortprims, maxhitboxes, synchitboxes, accum, termthresh,
+griddim, blocksize) are accepted and ignored here too.  Everything runs on the CURRENT stream with a
+device guard (the reference uses stream 0).
+"""
+import torch
+
+from . import _lib
+from ._lib import c_float, c_int, fptr, stream_ptr
+
+
+def _dims(template):
+    if template.dim() != 6 or template.size(-1) != 4:
+        raise RuntimeError("template must be channels-last [N, K, TD, TH, TW, 4]")
+    return template.shape[1], template.shape[2], template.shape[3], template.shape[4]
+
+
+class _MvpLib:
+    """Same entry points as the reference's compiled `mvpraymarchlib`."""
+
+    @staticmethod
+    def compute_morton(*_a, **_k):
+        raise NotImplementedError("Morton/LBVH build is a dead path in the reference (SURVEY 2.3): use usebvh='fixedorder'")
+
+    build_tree = compute_morton
+
+    @staticmethod
+    def compute_aabb(primpos, primrot, primscale, sortedobjid, nodechildren, nodeparent, nodeaabb, algo=0):
+        N, K = primpos.shape[:2]
+        with torch.cuda.device(primpos.device):
+            _lib.call("gol_mvp_aabb", c_int(N), c_int(K), fptr(primpos, "primpos"), fptr(primrot, "primrot"),
+                      fptr(primscale, "primscale"), fptr(nodeaabb, "nodeaabb"), stream_ptr())
+        return []
+
+    @staticmethod
+    def raymarch_forward(raypos, raydir, stepsize, tminmax, sortedobjid, nodechildren, nodeaabb, primpos, primrot,
+                         primscale, template, warp, rayrgba, raysat, rayterm, shadow, algo=0, sortboxes=False,
+                         maxhitboxes=512, synchitboxes=True, chlast=True, fadescale=8.0, fadeexp=8.0, accum=0,
+                         termthresh=0.0, griddim=3, blocksizex=8, blocksizey=16):
+        if warp is not None or algo != 0:
+            raise NotImplementedError("warp fields (algo 1) have no caller in the reference and are not implemented")
+        if not chlast:
+            raise NotImplementedError("only channels-last templates (chlast=True, the reference default)")
+        if nodeaabb is None:
+            raise NotImplementedError("usebvh=False is not implemented; use 'fixedorder'")
+        N, H, W = raypos.shape[:3]
+        K, TD, TH, TW = _dims(template)
+        with torch.cuda.device(raypos.device):
+            _lib.call("gol_mvp_march_fwd", c_int(N), c_int(H), c_int(W), c_int(K), fptr(raypos, "raypos"),
+                      fptr(raydir, "raydir"), c_float(stepsize), fptr(tminmax, "tminmax"), fptr(nodeaabb, "nodeaabb"),
+                      fptr(primpos, "primpos"), fptr(primrot, "primrot"), fptr(primscale, "primscale"),
+                      fptr(template, "template"), c_int(TD), c_int(TH), c_int(TW), c_float(fadescale),
+                      c_float(fadeexp), fptr(rayrgba, "rayrgba"), fptr(raysat, "raysat"), fptr(shadow, "shadow"),
+                      stream_ptr())
+        return []
+
+    @staticmethod
+    def raymarch_backward(raypos, raydir, stepsize, tminmax, sortedobjid, nodechildren, nodeaabb, primpos,
+                          grad_primpos, primrot, grad_primrot, primscale, grad_primscale, template, grad_template,
+                          warp, grad_warp, rayrgba, grad_rayrgba, raysat, rayterm, algo=0, sortboxes=False,
+                          maxhitboxes=512, synchitboxes=True, chlast=True, fadescale=8.0, fadeexp=8.0, accum=0,
+                          termthresh=0.0, griddim=3, blocksizex=8, blocksizey=16):
+        if warp is not None or algo != 0 or not chlast:
+            raise NotImplementedError("only algo 0 / channels-last / no warp field")
+        N, H, W = raypos.shape[:3]
+        K, TD, TH, TW = _dims(template)
+        with torch.cuda.device(raypos.device):
+            _lib.call("gol_mvp_march_bwd", c_int(N), c_int(H), c_int(W), c_int(K), fptr(raypos), fptr(raydir),
+                      c_float(stepsize), fptr(tminmax), fptr(nodeaabb), fptr(primpos), fptr(primrot), fptr(primscale),
+                      fptr(template), c_int(TD), c_int(TH), c_int(TW), c_float(fadescale), c_float(fadeexp),
+                      fptr(raysat, "raysat"), fptr(grad_rayrgba, "grad_rayrgba"), fptr(grad_primpos),
+                      fptr(grad_primrot), fptr(grad_primscale), fptr(grad_template), stream_ptr())
+        return []
+
+
+mvpraymarchlib = _MvpLib()
+
+
+def build_accel(primtransfin, algo=0, fixedorder=True):
+    """Fixed-order tree (mvpraymarch.py:21-84 with fixedorder=True): the implicit heap over the
+    primitives in their given order; only the node boxes are computed.  Returns (sortedobjid,
+    nodechildren, nodeaabb) like the reference (the first two are index tables the kernels never read)."""
+    if not fixedorder:
+        raise NotImplementedError("only usebvh='fixedorder' (the default of every caller in the reference)")
+    primpos, primrot, primscale = primtransfin
+    N, K = primpos.shape[:2]
+    dev = primpos.device
+    sortedobjid = torch.arange(K, dtype=torch.int32, device=dev).repeat(N, 1)
+    nodes = torch.arange(2 * K - 1, dtype=torch.int32, device=dev)
+    children = torch.stack([2 * nodes + 1, 2 * nodes + 2], -1)
+    children[K - 1:] = -1 - torch.arange(K, dtype=torch.int32, device=dev)[:, None]  # leaves: -(k+1) markers
+    nodechildren = children[None].repeat(N, 1, 1)
+    nodeaabb = torch.empty(N, 2 * K - 1, 2, 3, device=dev)
+    mvpraymarchlib.compute_aabb(primpos, primrot, primscale, sortedobjid, nodechildren, None, nodeaabb, algo)
+    return sortedobjid, nodechildren, nodeaabb
+
+
+class MVPRaymarch(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, raypos, raydir, stepsize, tminmax, primpos, primrot, primscale, template, gradmode, opts):
+        for name, t, last in (("raypos", raypos, 3), ("raydir", raydir, 3), ("tminmax", tminmax, 2)):
+            assert t.is_contiguous() and t.size(3) == last, name
+        for name, t in (("primpos", primpos), ("primrot", primrot), ("primscale", primscale)):
+            assert t.is_contiguous() and t.size(2) == 3, name
+        assert template.is_contiguous() and template.dim() == 6 and template.size(-1) == 4
+        _, _, nodeaabb = build_accel((primpos, primrot, primscale), opts["algo"], fixedorder=True)
+        N, H, W = raypos.shape[:3]
+        rayrgba = torch.empty(N, H, W, 4, device=raypos.device)
+        raysat = torch.full((N, H, W, 3), -1.0, device=raypos.device) if gradmode else None
+        shadow = torch.zeros(*template.shape[:5], 2, device=template.device) if opts["with_shadow"] else None
+        mvpraymarchlib.raymarch_forward(raypos, raydir, stepsize, tminmax, None, None, nodeaabb, primpos, primrot,
+                                        primscale, template, None, rayrgba, raysat, None, shadow,
+                                        fadescale=opts["fadescale"], fadeexp=opts["fadeexp"])
+        ctx.save_for_backward(raypos, raydir, tminmax, nodeaabb, primpos, primrot, primscale, template, raysat)
+        ctx.opts, ctx.stepsize = opts, stepsize
+        if shadow is not None:
+            ctx.mark_non_differentiable(shadow)
+        return rayrgba, shadow
+
+    @staticmethod
+    def backward(ctx, grad_rayrgba, _grad_shadow):
+        raypos, raydir, tminmax, nodeaabb, primpos, primrot, primscale, template, raysat = ctx.saved_tensors
+        if raysat is None:
+            raise RuntimeError("mvpraymarch was run with gradients disabled")
+        g_pos, g_rot, g_scale = torch.zeros_like(primpos), torch.zeros_like(primrot), torch.zeros_like(primscale)
+        g_tpl = torch.zeros_like(template)
+        mvpraymarchlib.raymarch_backward(raypos, raydir, ctx.stepsize, tminmax, None, None, nodeaabb, primpos, g_pos,
+                                         primrot, g_rot, primscale, g_scale, template, g_tpl, None, None, None,
+                                         grad_rayrgba.contiguous(), raysat, None, fadescale=ctx.opts["fadescale"],
+                                         fadeexp=ctx.opts["fadeexp"])
+        return None, None, None, None, g_pos, g_rot, g_scale, g_tpl, None, None
+
+
+def mvpraymarch(raypos, raydir, stepsize, tminmax, primtransf, template, warp, rayterm=None, algo=0,
+                usebvh="fixedorder", sortprims=False, randomorder=False, maxhitboxes=512, synchitboxes=True,
+                chlast=True, fadescale=8.0, fadeexp=8.0, accum=2, termthresh=0.99, griddim=3, blocksize=(8, 16),
+                bwdblocksize=(8, 16), with_shadow=False):
+    """raypos/raydir[N,H,W,3], tminmax[N,H,W,2], primtransf = (primpos[N,K,3], primrot[N,K,3,3],
+    primscale[N,K,3]) or the packed [N,K,5,3] tensor, template[N,K,TD,TH,TW,4] -> rayrgba[N,H,W,4]
+    (and the normalised shadow grid when with_shadow)."""
+    if warp is not None or algo != 0:
+        raise NotImplementedError("warp fields (algo 1) have no caller in the reference and are not implemented")
+    if usebvh != "fixedorder" or randomorder or not chlast:
+        raise NotImplementedError("only usebvh='fixedorder', randomorder=False, chlast=True")
+    if isinstance(primtransf, tuple):
+        primpos, primrot, primscale = primtransf
+    else:
+        primpos, primrot, primscale = (primtransf[:, :, 0, :].contiguous(), primtransf[:, :, 1:4, :].contiguous(),
+                                       primtransf[:, :, 4, :].contiguous())
+    opts = dict(algo=algo, fadescale=float(fadescale), fadeexp=float(fadeexp), with_shadow=bool(with_shadow))
+    out, shadow = MVPRaymarch.apply(raypos, raydir, float(stepsize), tminmax, primpos, primrot, primscale, template,
+                                    torch.is_grad_enabled(), opts)
+    if with_shadow:
+        return out, shadow[..., 0:1] / (shadow[..., 1:] + 1e-5)
+    return out
+
+
+# ------------------------------------------------------------------------------------------- raydirs
+class _UtilsLib:
+    @staticmethod
+    def compute_raydirs_forward(viewpos, viewrot, focal, princpt, pixelcoords, W, H, volradius, raypos, raydir,
+                                tminmax):
+        N = viewpos.shape[0]
+        with torch.cuda.device(viewpos.device):
+            _lib.call("gol_raydirs_fwd", c_int(N), c_int(H), c_int(W), fptr(viewpos, "viewpos"),
+                      fptr(viewrot, "viewrot"), fptr(focal, "focal"), fptr(princpt, "princpt"),
+                      fptr(pixelcoords, "pixelcoords"), c_float(volradius), fptr(raypos), fptr(raydir),
+                      fptr(tminmax), stream_ptr())
+        return []
+
+    @staticmethod
+    def compute_raydirs_backward(*_a, **_k):  # the reference's backward kernel writes nothing (utils.py:49-50)
+        return []
+
+
+utilslib = _UtilsLib()
+
+
+def compute_raydirs(viewpos, viewrot, focal, princpt, pixelcoords, volradius):
+    """pixelcoords: [N,H,W,2] tensor or a (W, H) tuple for the implicit pixel grid.  No gradients
+    (the reference returns None for every input, utils.py:49-50)."""
+    N = viewpos.size(0)
+    if isinstance(pixelcoords, tuple):
+        W, H = pixelcoords
+        pc = None
+    else:
+        pc = pixelcoords.detach()
+        H, W = pc.size(1), pc.size(2)
+    for t in (viewpos, viewrot, focal, princpt) + ((pc,) if pc is not None else ()):
+        assert t.is_contiguous()
+    dev = viewpos.device
+    raypos, raydir = torch.empty(N, H, W, 3, device=dev), torch.empty(N, H, W, 3, device=dev)
+    tminmax = torch.empty(N, H, W, 2, device=dev)
+    utilslib.compute_raydirs_forward(viewpos.detach(), viewrot.detach(), focal.detach(), princpt.detach(), pc, W, H,
+                                     float(volradius), raypos, raydir, tminmax)
+    return raypos, raydir, tminmax
+
+
+class Raymarcher(torch.nn.Module):
+    """ca_code/utils/render_raymarcher.py:17-71: scale positions by the volume radius, keep only
+    `valid_prims`, march, return (rgb[N,3,H,W], alpha[N,1,H,W], rgba[N,4,H,W], shadow)."""
+
+    def __init__(self, volradius, dt: float = 1.0):
+        super().__init__()
+        self.volume_radius = volradius
+        self.dt = dt / self.volume_radius  # step size in normalised volume units
+
+    def forward(self, raypos, raydir, tminmax, decout, renderoptions={}, rayterm=None, with_shadow=False):
+        primpos = decout["primpos"] / self.volume_radius
+        primrot, primscale, template = decout["primrot"], decout["primscale"], decout["primrgba"]
+        keep = decout.get("valid_prims", None)
+        if keep is not None:
+            assert keep.shape[0] == template.shape[1]
+            template, primpos = template[:, keep].contiguous(), primpos[:, keep].contiguous()
+            primrot, primscale = primrot[:, keep].contiguous(), primscale[:, keep].contiguous()
+        known = mvpraymarch.__code__.co_varnames
+        out = mvpraymarch(raypos, raydir, self.dt, tminmax, (primpos, primrot, primscale), template=template,
+                          warp=decout["warp"] if "warp" in decout else None, rayterm=rayterm,
+                          with_shadow=with_shadow, **{k: v for k, v in renderoptions.items() if k in known})
+        rayrgba, shadow = out if with_shadow else (out, None)
+        rayrgba = rayrgba.permute(0, 3, 1, 2)
+        return rayrgba[:, :3].contiguous(), rayrgba[:, 3:4].contiguous(), rayrgba, shadow

@@ -197,6 +197,38 @@ int gol_shade_fwd(const gol_shade_in* in, const gol_shade_out* out, void* stream
 int gol_shade_bwd(const gol_shade_in* in, const gol_shade_out* saved, const gol_shade_out_grad* g,
                   const gol_shade_in_grad* gin, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Mixture-of-Volumetric-Primitives ray marcher + its helpers (BASELINE config 5).
+ * Replaces utilslib.compute_raydirs_forward (extensions/utils/utils.cpp:46-82, kernel
+ * utils_kernel.cu:11-51) and mvpraymarchlib.compute_aabb / raymarch_forward / raymarch_backward
+ * (extensions/mvpraymarch/mvpraymarch.cpp:145-400; kernels mvpraymarch_subset_kernel.h:7-228,
+ * bvh.cu:157-201) for the configuration every model in the reference uses: algo 0 (no warp field),
+ * fixed-order BVH (implicit heap, children 2i+1 / 2i+2), channels-last template, additive
+ * accumulation.  Unlike the reference (stream 0, no device guard) everything runs on `stream`.
+ *   raypos/raydir[N,H,W,3] tminmax[N,H,W,2] primpos[N,K,3] primrot[N,K,3,3] primscale[N,K,3]
+ *   tplate[N,K,TD,TH,TW,4] nodeaabb[N,2K-1,2,3]
+ * march_fwd writes rayrgba[N,H,W,4] (every element) and, when non-NULL, raysat[N,H,W,3]; when
+ * shadow[N,K,TD,TH,TW,2] is non-NULL it is ACCUMULATED into (primsplatter.h:29-36).
+ * march_bwd ACCUMULATES into grad_primpos/rot/scale and grad_tplate (caller zeroes them,
+ * mvpraymarch.py:258-264).
+ * ---------------------------------------------------------------------------------------- */
+int gol_raydirs_fwd(int N, int H, int W, const float* viewpos, const float* viewrot, const float* focal,
+                    const float* princpt, const float* pixelcoords /* NULL = (w,h) grid */, float volradius,
+                    float* raypos, float* raydir, float* tminmax, void* stream);
+int gol_mvp_aabb(int N, int K, const float* primpos, const float* primrot, const float* primscale,
+                 float* nodeaabb, void* stream);
+int gol_mvp_march_fwd(int N, int H, int W, int K, const float* raypos, const float* raydir, float stepsize,
+                      const float* tminmax, const float* nodeaabb, const float* primpos,
+                      const float* primrot, const float* primscale, const float* tplate, int TD, int TH,
+                      int TW, float fadescale, float fadeexp, float* rayrgba, float* raysat, float* shadow,
+                      void* stream);
+int gol_mvp_march_bwd(int N, int H, int W, int K, const float* raypos, const float* raydir, float stepsize,
+                      const float* tminmax, const float* nodeaabb, const float* primpos,
+                      const float* primrot, const float* primscale, const float* tplate, int TD, int TH,
+                      int TW, float fadescale, float fadeexp, const float* raysat, const float* grad_rayrgba,
+                      float* grad_primpos, float* grad_primrot, float* grad_primscale, float* grad_tplate,
+                      void* stream);
+
 #ifdef __cplusplus
 }
 #endif

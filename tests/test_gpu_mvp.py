@@ -1,0 +1,121 @@
+"""GPU parity: HIP MVP ray marcher / raydirs / AABBs (C ABI) vs
+  (a) golden vectors from the reference's own in-tree PyTorch ray marcher (tests/golden/mvp_golden.npz,
+      raydirs_golden.npz) and (b) the C oracle (oracle/mvp_oracle.c, itself pinned to (a)).
+Tolerance rel-L2 <= 1e-4 forward; gradients 3e-4 (float atomics + __powf/__expf like the reference's
+-use_fast_math build)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from scenes import rel_l2
+from test_oracle_mvp import load, mvp_case
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_mvp_matches_reference_golden(tag):
+    from goliath_amd import mvp
+
+    G = load("mvp_golden.npz")
+    leaf = {k: G[f"{tag}/leaf_{k}"].cuda().requires_grad_(True) for k in ("template", "primpos", "primrot", "primscale")}
+    template = F.softplus(leaf["template"] * 1.5).permute(0, 1, 3, 4, 5, 2).contiguous()
+    fs, fe = (float(v) for v in G[f"{tag}/fade"])
+    out = mvp.mvpraymarch(G[f"{tag}/raypos"].cuda(), G[f"{tag}/raydir"].cuda(), float(G[f"{tag}/stepsize"]),
+                          G[f"{tag}/tminmax"].cuda(), (leaf["primpos"] * 0.3, leaf["primrot"].contiguous(),
+                                                       torch.exp(0.1 * leaf["primscale"])),
+                          template, None, fadescale=fs, fadeexp=fe, accum=0)
+    assert rel_l2(out, G[f"{tag}/rayrgba"]) < 1e-4, rel_l2(out, G[f"{tag}/rayrgba"])
+    out.backward(torch.ones_like(out))
+    for k in leaf:
+        e = rel_l2(leaf[k].grad, G[f"{tag}/grad_{k}"])
+        assert e < 3e-4, (k, e)
+
+
+def _random_case(N, H, W, K, T, seed, step=0.05):
+    g = torch.Generator().manual_seed(seed)
+    k3 = round(K ** (1 / 3))
+    lin = torch.linspace(-0.75, 0.75, k3)
+    centres = torch.stack(torch.meshgrid(lin, lin, lin, indexing="ij"), -1).reshape(-1, 3)[:K]
+    primpos = (centres[None] + 0.05 * torch.randn(N, K, 3, generator=g)).contiguous()
+    q = F.normalize(torch.randn(N, K, 4, generator=g), dim=-1)
+    w, x, y, z = q.unbind(-1)
+    primrot = torch.stack([1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y), 2 * (x * y + w * z),
+                           1 - 2 * (x * x + z * z), 2 * (y * z - w * x), 2 * (x * z - w * y), 2 * (y * z + w * x),
+                           1 - 2 * (x * x + y * y)], -1).reshape(N, K, 3, 3).contiguous()
+    primscale = (k3 * (0.8 + 0.4 * torch.rand(N, K, 3, generator=g))).contiguous()
+    template = F.softplus(1.5 * torch.randn(N, K, T[0], T[1], T[2], 4, generator=g))
+    template[..., 3] = F.softplus(1.5 * torch.randn(N, K, *T, generator=g) - 2.0)
+    viewpos = torch.tensor([[0.1, -0.2, -3.0]] * N) + 0.2 * torch.randn(N, 3, generator=g)
+    viewrot = torch.eye(3)[None].repeat(N, 1, 1).contiguous()
+    focal = torch.full((N, 2), 1.6 * W)
+    princpt = torch.tensor([[W * 0.5, H * 0.5]] * N)
+    return dict(primpos=primpos, primrot=primrot, primscale=primscale, template=template.contiguous(), viewpos=viewpos,
+                viewrot=viewrot, focal=focal, princpt=princpt, step=step)
+
+
+def test_raydirs_and_aabb_vs_golden_and_oracle():
+    from goliath_amd import mvp
+    from oracle import cref
+
+    G = load("raydirs_golden.npz")
+    c = lambda t: t.cuda().contiguous()
+    rp, rd, tm = mvp.compute_raydirs(c(G["viewpos"]), c(G["viewrot"]), c(G["focal"]), c(G["princpt"]),
+                                     c(G["pixelcoords"]), 1.0)
+    assert rel_l2(rd, G["raydir"]) < 1e-6 and rel_l2(tm, G["tminmax"]) < 1e-5
+    H, W = G["pixelcoords"].shape[1:3]
+    rp2, rd2, tm2 = mvp.compute_raydirs(c(G["viewpos"]), c(G["viewrot"]), c(G["focal"]), c(G["princpt"]), (W, H), 1.0)
+    assert torch.equal(rd2, rd) and torch.equal(tm2, tm) and torch.equal(rp2, rp)
+    case = _random_case(2, 8, 8, 27, (4, 4, 4), 3)
+    _, _, aabb = mvp.build_accel((c(case["primpos"]), c(case["primrot"]), c(case["primscale"])))
+    assert rel_l2(aabb, cref.mvp_aabb(case["primpos"], case["primrot"], case["primscale"])) < 1e-6
+
+
+@pytest.mark.parametrize("N,H,W,K,T", [(2, 70, 50, 64, (4, 8, 8)), (1, 33, 17, 27, (3, 5, 6)), (1, 40, 40, 1, (8, 8, 8))])
+def test_mvp_vs_oracle_with_shadow(N, H, W, K, T):
+    """Non power-of-two K (heap leaves on two levels), ragged image sizes, K = 1, shadow splatting."""
+    from goliath_amd import mvp
+    from oracle import cref
+
+    case = _random_case(N, H, W, K, T, seed=K)
+    c = lambda t: t.cuda().contiguous()
+    rp, rd, tm = mvp.compute_raydirs(c(case["viewpos"]), c(case["viewrot"]), c(case["focal"]), c(case["princpt"]),
+                                     (W, H), 1.0)
+    leaf = {k: c(case[k]).requires_grad_(True) for k in ("primpos", "primrot", "primscale", "template")}
+    out, shadow = mvp.mvpraymarch(rp, rd, case["step"], tm, (leaf["primpos"], leaf["primrot"], leaf["primscale"]),
+                                  leaf["template"], None, fadescale=6.5, fadeexp=7.5, with_shadow=True)
+    ref, raysat, ref_shadow = cref.mvp_forward(rp.cpu(), rd.cpu(), case["step"], tm.cpu(), case["primpos"],
+                                               case["primrot"], case["primscale"], case["template"], 6.5, 7.5,
+                                               with_shadow=True)
+    assert float(ref[..., 3].max()) > 0.2
+    assert rel_l2(out, ref) < 1e-4, rel_l2(out, ref)
+    ref_sh = ref_shadow[..., 0:1] / (ref_shadow[..., 1:] + 1e-5)
+    assert rel_l2(shadow, ref_sh) < 1e-3
+    gen = torch.Generator().manual_seed(1)
+    go = torch.randn(out.shape, generator=gen)
+    out.backward(go.cuda())
+    gp, gr, gs, gt = cref.mvp_backward(rp.cpu(), rd.cpu(), case["step"], tm.cpu(), case["primpos"], case["primrot"],
+                                       case["primscale"], case["template"], raysat, go, 6.5, 7.5)
+    for k, g in (("primpos", gp), ("primrot", gr), ("primscale", gs), ("template", gt)):
+        e = rel_l2(leaf[k].grad, g)
+        assert e < 3e-4, (k, e)
+
+
+def test_raymarcher_wrapper_and_errors():
+    from goliath_amd import mvp
+
+    case = _random_case(1, 32, 32, 8, (4, 4, 4), 5)
+    c = lambda t: t.cuda().contiguous()
+    rp, rd, tm = mvp.compute_raydirs(c(case["viewpos"]), c(case["viewrot"]), c(case["focal"]), c(case["princpt"]),
+                                     (32, 32), 1.0)
+    rm = mvp.Raymarcher(volradius=1.0, dt=0.05)
+    dec = dict(primpos=c(case["primpos"]), primrot=c(case["primrot"]), primscale=c(case["primscale"]),
+               primrgba=c(case["template"]), valid_prims=(torch.arange(8) % 2 == 0).cuda())
+    rgb, alpha, rgba, shadow = rm(rp, rd, tm, dec, renderoptions={"fadescale": 6.5, "fadeexp": 7.5, "bogus": 1})
+    assert rgb.shape == (1, 3, 32, 32) and alpha.shape == (1, 1, 32, 32) and shadow is None
+    with pytest.raises(NotImplementedError):
+        mvp.mvpraymarch(rp, rd, 0.05, tm, (dec["primpos"], dec["primrot"], dec["primscale"]), dec["primrgba"],
+                        torch.zeros(1, 8, 2, 2, 2, 3).cuda())
+    with pytest.raises(RuntimeError):  # CPU tensors
+        mvp.mvpraymarch(rp.cpu(), rd.cpu(), 0.05, tm.cpu(), (case["primpos"], case["primrot"], case["primscale"]),
+                        case["template"], None)
