@@ -19,6 +19,11 @@ from . import _lib
 from ._lib import c_float, c_int, fptr, stream_ptr
 
 
+def _need_gpu(t, name):
+    if not t.is_cuda:
+        raise _lib.GoliathHipError(f"{name} must be a CUDA tensor (there is no CPU path)")  # CHECK_INPUT
+
+
 def _dims(template):
     if template.dim() != 6 or template.size(-1) != 4:
         raise RuntimeError("template must be channels-last [N, K, TD, TH, TW, 4]")
@@ -37,6 +42,7 @@ class _MvpLib:
     @staticmethod
     def compute_aabb(primpos, primrot, primscale, sortedobjid, nodechildren, nodeparent, nodeaabb, algo=0):
         N, K = primpos.shape[:2]
+        _need_gpu(primpos, "primpos")
         with torch.cuda.device(primpos.device):
             _lib.call("gol_mvp_aabb", c_int(N), c_int(K), fptr(primpos, "primpos"), fptr(primrot, "primrot"),
                       fptr(primscale, "primscale"), fptr(nodeaabb, "nodeaabb"), stream_ptr())
@@ -55,6 +61,7 @@ class _MvpLib:
             raise NotImplementedError("usebvh=False is not implemented; use 'fixedorder'")
         N, H, W = raypos.shape[:3]
         K, TD, TH, TW = _dims(template)
+        _need_gpu(raypos, "raypos")
         with torch.cuda.device(raypos.device):
             _lib.call("gol_mvp_march_fwd", c_int(N), c_int(H), c_int(W), c_int(K), fptr(raypos, "raypos"),
                       fptr(raydir, "raydir"), c_float(stepsize), fptr(tminmax, "tminmax"), fptr(nodeaabb, "nodeaabb"),
@@ -74,6 +81,7 @@ class _MvpLib:
             raise NotImplementedError("only algo 0 / channels-last / no warp field")
         N, H, W = raypos.shape[:3]
         K, TD, TH, TW = _dims(template)
+        _need_gpu(raypos, "raypos")
         with torch.cuda.device(raypos.device):
             _lib.call("gol_mvp_march_bwd", c_int(N), c_int(H), c_int(W), c_int(K), fptr(raypos), fptr(raydir),
                       c_float(stepsize), fptr(tminmax), fptr(nodeaabb), fptr(primpos), fptr(primrot), fptr(primscale),
@@ -171,6 +179,7 @@ class _UtilsLib:
     def compute_raydirs_forward(viewpos, viewrot, focal, princpt, pixelcoords, W, H, volradius, raypos, raydir,
                                 tminmax):
         N = viewpos.shape[0]
+        _need_gpu(viewpos, "viewpos")
         with torch.cuda.device(viewpos.device):
             _lib.call("gol_raydirs_fwd", c_int(N), c_int(H), c_int(W), fptr(viewpos, "viewpos"),
                       fptr(viewrot, "viewrot"), fptr(focal, "focal"), fptr(princpt, "princpt"),
