@@ -95,9 +95,7 @@ def step(t, cfg, world):
     loss = (rgb - t["target"]).abs().mean()
     loss.backward()
     if world > 1:
-        import torch.distributed as dist
-
-        dist.all_reduce(t["albedo"].grad)  # the path's only parameter (rgca.py:462-464)
+        t["_sync"].sync()  # reduce-scatter + all-gather of the path's only parameter (albedo, rgca.py:462-464)
     return loss
 
 
@@ -183,6 +181,9 @@ def main():
     from goliath_amd import _lib, splat
 
     t = make_inputs(cfg, dev, rank)
+    from goliath_amd import parallel
+
+    t["_sync"] = parallel.GradSync([t["albedo"]])
     B, N = cfg["views_per_gpu"], cfg["gaussians"]
     P = cfg["height"] * cfg["width"]
 

@@ -1,0 +1,47 @@
+"""Make the reference's Python code (`ca_code`, `extensions/*/*.py`) run on libgoliath_hip.so unchanged.
+
+    import goliath_amd.dropin as dropin
+    dropin.install()              # before importing ca_code.* / extensions.*
+    dropin.patch_rgca()           # optional: fused shading tail + batched, sync-free render
+
+`install()` registers the module names the reference imports for its native code:
+    gsplat            project_gaussians, rasterize_gaussians   (ca_code/utils/render_gsplat.py:10-11)
+    sgutilslib        evaluate_gaussian_fwd/_bwd               (extensions/sgutils/sgutils.py:12-15)
+    mvpraymarchlib    compute_aabb, raymarch_forward/_backward (extensions/mvpraymarch/mvpraymarch.py:15-18)
+    utilslib          compute_raydirs_forward/_backward        (extensions/utils/utils.py:20-23)
+so `run_train.py` / `run_vis_relight.py` need no edit.  `patch_rgca()` additionally swaps the two
+Python-level hot spots of ca_code.models.rgca for their fused equivalents (same signatures/returns).
+"""
+import sys
+import types
+
+import torch
+
+
+def install():
+    from . import mvp, sg, splat
+
+    gs = types.ModuleType("gsplat")
+    gs.project_gaussians = splat.project_gaussians
+    gs.rasterize_gaussians = splat.rasterize_gaussians
+    gs.__version__ = "0.1.11+goliath_amd"
+    sys.modules["gsplat"] = gs
+    for name, obj in (("sgutilslib", sg.sgutilslib), ("mvpraymarchlib", mvp.mvpraymarchlib), ("utilslib", mvp.utilslib)):
+        m = types.ModuleType(name)
+        for attr in dir(obj):
+            if not attr.startswith("_"):
+                setattr(m, attr, getattr(obj, attr))
+        sys.modules[name] = m
+    return ["gsplat", "sgutilslib", "mvpraymarchlib", "utilslib"]
+
+
+def patch_rgca(rgca_module=None):
+    """Swap AutoEncoder.render (rgca.py:112-151) and PrimDecoder.forward (rgca.py:466-620) for the
+    batched / fused versions in goliath_amd.rgca.  Returns the patched module."""
+    from . import rgca as fused
+
+    if rgca_module is None:
+        import ca_code.models.rgca as rgca_module
+    rgca_module.AutoEncoder.render = fused.autoencoder_render
+    rgca_module.PrimDecoder.forward = fused.prim_decoder_forward
+    return rgca_module

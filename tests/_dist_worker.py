@@ -1,0 +1,48 @@
+"""world_size-2 gloo worker for tests/test_parallel.py (launched with torch.distributed.run)."""
+import os
+import sys
+
+import torch
+import torch.distributed as dist
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from goliath_amd import parallel  # noqa: E402
+
+
+def main():
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    torch.manual_seed(0)  # same model on every rank
+    model = torch.nn.Sequential(torch.nn.Linear(7, 13), torch.nn.Tanh(), torch.nn.Linear(13, 3))
+    B = 6
+    g = torch.Generator().manual_seed(1)
+    batch = {"x": torch.randn(B, 7, generator=g), "y": torch.randn(B, 3, generator=g), "ids": list(range(B)),
+             "cfg": "shared"}
+    mine = parallel.shard_batch(batch)
+    assert mine["ids"] == list(range(rank, B, world)) and mine["cfg"] == "shared"
+    # per-view loss summed over this rank's views, scaled so that the rank-average equals the full-batch mean
+    loss = ((model(mine["x"]) - mine["y"]) ** 2).sum() * world / B
+    loss.backward()
+    sync = parallel.GradSync(model.parameters(), bucket_bytes=256)  # tiny buckets -> several collectives
+    assert len(sync.buckets) > 1
+    sync.sync()
+    # reference: the whole batch on one process
+    torch.manual_seed(0)
+    ref = torch.nn.Sequential(torch.nn.Linear(7, 13), torch.nn.Tanh(), torch.nn.Linear(13, 3))
+    ((ref(batch["x"]) - batch["y"]) ** 2).sum().div(B).backward()
+    for p, q in zip(model.parameters(), ref.parameters()):
+        assert torch.allclose(p.grad, q.grad, atol=1e-6), (p.grad - q.grad).abs().max()
+    gn = parallel.global_grad_norm(model.parameters())
+    gathered = [torch.zeros(()) for _ in range(world)]
+    dist.all_gather(gathered, gn)
+    assert all(torch.equal(gathered[0], t) for t in gathered)
+    m = parallel.sync_mean(torch.tensor(float(rank)))
+    assert abs(float(m) - (world - 1) / 2) < 1e-6
+    dist.barrier()
+    if rank == 0:
+        print("DIST_OK")
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
