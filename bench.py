@@ -117,8 +117,9 @@ def cpu_baseline(cfg):
     the same workload, forward + backward, on the host cores."""
     from oracle import cref, shade_ref
 
-    threads = os.cpu_count() or 1
+    threads = min(32, os.cpu_count() or 1)  # more threads only add contention on the atomics
     torch.set_num_threads(threads)
+    cref.set_threads(threads)
     n_views, dt = 4, 0.0
     for v in range(n_views):
         t = make_inputs(dict(cfg, views_per_gpu=1), "cpu", rank=v)

@@ -46,6 +46,12 @@ def lib():
     return _lib
 
 
+def set_threads(n):
+    """Number of OpenMP threads the C oracle uses (it is linked against libgomp)."""
+    ctypes.CDLL("libgomp.so.1").omp_set_num_threads(int(n))
+    lib()
+
+
 def _p(t):
     if t is None:
         return ctypes.c_void_p(0)
