@@ -104,6 +104,7 @@ struct Bilinear {
 
 // F.grid_sample(mode=bilinear, padding_mode=border, align_corners=False) of a [3,h,w] image at
 // normalised (u,v) in [-1,1]
+template <bool PACKED>
 __device__ __forceinline__ Bilinear bilinear_border(const float* __restrict__ img, int h, int w, float u, float v) {
   Bilinear r;
   float ix = ((u + 1.f) * (float)w - 1.f) * 0.5f, iy = ((v + 1.f) * (float)h - 1.f) * 0.5f;
@@ -115,16 +116,30 @@ __device__ __forceinline__ Bilinear bilinear_border(const float* __restrict__ im
   const int x0 = (int)fx0, y0 = (int)fy0, x1 = x0 + 1, y1 = y0 + 1;
   const float wx1 = ix - fx0, wx0 = 1.f - wx1, wy1 = iy - fy0, wy0 = 1.f - wy1;
   const bool bx = x1 < w, by = y1 < h;
+  float t00[3], t01[3], t10[3], t11[3];
+  if constexpr (PACKED) {
+    // [h,w,4] texels: one 16-byte gather per tap, the two taps of a row are adjacent (32 B)
+    const float4* q = reinterpret_cast<const float4*>(img);
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 a = q[y0 * w + x0], b2 = bx ? q[y0 * w + x1] : z;
+    const float4 c2 = by ? q[y1 * w + x0] : z, d2 = (bx && by) ? q[y1 * w + x1] : z;
+    t00[0] = a.x; t00[1] = a.y; t00[2] = a.z; t01[0] = b2.x; t01[1] = b2.y; t01[2] = b2.z;
+    t10[0] = c2.x; t10[1] = c2.y; t10[2] = c2.z; t11[0] = d2.x; t11[1] = d2.y; t11[2] = d2.z;
+  } else {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float* p = img + (size_t)c * h * w;
+      t00[c] = p[y0 * w + x0];
+      t01[c] = bx ? p[y0 * w + x1] : 0.f;
+      t10[c] = by ? p[y1 * w + x0] : 0.f;
+      t11[c] = (bx && by) ? p[y1 * w + x1] : 0.f;
+    }
+  }
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
-    const float* p = img + (size_t)c * h * w;
-    const float v00 = p[y0 * w + x0];
-    const float v01 = bx ? p[y0 * w + x1] : 0.f;
-    const float v10 = by ? p[y1 * w + x0] : 0.f;
-    const float v11 = (bx && by) ? p[y1 * w + x1] : 0.f;
-    r.val[c] = wy0 * (wx0 * v00 + wx1 * v01) + wy1 * (wx0 * v10 + wx1 * v11);
-    r.d_ix[c] = wy0 * (v01 - v00) + wy1 * (v11 - v10);
-    r.d_iy[c] = wx0 * (v10 - v00) + wx1 * (v11 - v01);
+    r.val[c] = wy0 * (wx0 * t00[c] + wx1 * t01[c]) + wy1 * (wx0 * t10[c] + wx1 * t11[c]);
+    r.d_ix[c] = wy0 * (t01[c] - t00[c]) + wy1 * (t11[c] - t10[c]);
+    r.d_iy[c] = wx0 * (t10[c] - t00[c]) + wx1 * (t11[c] - t01[c]);
   }
   return r;
 }
@@ -147,11 +162,14 @@ __device__ __forceinline__ EnvSample env_lookup(const gol_shade_in& in, int b, f
     a = lam - fl;
   }
   const int h0 = in.mip_h[d1], w0 = in.mip_w[d1];
-  const Bilinear s0 = bilinear_border(in.mips[d1] + (size_t)b * 3 * h0 * w0, h0, w0, u, v);
+  const bool packed = in.mips_packed[0] != nullptr;
+  const Bilinear s0 = packed ? bilinear_border<true>(in.mips_packed[d1] + (size_t)b * 4 * h0 * w0, h0, w0, u, v)
+                             : bilinear_border<false>(in.mips[d1] + (size_t)b * 3 * h0 * w0, h0, w0, u, v);
   if (q > 1) {
     const int d2 = min(d1 + 1, q - 1);
     const int h1 = in.mip_h[d2], w1 = in.mip_w[d2];
-    const Bilinear s1 = bilinear_border(in.mips[d2] + (size_t)b * 3 * h1 * w1, h1, w1, u, v);
+    const Bilinear s1 = packed ? bilinear_border<true>(in.mips_packed[d2] + (size_t)b * 4 * h1 * w1, h1, w1, u, v)
+                               : bilinear_border<false>(in.mips[d2] + (size_t)b * 3 * h1 * w1, h1, w1, u, v);
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
       e.val[c] = s0.val[c] + a * (s1.val[c] - s0.val[c]);  // th.lerp
@@ -597,6 +615,15 @@ __global__ __launch_bounds__(256) void shade_bwd_kernel(const gol_shade_in in, c
   }
 }
 
+// [B,3,h,w] planar -> [B,h,w,4] texel-interleaved (4th lane 0), one lane per texel
+__global__ __launch_bounds__(256) void envmap_pack_kernel(int hw, const float* __restrict__ src, float4* __restrict__ dst) {
+  const int b = blockIdx.y;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= hw) return;
+  const float* s = src + (size_t)b * 3 * hw;
+  dst[(size_t)b * hw + i] = make_float4(s[i], s[hw + i], s[2 * (size_t)hw + i], 0.f);
+}
+
 int check_in(const gol_shade_in* in) {
   GOL_REQUIRE(in != nullptr, "null gol_shade_in");
   GOL_REQUIRE(in->B >= 0 && in->N >= 0, "negative size");
@@ -610,6 +637,8 @@ int check_in(const gol_shade_in* in) {
     GOL_REQUIRE(in->lightrot != nullptr, "env map needs lightrot");
     for (int i = 0; i < in->n_mips; ++i)
       GOL_REQUIRE(in->mips[i] && in->mip_h[i] > 0 && in->mip_w[i] > 0, "bad mip level");
+    for (int i = 0; i < in->n_mips; ++i)
+      GOL_REQUIRE((in->mips_packed[i] != nullptr) == (in->mips_packed[0] != nullptr), "mips_packed: all levels or none");
   } else {
     GOL_REQUIRE(in->L >= 0 && in->n_lights != nullptr, "point lights need n_lights");
     GOL_REQUIRE(in->L == 0 || (in->light_intensity && in->light_pos), "null light arrays");
@@ -618,6 +647,17 @@ int check_in(const gol_shade_in* in) {
 }
 
 }  // namespace
+
+extern "C" int gol_envmap_pack(int B, int h, int w, const float* src, float* dst, void* stream) {
+  GOL_REQUIRE(B >= 0 && h > 0 && w > 0, "bad size");
+  if (B == 0) return GOL_OK;
+  GOL_REQUIRE(src && dst, "null pointer");
+  GOL_REQUIRE(B <= 65535, "B > 65535");
+  envmap_pack_kernel<<<dim3(gol_cdiv((long long)h * w, 256), B), 256, 0, (hipStream_t)stream>>>(
+      h * w, src, reinterpret_cast<float4*>(dst));
+  GOL_CHECK_LAUNCH();
+  return GOL_OK;
+}
 
 #define GOL_SHADE_FWD_DISPATCH(...)                                                                \
   do {                                                                                           \

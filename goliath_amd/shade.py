@@ -25,7 +25,8 @@ class ShadeIn(ctypes.Structure):
                 ("tn", _fp), ("albedo", _fp), ("light_sh", _fp), ("light_sh_rand", _fp), ("campos", _fp),
                 ("L", ctypes.c_int32), ("light_intensity", _fp), ("light_pos", _fp), ("n_lights", _fp),
                 ("n_mips", ctypes.c_int32), ("mips", _fp * MAX_MIPS), ("mip_h", ctypes.c_int32 * MAX_MIPS),
-                ("mip_w", ctypes.c_int32 * MAX_MIPS), ("lightrot", _fp), ("primscale_min", ctypes.c_float),
+                ("mip_w", ctypes.c_int32 * MAX_MIPS), ("lightrot", _fp), ("mips_packed", _fp * MAX_MIPS),
+                ("primscale_min", ctypes.c_float),
                 ("primscale_max", ctypes.c_float)]
 
 
@@ -51,8 +52,20 @@ def _p(t, dtype=torch.float32):
     return _lib.ptr(t, dtype).value if t is not None else None
 
 
+def pack_envmap(mips):
+    """[B,3,h,w] mip levels -> [B,h,w,4] texel-interleaved copies for 16-byte gathers."""
+    out = []
+    for m in mips:
+        B, _, h, w = m.shape
+        p = torch.empty(B, h, w, 4, device=m.device)
+        _lib.call("gol_envmap_pack", _lib.c_int(B), _lib.c_int(h), _lib.c_int(w), _lib.fptr(m), _lib.fptr(p),
+                  stream_ptr())
+        out.append(p)
+    return out
+
+
 def _make_in(f_vnocond, f_vcond, postex, tn, albedo, light_sh, light_sh_rand, campos, light_intensity,
-             light_pos, n_lights, mips, lightrot, ncol, nmono):
+             light_pos, n_lights, mips, lightrot, ncol, nmono, packed=None):
     B, C = f_vnocond.shape[:2]
     N = f_vnocond[0, 0].numel()
     s = ShadeIn()
@@ -64,6 +77,8 @@ def _make_in(f_vnocond, f_vcond, postex, tn, albedo, light_sh, light_sh_rand, ca
         for i, m in enumerate(mips):
             s.mips[i] = _p(m)
             s.mip_h[i], s.mip_w[i] = m.shape[-2], m.shape[-1]
+            if packed:
+                s.mips_packed[i] = _p(packed[i])
         s.lightrot = _p(lightrot)
     else:
         s.n_mips = 0
@@ -83,14 +98,17 @@ class _Shade(torch.autograd.Function):
         dev = f_vnocond.device
         rand = light_sh_rand is not None
         outs = {n: torch.empty(B, N, k, device=dev) for n, k in OUT_FIELDS if rand or n != "color_rand"}
+        with torch.cuda.device(dev):
+            packed = pack_envmap(mips) if mips else None
         sin = _make_in(f_vnocond, f_vcond, postex, tn, albedo, light_sh, light_sh_rand, campos,
-                       light_intensity, light_pos, n_lights, list(mips), lightrot, ncol, nmono)
+                       light_intensity, light_pos, n_lights, list(mips), lightrot, ncol, nmono, packed)
         sout = ShadeOut()
         for n, t in outs.items():
             setattr(sout, n, _p(t))
         with torch.cuda.device(dev):
             _lib.call("gol_shade_fwd", ctypes.byref(sin), ctypes.byref(sout), stream_ptr())
         ctx.cfg = (ncol, nmono, len(mips), rand)
+        ctx.packed = packed  # not an input/output of the node: plain attribute
         ctx.save_for_backward(f_vnocond, f_vcond, postex, tn, albedo, light_sh, light_sh_rand, campos,
                               light_intensity, light_pos, n_lights, lightrot, outs["diff_sum"],
                               outs.get("color_rand"), *mips)
@@ -110,7 +128,7 @@ class _Shade(torch.autograd.Function):
         N = f_vnocond[0, 0].numel()
         dev = f_vnocond.device
         sin = _make_in(f_vnocond, f_vcond, postex, tn, albedo, light_sh, light_sh_rand, campos,
-                       light_intensity, light_pos, n_lights, mips, lightrot, ncol, nmono)
+                       light_intensity, light_pos, n_lights, mips, lightrot, ncol, nmono, ctx.packed)
         saved = ShadeOut()
         saved.diff_sum = _p(diff_sum)
         saved.color_rand = _p(color_rand)
