@@ -61,7 +61,7 @@ __device__ __forceinline__ int quadrant_mask(float gx, float gy, float ca, float
 
 template <bool EXTRA>
 __global__ __launch_bounds__(256) void raster_fwd_kernel(
-    int N, int img_h, int img_w, int tiles_x, int tiles_y, const int2* __restrict__ tile_bins,
+    int N, int img_h, int img_w, int planar, int tiles_x, int tiles_y, const int2* __restrict__ tile_bins,
     const int32_t* __restrict__ sorted_ids, int64_t capacity, const float* __restrict__ xys,
     const float* __restrict__ conics, const float* __restrict__ colors, const float* __restrict__ extra,
     const float* __restrict__ opacities, const float* __restrict__ background, float* __restrict__ out_img,
@@ -144,9 +144,13 @@ __global__ __launch_bounds__(256) void raster_fwd_kernel(
     const size_t p = ((size_t)view * img_h + i) * img_w + j;
     final_Ts[p] = T_cur;
     final_idx[p] = cur_idx;
-    out_img[3 * p] = acc0 + T_cur * background[0];
-    out_img[3 * p + 1] = acc1 + T_cur * background[1];
-    out_img[3 * p + 2] = acc2 + T_cur * background[2];
+    // planar: [B,3,H,W] (what the model consumes, rgca.py:139); else gsplat's [B,H,W,3]
+    const size_t hw = (size_t)img_h * img_w;
+    const size_t o0 = planar ? (size_t)view * 3 * hw + (size_t)i * img_w + j : 3 * p;
+    const size_t os = planar ? hw : 1;
+    out_img[o0] = acc0 + T_cur * background[0];
+    out_img[o0 + os] = acc1 + T_cur * background[1];
+    out_img[o0 + 2 * os] = acc2 + T_cur * background[2];
     if (EXTRA) out_extra[p] = acc3;
   }
 }
@@ -156,7 +160,7 @@ constexpr int kAcc = 12;      // r g b v_opacity | Sx Sy Sxx Sxy | Syy extra - -
 
 template <bool EXTRA>
 __global__ __launch_bounds__(256) void raster_bwd_kernel(
-    int N, int img_h, int img_w, int tiles_x, int tiles_y, const int2* __restrict__ tile_bins,
+    int N, int img_h, int img_w, int planar, int tiles_x, int tiles_y, const int2* __restrict__ tile_bins,
     const int32_t* __restrict__ sorted_ids, int64_t capacity, const float* __restrict__ xys,
     const float* __restrict__ conics, const float* __restrict__ colors, const float* __restrict__ extra,
     const float* __restrict__ opacities, const float* __restrict__ background,
@@ -193,7 +197,10 @@ __global__ __launch_bounds__(256) void raster_bwd_kernel(
   const int bin_final = inside ? final_idx[p] : (range.x - 1);
   float vo0 = 0.f, vo1 = 0.f, vo2 = 0.f, vo3 = 0.f, voa = 0.f;
   if (inside) {
-    vo0 = v_out_img[3 * p]; vo1 = v_out_img[3 * p + 1]; vo2 = v_out_img[3 * p + 2];
+    const size_t hw = (size_t)img_h * img_w;
+    const size_t o0 = planar ? (size_t)view * 3 * hw + (size_t)i * img_w + j : 3 * p;
+    const size_t os = planar ? hw : 1;
+    vo0 = v_out_img[o0]; vo1 = v_out_img[o0 + os]; vo2 = v_out_img[o0 + 2 * os];
     if (EXTRA && v_out_extra) vo3 = v_out_extra[p];
     if (v_out_alpha) voa = v_out_alpha[p];
   }
@@ -318,7 +325,7 @@ __global__ __launch_bounds__(256) void raster_bwd_kernel(
 
 }  // namespace
 
-extern "C" int gol_rasterize_fwd(int B, int N, int img_h, int img_w, int block, const int32_t* tile_bins,
+extern "C" int gol_rasterize_fwd(int B, int N, int img_h, int img_w, int block, int planar, const int32_t* tile_bins,
                                  const int32_t* sorted_ids, int64_t capacity, const float* xys,
                                  const float* conics, const float* colors, const float* extra,
                                  const float* opacities, const float* background, float* out_img,
@@ -337,18 +344,18 @@ extern "C" int gol_rasterize_fwd(int B, int N, int img_h, int img_w, int block, 
   const int2* bins = reinterpret_cast<const int2*>(tile_bins);
   hipStream_t s = (hipStream_t)stream;
   if (extra)
-    raster_fwd_kernel<true><<<grid, 256, 0, s>>>(N, img_h, img_w, tiles_x, tiles_y, bins, sorted_ids, capacity, xys,
+    raster_fwd_kernel<true><<<grid, 256, 0, s>>>(N, img_h, img_w, planar, tiles_x, tiles_y, bins, sorted_ids, capacity, xys,
                                                   conics, colors, extra, opacities, background, out_img, out_extra,
                                                   final_Ts, final_idx);
   else
-    raster_fwd_kernel<false><<<grid, 256, 0, s>>>(N, img_h, img_w, tiles_x, tiles_y, bins, sorted_ids, capacity, xys,
+    raster_fwd_kernel<false><<<grid, 256, 0, s>>>(N, img_h, img_w, planar, tiles_x, tiles_y, bins, sorted_ids, capacity, xys,
                                                    conics, colors, extra, opacities, background, out_img, out_extra,
                                                    final_Ts, final_idx);
   GOL_CHECK_LAUNCH();
   return GOL_OK;
 }
 
-extern "C" int gol_rasterize_bwd(int B, int N, int img_h, int img_w, int block, const int32_t* tile_bins,
+extern "C" int gol_rasterize_bwd(int B, int N, int img_h, int img_w, int block, int planar, const int32_t* tile_bins,
                                  const int32_t* sorted_ids, int64_t capacity, const float* xys,
                                  const float* conics, const float* colors, const float* extra,
                                  const float* opacities, const float* background, const float* final_Ts,
@@ -369,12 +376,12 @@ extern "C" int gol_rasterize_bwd(int B, int N, int img_h, int img_w, int block, 
   const int2* bins = reinterpret_cast<const int2*>(tile_bins);
   hipStream_t s = (hipStream_t)stream;
   if (extra && (v_out_extra || v_extra))
-    raster_bwd_kernel<true><<<grid, 256, 0, s>>>(N, img_h, img_w, tiles_x, tiles_y, bins, sorted_ids, capacity, xys,
+    raster_bwd_kernel<true><<<grid, 256, 0, s>>>(N, img_h, img_w, planar, tiles_x, tiles_y, bins, sorted_ids, capacity, xys,
                                                   conics, colors, extra, opacities, background, final_Ts, final_idx,
                                                   v_out_img, v_out_extra, v_out_alpha, v_xy, v_conic, v_colors,
                                                   v_extra, v_opacity);
   else
-    raster_bwd_kernel<false><<<grid, 256, 0, s>>>(N, img_h, img_w, tiles_x, tiles_y, bins, sorted_ids, capacity, xys,
+    raster_bwd_kernel<false><<<grid, 256, 0, s>>>(N, img_h, img_w, planar, tiles_x, tiles_y, bins, sorted_ids, capacity, xys,
                                                    conics, colors, nullptr, opacities, background, final_Ts,
                                                    final_idx, v_out_img, nullptr, v_out_alpha, v_xy, v_conic,
                                                    v_colors, nullptr, v_opacity);

@@ -211,7 +211,7 @@ class _RasterizeGaussians(torch.autograd.Function):
             with torch.cuda.device(dev):
                 _bin_sort(1, N, xys, depths, radii, img_height, img_width, ws, conics, opacity)
                 _lib.call("gol_rasterize_fwd", c_int(1), c_int(N), c_int(img_height), c_int(img_width),
-                          c_int(BLOCK), iptr(ws.tile_bins), iptr(ws.sorted_ids), c_i64(ws.capacity), fptr(xys),
+                          c_int(BLOCK), c_int(0), iptr(ws.tile_bins), iptr(ws.sorted_ids), c_i64(ws.capacity), fptr(xys),
                           fptr(conics), fptr(colors), fptr(None), fptr(opacity), fptr(background),
                           fptr(out_img), fptr(None), fptr(final_Ts), iptr(final_idx), stream_ptr())
             ctx.ws = ws
@@ -236,7 +236,7 @@ class _RasterizeGaussians(torch.autograd.Function):
             ws = ctx.ws
             va = None if v_out_alpha is None else _f32c(v_out_alpha)
             with torch.cuda.device(xys.device):
-                _lib.call("gol_rasterize_bwd", c_int(1), c_int(N), c_int(H), c_int(W), c_int(BLOCK),
+                _lib.call("gol_rasterize_bwd", c_int(1), c_int(N), c_int(H), c_int(W), c_int(BLOCK), c_int(0),
                           iptr(ws.tile_bins), iptr(ws.sorted_ids), c_i64(ws.capacity), fptr(xys), fptr(conics),
                           fptr(colors), fptr(None), fptr(opacity), fptr(background), fptr(final_Ts),
                           iptr(final_idx), fptr(_f32c(v_out_img)), fptr(None), fptr(va), fptr(v_xy),
@@ -287,11 +287,11 @@ class _RenderViews(torch.autograd.Function):
                 B, N, means, scales, glob_scale, quats, viewmats, intrins, img_h, img_w, clip_thresh,
                 opacities=opacity)
             _bin_sort(B, N, xys, depths, radii, img_h, img_w, ws, conics, opac_eff)
-            out_img = torch.empty(B, img_h, img_w, 3, device=dev)
+            out_img = torch.empty(B, 3, img_h, img_w, device=dev)  # planar, as the model consumes it
             out_depth = torch.empty(B, img_h, img_w, device=dev) if with_depth else None
             final_Ts = torch.empty(B, img_h, img_w, device=dev)
             final_idx = torch.empty(B, img_h, img_w, dtype=torch.int32, device=dev)
-            _lib.call("gol_rasterize_fwd", c_int(B), c_int(N), c_int(img_h), c_int(img_w), c_int(BLOCK),
+            _lib.call("gol_rasterize_fwd", c_int(B), c_int(N), c_int(img_h), c_int(img_w), c_int(BLOCK), c_int(1),
                       iptr(ws.tile_bins), iptr(ws.sorted_ids), c_i64(ws.capacity), fptr(xys), fptr(conics),
                       fptr(colors), fptr(depths if with_depth else None), fptr(opac_eff), fptr(background),
                       fptr(out_img), fptr(out_depth), fptr(final_Ts), iptr(final_idx), stream_ptr())
@@ -317,7 +317,7 @@ class _RenderViews(torch.autograd.Function):
         if v_img is None and v_alpha is None and v_depth is None:
             return (None,) * 14
         if v_img is None:
-            v_img = torch.zeros(B, img_h, img_w, 3, device=dev)
+            v_img = torch.zeros(B, 3, img_h, img_w, device=dev)
         use_depth = with_depth and v_depth is not None
         v_xy = torch.zeros(B, N, 2, device=dev)
         v_conic = torch.zeros(B, N, 3, device=dev)
@@ -329,7 +329,7 @@ class _RenderViews(torch.autograd.Function):
         v_quat = torch.empty_like(quats)
         v_opacity = torch.empty_like(opacity)
         with torch.cuda.device(dev):
-            _lib.call("gol_rasterize_bwd", c_int(B), c_int(N), c_int(img_h), c_int(img_w), c_int(BLOCK),
+            _lib.call("gol_rasterize_bwd", c_int(B), c_int(N), c_int(img_h), c_int(img_w), c_int(BLOCK), c_int(1),
                       iptr(ws.tile_bins), iptr(ws.sorted_ids), c_i64(ws.capacity), fptr(xys), fptr(conics),
                       fptr(colors), fptr(depths if use_depth else None), fptr(opac_eff), fptr(background),
                       fptr(final_Ts), iptr(final_idx), fptr(_f32c(v_img)),
@@ -384,7 +384,7 @@ def render_views(means, scales, quats, opacity, colors, viewmats, intrins, img_h
                                 background, glob_scale, clip_thresh, with_depth, capacity=new_cap)
     elif key in PLANNER.capacity:
         PLANNER.note(key, n_isect, capacity)
-    res = {"render": img.permute(0, 3, 1, 2), "alpha": alpha[:, None], "final_T": (1 - alpha)[:, None],
+    res = {"render": img, "alpha": alpha[:, None], "final_T": (1 - alpha)[:, None],
            "radii": radii, "n_isect": n_isect}
     if with_depth:
         res["depth"] = depth[:, None]

@@ -107,17 +107,19 @@ int gol_bin_sort(int B, int N, const float* xys, const float* depths, const int3
  * specialisation (call sites render_gsplat.py:65-78, 91-104; semantics SURVEY.md A.3, A.4).
  * One launch composites colours[B,N,3] and, when extra != NULL, a 4th channel extra[B,N]
  * (the depth pass of render_gsplat.py:91-104 fused into the colour pass; its background is 0).
- *   background[3]; out_img[B,H,W,3]; out_extra[B,H,W]; final_Ts[B,H,W]; final_idx[B,H,W] int32
+ *   planar = 0: out_img / v_out_img are [B,H,W,3] (gsplat); planar = 1: [B,3,H,W] (what
+ *   AutoEncoder.render stacks, rgca.py:139 -- saves the permute copy in the backward).
+ *   background[3]; out_extra[B,H,W]; final_Ts[B,H,W]; final_idx[B,H,W] int32
  *   (index into the view's sorted_ids segment of the last contributing Gaussian, 0 if none).
  * bwd ACCUMULATES into v_xy[B,N,2] v_conic[B,N,3] v_colors[B,N,3] v_opacity[B,N]
  * (and v_extra[B,N]) which the caller zeroes; v_out_alpha / v_out_extra may be NULL.
  * ---------------------------------------------------------------------------------------- */
-int gol_rasterize_fwd(int B, int N, int img_h, int img_w, int block, const int32_t* tile_bins,
+int gol_rasterize_fwd(int B, int N, int img_h, int img_w, int block, int planar, const int32_t* tile_bins,
                       const int32_t* sorted_ids, int64_t capacity, const float* xys,
                       const float* conics, const float* colors, const float* extra,
                       const float* opacities, const float* background, float* out_img,
                       float* out_extra, float* final_Ts, int32_t* final_idx, void* stream);
-int gol_rasterize_bwd(int B, int N, int img_h, int img_w, int block, const int32_t* tile_bins,
+int gol_rasterize_bwd(int B, int N, int img_h, int img_w, int block, int planar, const int32_t* tile_bins,
                       const int32_t* sorted_ids, int64_t capacity, const float* xys,
                       const float* conics, const float* colors, const float* extra,
                       const float* opacities, const float* background, const float* final_Ts,
