@@ -157,6 +157,89 @@ def _cpu_view(t, cfg, cref, shade_ref):
         (preds["opacity"][0, :, 0] * v_op[:, 0] * comp).sum()).backward()
 
 
+MVP_CFG = dict(workload="mvp_config5", prims=4096, tdim=(8, 16, 16), height=2048, width=1334, views_per_gpu=1,
+               seed=1112)
+
+
+def mvp_inputs(cfg, device, rank=0):
+    """16^3 perturbed lattice of boxes filling the unit cube, softplus(1.5 N(0,1))
+    template with alpha - 3.5, primscale 16 (box half-extent 1/16), stepsize 1/64, pinhole camera."""
+    g = torch.Generator().manual_seed(cfg["seed"] + rank)
+    B, K = cfg["views_per_gpu"], cfg["prims"]
+    k3 = round(K ** (1 / 3))
+    lin = (torch.arange(k3) + 0.5) / k3 * 2 - 1
+    centres = torch.stack(torch.meshgrid(lin, lin, lin, indexing="ij"), -1).reshape(-1, 3)
+    primpos = (centres[None] + 0.02 * torch.randn(B, K, 3, generator=g)).contiguous()
+    q = F.normalize(torch.randn(B, K, 4, generator=g) * 0.1 + torch.tensor([1.0, 0, 0, 0]), dim=-1)
+    w, x, y, z = q.unbind(-1)
+    primrot = torch.stack([1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y), 2 * (x * y + w * z),
+                           1 - 2 * (x * x + z * z), 2 * (y * z - w * x), 2 * (x * z - w * y), 2 * (y * z + w * x),
+                           1 - 2 * (x * x + y * y)], -1).reshape(B, K, 3, 3).contiguous()
+    primscale = torch.full((B, K, 3), float(k3))
+    TD, TH, TW = cfg["tdim"]
+    raw = 1.5 * torch.randn(B, K, TD, TH, TW, 4, generator=g)
+    raw[..., 3] -= 3.5
+    template = F.softplus(raw)
+    H, W = cfg["height"], cfg["width"]
+    t = dict(primpos=primpos, primrot=primrot, primscale=primscale, template=template,
+             viewpos=torch.tensor([[0.3, -0.2, -2.6]] * B), viewrot=torch.eye(3)[None].repeat(B, 1, 1),
+             focal=torch.full((B, 2), 2600.0), princpt=torch.tensor([[W / 2.0, H / 2.0]] * B),
+             target=torch.rand(B, H, W, 4, generator=g))
+    t = {k: v.to(device).contiguous() for k, v in t.items()}
+    for k in ("primpos", "primrot", "primscale", "template"):
+        t[k].requires_grad_(True)
+    return t
+
+
+def mvp_main(args):
+    """Secondary workload (BASELINE config 5): MVP ray march fwd+bwd, 1 view of 2048x1334 per step."""
+    from goliath_amd import _lib, mvp
+
+    cfg = MVP_CFG
+    dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
+    torch.cuda.set_device(dev)
+    t = mvp_inputs(cfg, dev)
+    H, W = cfg["height"], cfg["width"]
+
+    def step():
+        for k in ("primpos", "primrot", "primscale", "template"):
+            t[k].grad = None
+        rp, rd, tm = mvp.compute_raydirs(t["viewpos"], t["viewrot"], t["focal"], t["princpt"], (W, H), 1.0)
+        out = mvp.mvpraymarch(rp, rd, 1.0 / 64, tm, (t["primpos"], t["primrot"], t["primscale"]), t["template"], None,
+                              fadescale=8.0, fadeexp=8.0)
+        (out - t["target"]).abs().mean().backward()
+        return out
+
+    for _ in range(args.warmup):
+        out = step()
+    torch.cuda.synchronize()
+    _lib.TIMING = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    timing, _lib.TIMING = _lib.TIMING, None
+    per = {}
+    for name, e0, e1 in timing:
+        per.setdefault(name, []).append(e0.elapsed_time(e1))
+    ms = {k: sum(v) / len(v) for k, v in per.items()}
+    P = H * W
+    tpl_bytes = t["template"].numel() * 4
+    alg = {"gol_mvp_march_fwd": 32 * P + 28 * P + tpl_bytes, "gol_mvp_march_bwd": 32 * P + 28 * P + 3 * tpl_bytes}
+    dom = max(ms, key=ms.get)
+    ach = alg.get(dom, 0) / (ms[dom] * 1e-3) / 1e9
+    print(json.dumps({
+        "metric": "MVP ray-march views/sec (fwd+bwd) at 2048x1334, 4096 primitives", "value": args.steps / dt,
+        "unit": "views/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": cfg["workload"], "prims": cfg["prims"], "template": list(cfg["tdim"]),
+                   "image": [H, W], "stepsize": 1.0 / 64, "mean_alpha": float(out[..., 3].mean())},
+        "kernels_ms_per_call": ms,
+        "roofline": {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": ach / HBM_PEAK_GBS, "traffic": None}}), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -164,7 +247,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--views", type=int, default=CFG["views_per_gpu"])
+    ap.add_argument("--workload", choices=["rgca", "mvp"], default="rgca",
+                    help="rgca = the BASELINE metric (default); mvp = secondary BASELINE config 5 line")
     args = ap.parse_args()
+    if args.workload == "mvp":
+        return mvp_main(args)
     cfg = dict(CFG, views_per_gpu=args.views)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
