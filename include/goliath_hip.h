@@ -237,6 +237,32 @@ int gol_mvp_march_bwd(int N, int H, int W, int K, const float* raypos, const flo
                       float* grad_primpos, float* grad_primrot, float* grad_primscale, float* grad_tplate,
                       void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * URHand per-texel-per-light UV feature loops (BASELINE config 4).  Replace the broadcast PyTorch
+ * expressions of ConvTeacherDecoder.forward: ca_code/models/urhand.py:419-445 (Lambert + Phong^p
+ * features) and :508-567 (GGX/Schlick features + physically based texture).  All images planar:
+ *   p_uv[B,3,HW] nml[B,3,HW] cam_pos[B,3] light_pos[B,L,3] light_intensity[B,L]
+ *   shadow_map[B,L,HW] or NULL; GGX only: roughness[B,HW] tex_mean[B,3,HW] (0..255), fresnel
+ *   pow[n_pow] = spec_powers (urhand.py:277: 1, 16, 32)
+ * phong: diff[B,HW] = diff_feature_raw, spec[B,n_pow,HW] = spec_feature_raw.
+ * ggx:   feat[B,1+n_pow,HW] = feat_p (urhand.py:558), rgb[B,3,HW] = phys_tex before the global
+ *        scale of :567.  Backward writes g_* in full (no accumulation); lights, camera and the
+ *        shadow map receive no gradient (data / computed under no_grad in the reference).
+ * ---------------------------------------------------------------------------------------- */
+#define GOL_UV_MAX_POW 4
+typedef struct {
+  int32_t B, L, HW, n_pow;
+  float pow[GOL_UV_MAX_POW];
+  float fresnel;
+  const float *p_uv, *nml, *cam_pos, *light_pos, *light_intensity, *shadow_map, *roughness, *tex_mean;
+} gol_uvlight_in;
+int gol_uvlight_phong_fwd(const gol_uvlight_in* in, float* diff, float* spec, void* stream);
+int gol_uvlight_phong_bwd(const gol_uvlight_in* in, const float* u_diff, const float* u_spec, float* g_p_uv,
+                          float* g_nml, void* stream);
+int gol_uvlight_ggx_fwd(const gol_uvlight_in* in, float* feat, float* rgb, void* stream);
+int gol_uvlight_ggx_bwd(const gol_uvlight_in* in, const float* u_feat, const float* u_rgb, float* g_p_uv,
+                        float* g_nml, float* g_roughness, float* g_tex, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,71 @@
+"""GPU parity: URHand UV light-loop kernels (C ABI gol_uvlight_*) vs golden vectors produced by the
+reference's own source lines (tests/golden/urhand_golden.npz) and vs the torch oracle at 256x256 with
+32 lights (the OLAT sweep of BASELINE config 4).  Tolerance rel-L2 <= 1e-4."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from scenes import rel_l2
+from test_oracle_urhand import load_golden
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+@pytest.mark.parametrize("tag", ["sh", "nosh"])
+def test_uvlight_matches_reference_golden(tag):
+    from goliath_amd import uvlight
+
+    G = load_golden()
+    c = lambda k: G[f"in/{k}"].cuda()
+    leaf = {k: c(k).requires_grad_(True) for k in ("p_uv", "nml", "roughness", "tex_mean")}
+    sh = c("shadow_map") if tag == "sh" else None
+    d, s = uvlight.phong_features(leaf["p_uv"], leaf["nml"], c("cam_pos"), c("light_pos"), c("light_intensity"), sh)
+    assert rel_l2(d, G[f"{tag}/phong/diff"]) < TOL and rel_l2(s, G[f"{tag}/phong/spec"]) < TOL
+    ((d * G[f"{tag}/phong/w_diff"].cuda()).sum() + (s * G[f"{tag}/phong/w_spec"].cuda()).sum()).backward()
+    assert rel_l2(leaf["p_uv"].grad, G[f"{tag}/phong/g_p_uv"]) < TOL
+    assert rel_l2(leaf["nml"].grad, G[f"{tag}/phong/g_nml"]) < TOL
+    for t in leaf.values():
+        t.grad = None
+    f, rgb = uvlight.ggx_features(leaf["p_uv"], leaf["nml"], c("cam_pos"), c("light_pos"), c("light_intensity"),
+                                  leaf["roughness"], leaf["tex_mean"], sh)
+    assert rel_l2(f, G[f"{tag}/ggx/feat"].reshape(f.shape)) < TOL and rel_l2(rgb, G[f"{tag}/ggx/rgb"]) < TOL
+    ((f * G[f"{tag}/ggx/w_feat"].reshape(f.shape).cuda()).sum() + (rgb * G[f"{tag}/ggx/w_rgb"].cuda()).sum()).backward()
+    for k, n in (("p_uv", "g_p_uv"), ("nml", "g_nml"), ("roughness", "g_roughness"), ("tex_mean", "g_tex")):
+        assert rel_l2(leaf[k].grad, G[f"{tag}/ggx/{n}"]) < TOL, (k, rel_l2(leaf[k].grad, G[f"{tag}/ggx/{n}"]))
+
+
+def test_uvlight_olat_32_lights_vs_oracle():
+    from goliath_amd import uvlight
+    from oracle import urhand_ref
+
+    g = torch.Generator().manual_seed(9)
+    B, L, S = 1, 32, 256
+    p_uv = 40 * torch.randn(B, 3, S, S, generator=g)
+    nml = F.normalize(torch.randn(B, 3, S, S, generator=g), dim=1)
+    cam = torch.tensor([[20.0, 10.0, -800.0]])
+    lp = F.normalize(torch.randn(B, L, 3, generator=g), dim=-1) * 1100
+    li = torch.zeros(B, L, 1)
+    li[:, 7] = 1.0  # one-light-at-a-time frame
+    li = li + 0.05
+    rough = 0.3 + 0.6 * torch.rand(B, 1, S, S, generator=g)  # below ~0.3 the GGX lobe is ill-conditioned in fp32
+    tex = 255 * torch.rand(B, 3, S, S, generator=g)
+    shm = torch.rand(B, L, 1, S, S, generator=g)
+    cpu = [t.clone().requires_grad_(True) for t in (p_uv, nml, rough, tex)]
+    gpu = [t.clone().cuda().requires_grad_(True) for t in (p_uv, nml, rough, tex)]
+    rf, rr = urhand_ref.ggx_features(cpu[0], cpu[1], cam, lp, li, cpu[2], cpu[3], shm)
+    of, orr = uvlight.ggx_features(gpu[0], gpu[1], cam.cuda(), lp.cuda(), li.cuda(), gpu[2], gpu[3], shm.cuda())
+    assert rel_l2(of, rf) < TOL and rel_l2(orr, rr) < TOL
+    wf, wr = torch.randn(rf.shape, generator=g), torch.randn(rr.shape, generator=g)
+    ((rf * wf).sum() + (rr * wr).sum()).backward()
+    ((of * wf.cuda()).sum() + (orr * wr.cuda()).sum()).backward()
+    for a, b, n in zip(gpu, cpu, ("p_uv", "nml", "roughness", "tex")):
+        # torch yields NaN (0 * inf) where spec^31 overflows behind the clamp(max=1) -- a quirk of the
+        # reference expression that the kernel does not reproduce (it returns the gated 0); compare elsewhere
+        ok = torch.isfinite(b.grad)
+        assert float(ok.float().mean()) > 0.99 and bool(torch.isfinite(a.grad).all())
+        assert rel_l2(a.grad.cpu()[ok], b.grad[ok]) < 5 * TOL, (n, rel_l2(a.grad.cpu()[ok], b.grad[ok]))  # 32 lights x pow(.,32): conditioning
+    # Phong path, no shadow map
+    rd, rs = urhand_ref.phong_features(p_uv, nml, cam, lp, li, None)
+    od, os_ = uvlight.phong_features(p_uv.cuda(), nml.cuda(), cam.cuda(), lp.cuda(), li.cuda(), None)
+    assert rel_l2(od, rd) < TOL and rel_l2(os_, rs) < TOL
