@@ -401,6 +401,10 @@ __global__ __launch_bounds__(256) void march_bwd_kernel(MarchArgs a, const float
       const bool ev = ray.live && valid_pos(y0) && !sat && ray.t < ray.rt1 + 1e-5f;
       if (__ballot(ev) == 0ull) continue;
       V3 dLy = v3(0.f, 0.f, 0.f);
+      float sd0 = 0.f, sd1 = 0.f, sd2 = 0.f, sd3 = 0.f, cw[8];
+      int cidx[8], cellkey = -1;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) { cidx[c] = -1; cw[c] = 0.f; }
       if (ev) {
         const float ax = fabsf(y0.x), ay = fabsf(y0.y), az = fabsf(y0.z);
         const float fade = __expf(-fs * (__powf(ax, fe) + __powf(ay, fe) + __powf(az, fe)));
@@ -428,15 +432,11 @@ __global__ __launch_bounds__(256) void march_bwd_kernel(MarchArgs a, const float
         dLy = v3(kf * __powf(ax, fe - 1.f) * (y0.x > 0.f ? 1.f : -1.f), kf * __powf(ay, fe - 1.f) * (y0.y > 0.f ? 1.f : -1.f),
                  kf * __powf(az, fe - 1.f) * (y0.z > 0.f ? 1.f : -1.f)) * (s3 * d3);
         d3 *= fade;
-        // trilinear backward (utils.h:619-770): template gradient scatter + position gradient
-        float* gt = g_tplate + (size_t)k * vox * 4;
+        // trilinear backward (utils.h:619-770): position gradient here, template scatter below
         float gix = 0.f, giy = 0.f, giz = 0.f;
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
           if (q.idx[c] >= 0) {
-            float* g = gt + (size_t)q.idx[c] * 4;
-            atomicAdd(g, q.w[c] * d0); atomicAdd(g + 1, q.w[c] * d1); atomicAdd(g + 2, q.w[c] * d2);
-            atomicAdd(g + 3, q.w[c] * d3);
             const float dp = cv[c].x * d0 + cv[c].y * d1 + cv[c].z * d2 + cv[c].w * d3;
             const int dx = c & 1, dy = (c >> 1) & 1, dz = (c >> 2) & 1;
             const float wx = dx ? q.fx : 1.f - q.fx, wy = dy ? q.fy : 1.f - q.fy, wz = dz ? q.fz : 1.f - q.fz;
@@ -446,6 +446,45 @@ __global__ __launch_bounds__(256) void march_bwd_kernel(MarchArgs a, const float
           }
         }
         dLy = dLy + v3(gix * 0.5f * (float)(a.TW - 1), giy * 0.5f * (float)(a.TH - 1), giz * 0.5f * (float)(a.TD - 1));
+        sd0 = d0; sd1 = d1; sd2 = d2; sd3 = d3;
+        cellkey = ((q.z0 + 1) * (a.TH + 1) + (q.y0 + 1)) * (a.TW + 1) + (q.x0 + 1);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) { cidx[c] = q.idx[c]; cw[c] = q.w[c]; }
+      }
+      // Template-gradient scatter.  The 64 rays of a wave sample only a handful of distinct voxel cells
+      // of this box at this step, and every device-scope float atomic is a fabric transaction on
+      // MI355X: group the lanes by cell (ballot + readlane), reduce each group's 8 corners x 4
+      // channels over the wave (v_permlane swaps) and issue ONE atomic per (cell, corner, channel)
+      // instead of one per lane (mvpraymarch utils.h:83-113 issues one per lane).
+      {
+        float* gt = g_tplate + (size_t)k * vox * 4;
+        unsigned long long todo = __ballot(ev);
+        while (todo) {
+          const int leader = __builtin_ctzll(todo);
+          const int key = __builtin_amdgcn_readlane(cellkey, leader);
+          const bool mine = ev && (cellkey == key);
+          const unsigned long long grp = __ballot(mine);
+          todo &= ~grp;
+          if (__builtin_popcountll(grp) >= 3) {
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+              const int ic = __builtin_amdgcn_readlane(cidx[c], leader);
+              if (ic < 0) continue;
+              const float wv = mine ? cw[c] : 0.f;
+              const float rsum = gol_wave_sum4(wv * sd0, wv * sd1, wv * sd2, wv * sd3);
+              if ((lane & 15) == 15) atomicAdd(gt + (size_t)ic * 4 + (lane >> 4), rsum);
+            }
+          } else if (mine) {
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+              if (cidx[c] >= 0) {
+                float* g = gt + (size_t)cidx[c] * 4;
+                atomicAdd(g, cw[c] * sd0); atomicAdd(g + 1, cw[c] * sd1); atomicAdd(g + 2, cw[c] * sd2);
+                atomicAdd(g + 3, cw[c] * sd3);
+              }
+            }
+          }
+        }
       }
       // PrimTransfSRT::backward (primtransf.h:155-179): 15 wave sums, one atomic each
       const V3 gs = ev ? xf.rxmt * dLy : v3(0.f, 0.f, 0.f);
