@@ -27,16 +27,20 @@ constexpr int kBatch = 256;
 
 struct TileCoord { int tile, tx, ty; bool ok; };
 
-// XCD-aware remap: consecutive workgroups land on different XCDs (observed b % 8), so give XCD x
-// the x-th contiguous chunk of row-major tiles.  Speed only -- any mapping is correct.
+// XCD-aware remap.  Consecutive workgroups land on different XCDs (observed: block b -> XCD b % 8), so
+// XCD x is given tile rows x, x+8, x+16, ...: inside a die consecutive workgroups walk along a tile
+// row (neighbouring tiles share most of their Gaussians -> L2 hits), while the rows of every die are
+// spread over the whole image so the dies stay balanced (contiguous image eighths per die left most of
+// the chip idle: the head covers only the middle rows).  Speed only -- any mapping is correct.
 __device__ __forceinline__ TileCoord tile_of_block(int bid, int T, int tiles_x) {
-  const int chunk = (T + 7) >> 3;
-  const int tile = (bid & 7) * chunk + (bid >> 3);
+  const int tiles_y = T / tiles_x;
+  const int xcd = bid & 7, j = bid >> 3;
   TileCoord tc;
-  tc.tile = tile;
-  tc.ok = (bid >> 3) < chunk && tile < T;
-  tc.ty = tile / tiles_x;
-  tc.tx = tile - tc.ty * tiles_x;
+  const int row_local = j / tiles_x;
+  tc.tx = j - row_local * tiles_x;
+  tc.ty = row_local * 8 + xcd;
+  tc.ok = tc.ty < tiles_y;
+  tc.tile = tc.ty * tiles_x + tc.tx;
   return tc;
 }
 
@@ -340,7 +344,7 @@ extern "C" int gol_rasterize_fwd(int B, int N, int img_h, int img_w, int block, 
   GOL_REQUIRE(N == 0 || (xys && conics && colors && opacities), "null Gaussian attribute");
   GOL_REQUIRE((extra == nullptr) == (out_extra == nullptr), "extra and out_extra go together");
   const int tiles_x = (img_w + 15) / 16, tiles_y = (img_h + 15) / 16, T = tiles_x * tiles_y;
-  dim3 grid(8 * ((T + 7) / 8), B);
+  dim3 grid(8 * ((tiles_y + 7) / 8) * tiles_x, B);
   const int2* bins = reinterpret_cast<const int2*>(tile_bins);
   hipStream_t s = (hipStream_t)stream;
   if (extra)
@@ -372,7 +376,7 @@ extern "C" int gol_rasterize_bwd(int B, int N, int img_h, int img_w, int block, 
   GOL_REQUIRE(v_xy && v_conic && v_colors && v_opacity, "null gradient output");
   GOL_REQUIRE(!(v_out_extra || v_extra) || extra, "extra-channel gradients need extra");
   const int tiles_x = (img_w + 15) / 16, tiles_y = (img_h + 15) / 16, T = tiles_x * tiles_y;
-  dim3 grid(8 * ((T + 7) / 8), B);
+  dim3 grid(8 * ((tiles_y + 7) / 8) * tiles_x, B);
   const int2* bins = reinterpret_cast<const int2*>(tile_bins);
   hipStream_t s = (hipStream_t)stream;
   if (extra && (v_out_extra || v_extra))
