@@ -26,7 +26,9 @@ constexpr float kNormEps = 1e-12f;               // torch F.normalize default ep
 template <int V>
 __device__ __forceinline__ void ldv(const float* __restrict__ p, float (&x)[V]) {
   if constexpr (V == 4) {
-    const float4 t = *reinterpret_cast<const float4*>(p);
+    // streamed once: non-temporal so the planes do not evict the env-map texels from L2
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    const f4 t = __builtin_nontemporal_load(reinterpret_cast<const f4*>(p));
     x[0] = t.x; x[1] = t.y; x[2] = t.z; x[3] = t.w;
   } else {
 #pragma unroll
@@ -608,7 +610,9 @@ __global__ __launch_bounds__(256) void shade_bwd_kernel(const gol_shade_in in, c
     }
     float* dst = GP + (size_t)ch * N;
     if (VEC4) {
-      *reinterpret_cast<float4*>(dst) = make_float4(x[0], x[1], x[2], x[3]);
+      typedef float f4 __attribute__((ext_vector_type(4)));
+      f4 v4 = {x[0], x[1], x[2], x[3]};
+      __builtin_nontemporal_store(v4, reinterpret_cast<f4*>(dst));  // written once, consumed by the decoder backward much later
     } else {
       for (int v = 0; v < nvalid; ++v) dst[v] = x[v];
     }
