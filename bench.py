@@ -9,7 +9,7 @@ decoder outputs already resident in HBM (SURVEY 8d mode A):
     EWA projection (+ tile counts)                                        gol_project_fwd
     tile binning + per-tile depth sort                                    gol_bin_sort
     colour + depth tile raster                                            gol_rasterize_fwd
-    L1 loss vs a fixed random target image (torch elementwise)
+    L1 loss vs a fixed random target image                                gol_l1_fwd / gol_l1_bwd
     raster / projection / shading backward                                gol_*_bwd
 Multi-GPU: views are independent units -> each rank renders its own 8 views (weak scaling); the only
 parameter on this path, the albedo map, has its gradient all-reduced over RCCL every step.
@@ -85,14 +85,14 @@ def make_inputs(cfg, device, rank=0):
 
 
 def step(t, cfg, world):
-    from goliath_amd import render_gs, shade
+    from goliath_amd import losses, render_gs, shade
 
     for k in ("f_vn", "f_vc", "postex", "tn", "albedo"):
         t[k].grad = None
     preds = shade.shading_tail(t["f_vn"], t["f_vc"], t["postex"], t["tn"], t["albedo"], t["light_sh"], t["campos"],
                                preconv_envmap=t["mips"], lightrot=t["lightrot"])
     rgb, alpha, depth = render_gs.render_batch(t["K"], t["Rt"], preds, cfg["height"], cfg["width"])
-    loss = (rgb - t["target"]).abs().mean()
+    loss = losses.l1_image(rgb, t["target"])  # == (rgb - target).abs().mean(), rgb_l1 of loss/__init__.py:411
     loss.backward()
     if world > 1:
         t["_sync"].sync()  # reduce-scatter + all-gather of the path's only parameter (albedo, rgca.py:462-464)

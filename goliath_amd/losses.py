@@ -1,0 +1,60 @@
+"""Image losses on top of the C ABI ("next" row).
+
+  rgb_l1(preds, targets, ...)   <- ca_code/loss/__init__.py:391-411  (same signature / keys)
+  l1_image(pred, target, mask)  the fused op: one read pass forward, one read + one write pass backward
+"""
+from typing import Optional
+
+import torch
+
+from . import _lib
+from ._lib import c_int, fptr, stream_ptr
+
+
+class _L1(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pred, target, mask):
+        B, C = pred.shape[:2]
+        HW = pred[0, 0].numel()
+        mask_c = 0 if mask is None else mask.shape[1]
+        nb = _lib.load().gol_l1_blocks(HW)
+        partial = torch.empty(B * C * nb, device=pred.device)
+        with torch.cuda.device(pred.device):
+            _lib.call("gol_l1_fwd", c_int(B), c_int(C), c_int(HW), c_int(mask_c), fptr(pred), fptr(target), fptr(mask),
+                      fptr(partial), stream_ptr())
+        ctx.save_for_backward(pred, target, mask)
+        return partial.sum() / (B * C * HW)
+
+    @staticmethod
+    def backward(ctx, g):
+        pred, target, mask = ctx.saved_tensors
+        B, C = pred.shape[:2]
+        HW = pred[0, 0].numel()
+        mask_c = 0 if mask is None else mask.shape[1]
+        out = torch.empty_like(pred)
+        g = g.to(torch.float32).reshape(1).contiguous()
+        with torch.cuda.device(pred.device):
+            _lib.call("gol_l1_bwd", c_int(B), c_int(C), c_int(HW), c_int(mask_c), fptr(pred), fptr(target), fptr(mask),
+                      fptr(g), fptr(out), stream_ptr())
+        return out, None, None
+
+
+def l1_image(pred: torch.Tensor, target: torch.Tensor, mask: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """mean(|(pred - target) * mask|) for [B,C,H,W] images; mask [B,1,H,W] or [B,C,H,W] or None."""
+    if not pred.is_cuda:
+        raise _lib.GoliathHipError("l1_image needs CUDA(HIP) tensors; there is no CPU path")
+    c = lambda t: None if t is None else t.detach().to(torch.float32).contiguous()
+    return _L1.apply(pred.to(torch.float32).contiguous(), c(target), c(mask))
+
+
+def rgb_l1(preds, targets, src_key: str = "rendered_rgb", tgt_key: str = "image", mask_key: str = "image_mask",
+           ddisc_key: str = "depth_disc_mask", mask_erode: Optional[int] = None):
+    """Same semantics as the reference's rgb_l1 (mask erosion is not fused: pass an eroded mask)."""
+    if mask_erode is not None:
+        raise NotImplementedError("mask_erode: erode the mask first (ca_code/utils/image.py) and pass it in")
+    mask = targets.get(mask_key, preds.get(mask_key, None))
+    if ddisc_key in preds:
+        d = preds[ddisc_key]
+        inv = (~d).float() if d.dtype == torch.bool else (1 - d)
+        mask = inv if mask is None else mask * inv
+    return l1_image(preds[src_key], targets[tgt_key], None if mask is None else mask.float())

@@ -263,6 +263,19 @@ int gol_uvlight_ggx_fwd(const gol_uvlight_in* in, float* feat, float* rgb, void*
 int gol_uvlight_ggx_bwd(const gol_uvlight_in* in, const float* u_feat, const float* u_rgb, float* g_p_uv,
                         float* g_nml, float* g_roughness, float* g_tex, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Masked L1 image loss ("next" row).  Replaces the ATen chain of rgb_l1
+ * (ca_code/loss/__init__.py:391-411): ((pred - target) * mask).abs().mean().
+ *   pred, target [B,C,HW]; mask NULL, [B,1,HW] (mask_c = 1) or [B,C,HW] (mask_c = C)
+ * fwd writes partial[B*C*gol_l1_blocks(HW)] per-workgroup sums (loss = sum(partial)/(B*C*HW));
+ * bwd writes g_pred = sign((pred-target)*mask) * mask * g_loss[0] / (B*C*HW)  (g_loss: device scalar).
+ * ---------------------------------------------------------------------------------------- */
+int gol_l1_blocks(int HW);
+int gol_l1_fwd(int B, int C, int HW, int mask_c, const float* pred, const float* target, const float* mask,
+               float* partial, void* stream);
+int gol_l1_bwd(int B, int C, int HW, int mask_c, const float* pred, const float* target, const float* mask,
+               const float* g_loss, float* g_pred, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
