@@ -342,12 +342,12 @@ extern "C" int gol_rasterize_fwd(int B, int N, int img_h, int img_w, int block, 
   GOL_REQUIRE(tile_bins && background && out_img && final_Ts && final_idx, "null pointer");
   GOL_REQUIRE(capacity == 0 || sorted_ids, "null sorted_ids");
   GOL_REQUIRE(N == 0 || (xys && conics && colors && opacities), "null Gaussian attribute");
-  GOL_REQUIRE((extra == nullptr) == (out_extra == nullptr), "extra and out_extra go together");
+  GOL_REQUIRE(N == 0 || ((extra == nullptr) == (out_extra == nullptr)), "extra and out_extra go together");
   const int tiles_x = (img_w + 15) / 16, tiles_y = (img_h + 15) / 16, T = tiles_x * tiles_y;
   dim3 grid(8 * ((tiles_y + 7) / 8) * tiles_x, B);
   const int2* bins = reinterpret_cast<const int2*>(tile_bins);
   hipStream_t s = (hipStream_t)stream;
-  if (extra)
+  if (out_extra)
     raster_fwd_kernel<true><<<grid, 256, 0, s>>>(N, img_h, img_w, planar, tiles_x, tiles_y, bins, sorted_ids, capacity, xys,
                                                   conics, colors, extra, opacities, background, out_img, out_extra,
                                                   final_Ts, final_idx);

@@ -64,7 +64,7 @@ class CapacityPlanner:
         self.pending.append((ev, host, capacity, key))
 
     def poll(self, block=False):
-        still = []
+        still, overflow = [], None
         for ev, host, capacity, key in self.pending:
             if block:
                 ev.synchronize()
@@ -72,15 +72,18 @@ class CapacityPlanner:
                 worst = int(host.max()) if host.numel() else 0
                 if worst > capacity:
                     self.set(key, worst)
-                    raise _lib.GoliathHipError(
-                        f"a previous render_views call overflowed its intersection capacity "
-                        f"({worst} > {capacity}); its image is incomplete. Capacity was raised to "
-                        f"{self.capacity[key]} -- re-run the step (or set GOLIATH_STRICT_CAPACITY=1).")
-                if worst * 1.25 > capacity:  # grow early, before it overflows
+                    overflow = (worst, capacity, key)
+                elif worst * 1.25 > capacity:  # grow early, before it overflows
                     self.set(key, worst)
             else:
                 still.append((ev, host, capacity, key))
         self.pending = still
+        if overflow is not None:
+            worst, capacity, key = overflow
+            raise _lib.GoliathHipError(
+                f"a previous render_views call overflowed its intersection capacity ({worst} > {capacity}); "
+                f"its image is incomplete. Capacity was raised to {self.capacity[key]} -- re-run the step "
+                f"(or set GOLIATH_STRICT_CAPACITY=1).")
 
 
 PLANNER = CapacityPlanner()
@@ -358,7 +361,7 @@ def render_views(means, scales, quats, opacity, colors, viewmats, intrins, img_h
         raise _lib.GoliathHipError("render_views needs CUDA(HIP) tensors; there is no CPU path")
     means, scales, quats, colors = _f32c(means), _f32c(scales), _f32c(quats), _f32c(colors)
     opacity = _f32c(opacity).reshape(B, N)
-    viewmats = _f32c(viewmats).reshape(B, -1)[:, :12].contiguous()
+    viewmats = _f32c(viewmats).reshape(B, viewmats[0].numel() if B else 12)[:, :12].contiguous()
     intrins = _f32c(intrins).reshape(B, 4)
     if background is None:
         background = torch.zeros(3, device=dev)  # render_gsplat.py:38-39
@@ -366,6 +369,7 @@ def render_views(means, scales, quats, opacity, colors, viewmats, intrins, img_h
     T = _tiles(img_h, img_w)
     key = (B, N, img_h, img_w, dev.index)
     calibrate = False
+    explicit = capacity is not None  # the caller sized the buffers: overflow is theirs to check (n_isect)
     if capacity is None:
         PLANNER.poll()
         capacity = PLANNER.get(key, N)
@@ -374,15 +378,17 @@ def render_views(means, scales, quats, opacity, colors, viewmats, intrins, img_h
     out = _RenderViews.apply(means, scales, quats, opacity, colors, viewmats, intrins, background, img_h,
                              img_w, float(glob_scale), float(clip_thresh), bool(with_depth), int(capacity))
     img, alpha, depth, radii, n_isect = out
-    if calibrate or PLANNER.strict():
-        worst = int(n_isect.max().item()) if B > 0 else 0  # one blocking read per new shape
+    if B == 0:
+        calibrate = False
+    if (calibrate or PLANNER.strict()) and B > 0:
+        worst = int(n_isect.max().item())  # one blocking read per new shape
         if calibrate:
             PLANNER.set(key, worst)
         if worst > capacity:
-            new_cap = PLANNER.capacity.get(key) or PLANNER.set(key, worst)
+            new_cap = PLANNER.set(key, worst)
             return render_views(means, scales, quats, opacity, colors, viewmats, intrins, img_h, img_w,
                                 background, glob_scale, clip_thresh, with_depth, capacity=new_cap)
-    elif key in PLANNER.capacity:
+    elif key in PLANNER.capacity and not explicit and B > 0:
         PLANNER.note(key, n_isect, capacity)
     res = {"render": img, "alpha": alpha[:, None], "final_T": (1 - alpha)[:, None],
            "radii": radii, "n_isect": n_isect}
