@@ -30,6 +30,10 @@ __device__ __forceinline__ void ldv(const float* __restrict__ p, float (&x)[V]) 
     typedef float f4 __attribute__((ext_vector_type(4)));
     const f4 t = __builtin_nontemporal_load(reinterpret_cast<const f4*>(p));
     x[0] = t.x; x[1] = t.y; x[2] = t.z; x[3] = t.w;
+  } else if constexpr (V == 2) {
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    const f2 t = __builtin_nontemporal_load(reinterpret_cast<const f2*>(p));
+    x[0] = t.x; x[1] = t.y;
   } else {
 #pragma unroll
     for (int v = 0; v < V; ++v) x[v] = p[v];
@@ -55,6 +59,12 @@ __device__ __forceinline__ void ld_aos(const float* __restrict__ base, size_t g0
       const float4 t = reinterpret_cast<const float4*>(p)[j];
       buf[4 * j] = t.x; buf[4 * j + 1] = t.y; buf[4 * j + 2] = t.z; buf[4 * j + 3] = t.w;
     }
+  } else if constexpr (V == 2) {
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+      const float2 t = reinterpret_cast<const float2*>(p)[j];
+      buf[2 * j] = t.x; buf[2 * j + 1] = t.y;
+    }
   } else {
 #pragma unroll
     for (int j = 0; j < V * K; ++j) buf[j] = p[j];
@@ -76,6 +86,9 @@ __device__ __forceinline__ void st_aos(float* __restrict__ base, size_t g0, cons
 #pragma unroll
     for (int j = 0; j < V * K / 4; ++j)
       reinterpret_cast<float4*>(p)[j] = make_float4(buf[4 * j], buf[4 * j + 1], buf[4 * j + 2], buf[4 * j + 3]);
+  } else if constexpr (V == 2) {
+#pragma unroll
+    for (int j = 0; j < K; ++j) reinterpret_cast<float2*>(p)[j] = make_float2(buf[2 * j], buf[2 * j + 1]);
   } else {
 #pragma unroll
     for (int j = 0; j < V * K; ++j) p[j] = buf[j];
@@ -663,22 +676,22 @@ extern "C" int gol_envmap_pack(int B, int h, int w, const float* src, float* dst
   return GOL_OK;
 }
 
-#define GOL_SHADE_FWD_DISPATCH(...)                                                                \
+#define GOL_SHADE_FWD_V(V, ...)                                                                   \
+  do {                                                                                           \
+    dim3 grid(gol_cdiv(in->N / V, 256), in->B);                                                  \
+    if (env && rnd) shade_fwd_kernel<V, true, true><<<grid, 256, 0, s>>>(__VA_ARGS__);           \
+    else if (env) shade_fwd_kernel<V, true, false><<<grid, 256, 0, s>>>(__VA_ARGS__);            \
+    else if (rnd) shade_fwd_kernel<V, false, true><<<grid, 256, 0, s>>>(__VA_ARGS__);            \
+    else shade_fwd_kernel<V, false, false><<<grid, 256, 0, s>>>(__VA_ARGS__);                    \
+  } while (0)
+
+// 4 Gaussians per lane (16-byte plane loads) when N allows, else 2 (8-byte), else 1
+#define GOL_SHADE_FWD_DISPATCH(...)                                                              \
   do {                                                                                           \
     const bool env = in->n_mips > 0, rnd = in->light_sh_rand != nullptr;                         \
-    if (in->N % 4 == 0) {                                                                        \
-      dim3 grid(gol_cdiv(in->N / 4, 256), in->B);                                                \
-      if (env && rnd) shade_fwd_kernel<4, true, true><<<grid, 256, 0, s>>>(__VA_ARGS__);         \
-      else if (env) shade_fwd_kernel<4, true, false><<<grid, 256, 0, s>>>(__VA_ARGS__);          \
-      else if (rnd) shade_fwd_kernel<4, false, true><<<grid, 256, 0, s>>>(__VA_ARGS__);          \
-      else shade_fwd_kernel<4, false, false><<<grid, 256, 0, s>>>(__VA_ARGS__);                  \
-    } else {                                                                                     \
-      dim3 grid(gol_cdiv(in->N, 256), in->B);                                                    \
-      if (env && rnd) shade_fwd_kernel<1, true, true><<<grid, 256, 0, s>>>(__VA_ARGS__);         \
-      else if (env) shade_fwd_kernel<1, true, false><<<grid, 256, 0, s>>>(__VA_ARGS__);          \
-      else if (rnd) shade_fwd_kernel<1, false, true><<<grid, 256, 0, s>>>(__VA_ARGS__);          \
-      else shade_fwd_kernel<1, false, false><<<grid, 256, 0, s>>>(__VA_ARGS__);                  \
-    }                                                                                            \
+    if (in->N % 4 == 0) GOL_SHADE_FWD_V(4, __VA_ARGS__);                                         \
+    else if (in->N % 2 == 0) GOL_SHADE_FWD_V(2, __VA_ARGS__);                                    \
+    else GOL_SHADE_FWD_V(1, __VA_ARGS__);                                                        \
   } while (0)
 
 #define GOL_SHADE_BWD_CASE(E, R)                                                                 \
