@@ -3,8 +3,9 @@
 
 Metric (BASELINE.json): "relit views/sec (fwd+bwd) at 2048x1334, 250k Gaussians; 1/2/4/8 GPU".
 Workload = BASELINE config 2: RGCA head, 250,000 Gaussians, 8 views x 2048x1334 per
-GPU, single env-map relight.  One "step" = one batch of 8 views through the whole hot path with the
-decoder outputs already resident in HBM (SURVEY 8d mode A):
+GPU, single env-map relight.  One "step" = one batch of 8 views (issued as 2 micro-batches of 4 views on 2
+HIP streams, --micro) through the whole hot path with the decoder outputs already resident in HBM
+(SURVEY 8d mode A):
     fused shading tail (SH diffuse + activations + env-map specular)      gol_shade_fwd
     EWA projection (+ tile counts)                                        gol_project_fwd
     tile binning + per-tile depth sort                                    gol_bin_sort
@@ -85,18 +86,41 @@ def make_inputs(cfg, device, rank=0):
 
 
 def step(t, cfg, world):
+    """One step = all views of this GPU's batch, as `len(t["micro"])` micro-batches on separate HIP
+    streams (the views are independent; two half-batches in flight keep the chip busy while one of
+    them is in a small-grid kernel such as the tile scan or the tail of the per-tile sort)."""
     from goliath_amd import losses, render_gs, shade
 
-    for k in ("f_vn", "f_vc", "postex", "tn", "albedo"):
-        t[k].grad = None
-    preds = shade.shading_tail(t["f_vn"], t["f_vc"], t["postex"], t["tn"], t["albedo"], t["light_sh"], t["campos"],
-                               preconv_envmap=t["mips"], lightrot=t["lightrot"])
-    rgb, alpha, depth = render_gs.render_batch(t["K"], t["Rt"], preds, cfg["height"], cfg["width"])
-    loss = losses.l1_image(rgb, t["target"])  # == (rgb - target).abs().mean(), rgb_l1 of loss/__init__.py:411
-    loss.backward()
+    main = torch.cuda.current_stream()
+    loss = None
+    for mb, stream in zip(t["micro"], t["streams"]):
+        stream.wait_stream(main)
+        with torch.cuda.stream(stream):
+            for k in ("f_vn", "f_vc", "postex", "tn", "albedo"):
+                mb[k].grad = None
+            preds = shade.shading_tail(mb["f_vn"], mb["f_vc"], mb["postex"], mb["tn"], mb["albedo"], mb["light_sh"],
+                                       mb["campos"], preconv_envmap=mb["mips"], lightrot=mb["lightrot"])
+            rgb, alpha, depth = render_gs.render_batch(mb["K"], mb["Rt"], preds, cfg["height"], cfg["width"])
+            loss = losses.l1_image(rgb, mb["target"])  # == (rgb - target).abs().mean(), loss/__init__.py:411
+            loss.backward()
+    for stream in t["streams"]:
+        main.wait_stream(stream)
+    # the path's only parameter (albedo, rgca.py:462-464) is shared by all views: sum the micro-batch grads
+    t["albedo"].grad = torch.stack([mb["albedo"].grad for mb in t["micro"]]).sum(0)
     if world > 1:
-        t["_sync"].sync()  # reduce-scatter + all-gather of the path's only parameter (albedo, rgca.py:462-464)
+        t["_sync"].sync()  # reduce-scatter + all-gather over RCCL
     return loss
+
+
+def make_step_inputs(cfg, device, rank, n_micro):
+    """The GPU's batch as n_micro micro-batches (leaf tensors per micro-batch, one shared albedo)."""
+    B = cfg["views_per_gpu"]
+    assert B % n_micro == 0
+    micro = [make_inputs(dict(cfg, views_per_gpu=B // n_micro), device, rank * n_micro + i) for i in range(n_micro)]
+    albedo = micro[0]["albedo"].detach().clone().requires_grad_(True)
+    for mb in micro:
+        mb["albedo"] = albedo.detach().clone().requires_grad_(True)  # per-stream alias of the shared parameter
+    return {"micro": micro, "albedo": albedo, "streams": [torch.cuda.Stream(device=device) for _ in range(n_micro)]}
 
 
 # algorithmic HBM bytes per view of each ABI call (DESIGN.md "Kernels and their rooflines").
@@ -247,6 +271,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--views", type=int, default=CFG["views_per_gpu"])
+    ap.add_argument("--micro", type=int, default=2, help="micro-batches (HIP streams) per step")
     ap.add_argument("--workload", choices=["rgca", "mvp"], default="rgca",
                     help="rgca = the BASELINE metric (default); mvp = secondary BASELINE config 5 line")
     args = ap.parse_args()
@@ -268,7 +293,7 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
     from goliath_amd import _lib, splat
 
-    t = make_inputs(cfg, dev, rank)
+    t = make_step_inputs(cfg, dev, rank, args.micro)
     from goliath_amd import parallel
 
     t["_sync"] = parallel.GradSync([t["albedo"]])
@@ -310,20 +335,24 @@ def main():
         with torch.no_grad():
             from goliath_amd import render_gs, shade
 
-            preds = shade.shading_tail(t["f_vn"], t["f_vc"], t["postex"], t["tn"], t["albedo"], t["light_sh"],
-                                       t["campos"], preconv_envmap=t["mips"], lightrot=t["lightrot"])
-            intr = torch.stack([t["K"][:, 0, 0], t["K"][:, 1, 1], t["K"][:, 0, 2], t["K"][:, 1, 2]], -1)
+            m0 = t["micro"][0]
+            preds = shade.shading_tail(m0["f_vn"], m0["f_vc"], m0["postex"], m0["tn"], m0["albedo"], m0["light_sh"],
+                                       m0["campos"], preconv_envmap=m0["mips"], lightrot=m0["lightrot"])
+            intr = torch.stack([m0["K"][:, 0, 0], m0["K"][:, 1, 1], m0["K"][:, 0, 2], m0["K"][:, 1, 2]], -1)
             out = splat.render_views(preds["primpos"], preds["primscale"], preds["primqvec"], preds["opacity"],
-                                     preds["color"], t["Rt"], intr, cfg["height"], cfg["width"])
+                                     preds["color"], m0["Rt"], intr, cfg["height"], cfg["width"])
             I = float(out["n_isect"].float().mean())
             mean_alpha = float(out["alpha"].mean())
         dom = max(kernels_ms, key=kernels_ms.get)
-        mip_bytes = sum(m[0].numel() * 4 for m in t["mips"])
-        ach = B * algorithmic_bytes(dom, N, I, P, mip_bytes) / (kernels_ms[dom] * 1e-3) / 1e9
+        mip_bytes = sum(m[0].numel() * 4 for m in t["micro"][0]["mips"])
+        views_per_launch = B // args.micro  # every ABI call processes one micro-batch
+        ach = views_per_launch * algorithmic_bytes(dom, N, I, P, mip_bytes) / (kernels_ms[dom] * 1e-3) / 1e9
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             traffic = json.load(open(tpath)).get(dom)
+            if traffic is not None:
+                traffic = traffic * views_per_launch / 8.0  # profiles/traffic.json is per 8-view launch
         views = B * world * args.steps
         res = {
             "metric": "relit views/sec (fwd+bwd) at 2048x1334, 250k Gaussians",
@@ -331,7 +360,7 @@ def main():
             "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": cfg["workload"], "gaussians": N, "image": [cfg["height"], cfg["width"]],
-                       "views_per_gpu": B, "relight": "envmap_4mips", "intersections_per_view": I,
+                       "views_per_gpu": B, "micro_batches": args.micro, "relight": "envmap_4mips", "intersections_per_view": I,
                        "mean_alpha": mean_alpha, "parallelism": f"view-parallel x{world}"},
             "kernels_ms_per_call": kernels_ms,
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
