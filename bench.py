@@ -215,6 +215,115 @@ def mvp_inputs(cfg, device, rank=0):
     return t
 
 
+def _time_steps(step, args):
+    """warmup + timed steps of a secondary workload; returns (last output, seconds, mean ms per ABI call)."""
+    from goliath_amd import _lib
+
+    for _ in range(args.warmup):
+        out = step()
+    torch.cuda.synchronize()
+    _lib.TIMING = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    timing, _lib.TIMING = _lib.TIMING, None
+    per = {}
+    for name, e0, e1 in timing:
+        per.setdefault(name, []).append(e0.elapsed_time(e1))
+    return out, dt, {k: sum(v) / len(v) for k, v in per.items()}
+
+
+def _secondary_line(metric, unit, units_per_step, args, dt, ms, alg, config):
+    dom = max(ms, key=ms.get)
+    ach = alg.get(dom, 0) / (ms[dom] * 1e-3) / 1e9
+    print(json.dumps({
+        "metric": metric, "value": units_per_step * args.steps / dt, "unit": unit, "n_gpus": 1, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic", "config": config, "kernels_ms_per_call": ms,
+        "algorithmic_GBs_per_call": {k: alg[k] / (ms[k] * 1e-3) / 1e9 for k in ms if k in alg},
+        "roofline": {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": ach / HBM_PEAK_GBS, "traffic": None}}), flush=True)
+
+
+URHAND_CFG = dict(workload="urhand_config4_uvlight", uv=1024, lights=32, frames_per_gpu=1, seed=4)
+
+
+def urhand_main(args):
+    """Secondary workload (BASELINE config 4): URHand UV light loops, S=1024, L=32 point lights on a
+    1100 mm sphere, B=1: Phong features (urhand.py:419-445) + GGX shading (:508-567), fwd+bwd."""
+    from goliath_amd import uvlight
+
+    cfg = URHAND_CFG
+    dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
+    torch.cuda.set_device(dev)
+    g = torch.Generator().manual_seed(cfg["seed"])
+    B, S, L = cfg["frames_per_gpu"], cfg["uv"], cfg["lights"]
+    d = F.normalize(torch.randn(B, 3, S, S, generator=g), dim=1)
+    t = dict(p_uv=d * 90.0, nml=F.normalize(d + 0.2 * torch.randn(B, 3, S, S, generator=g), dim=1),
+             cam=torch.tensor([[0.0, 0.0, -700.0]] * B),
+             lpos=1100.0 * F.normalize(torch.randn(B, L, 3, generator=g), dim=-1),
+             lint=torch.rand(B, L, 1, generator=g), shadow=torch.rand(B, L, 1, S, S, generator=g),
+             rough=0.3 + 0.5 * torch.rand(B, 1, S, S, generator=g), tex=torch.rand(B, 3, S, S, generator=g),
+             u1=torch.randn(B, 1, S, S, generator=g), u2=torch.randn(B, 3, 1, S, S, generator=g),
+             u3=torch.randn(B, 4, S, S, generator=g), u4=torch.randn(B, 3, S, S, generator=g))
+    t = {k: v.to(dev).contiguous() for k, v in t.items()}
+    for k in ("p_uv", "nml", "rough", "tex"):
+        t[k].requires_grad_(True)
+
+    def step():
+        for k in ("p_uv", "nml", "rough", "tex"):
+            t[k].grad = None
+        diff, spec = uvlight.phong_features(t["p_uv"], t["nml"], t["cam"], t["lpos"], t["lint"], t["shadow"])
+        feat, rgb = uvlight.ggx_features(t["p_uv"], t["nml"], t["cam"], t["lpos"], t["lint"], t["rough"], t["tex"],
+                                         t["shadow"])
+        torch.autograd.backward([diff, spec, feat, rgb], [t["u1"], t["u2"], t["u3"], t["u4"]])
+        return rgb
+
+    _, dt, ms = _time_steps(step, args)
+    T = B * S * S
+    sh = 4 * L * T  # the shadow map is the dominant stream: one float per texel per light
+    alg = {"gol_uvlight_phong_fwd": sh + 24 * T + 16 * T, "gol_uvlight_phong_bwd": sh + 24 * T + 16 * T + 24 * T,
+           "gol_uvlight_ggx_fwd": sh + 40 * T + 28 * T, "gol_uvlight_ggx_bwd": sh + 40 * T + 28 * T + 40 * T}
+    _secondary_line("URHand UV light-loop frames/sec (Phong + GGX, fwd+bwd), 1024x1024 texels x 32 lights",
+                    "frames/s", B, args, dt, ms, alg,
+                    {"workload": cfg["workload"], "uv": [S, S], "lights": L, "frames_per_gpu": B})
+
+
+SG_CFG = dict(workload="sgutils_native", gaussians=1_048_576, views=8, lights=8, seed=7)
+
+
+def sg_main(args):
+    """Secondary workload: sgutils evaluate_gaussian fwd+bwd at the reference-native N=1,048,576 Gaussians,
+    B=8 views, 8 point lights per view (sgutils.py:17-98; SURVEY 8d sgutils bytes)."""
+    from goliath_amd import sg
+
+    cfg = SG_CFG
+    dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
+    torch.cuda.set_device(dev)
+    g = torch.Generator().manual_seed(cfg["seed"])
+    B, N, L = cfg["views"], cfg["gaussians"], cfg["lights"]
+    t = dict(dirs=F.normalize(torch.randn(B, N, 3, generator=g), dim=-1), sig=0.02 + 0.3 * torch.rand(B, N, generator=g),
+             lval=torch.rand(B, L, 3, generator=g), lpts=1100.0 * F.normalize(torch.randn(B, L, 3, generator=g), dim=-1),
+             pts=100.0 * torch.randn(B, N, 3, generator=g), nl=torch.full((B,), L, dtype=torch.int32),
+             up=torch.randn(B, N, 3, generator=g))
+    t = {k: v.to(dev).contiguous() for k, v in t.items()}
+    t["dirs"].requires_grad_(True)
+    t["sig"].requires_grad_(True)
+
+    def step():
+        t["dirs"].grad = t["sig"].grad = None
+        out = sg.evaluate_gaussian(t["dirs"], t["sig"], t["lval"], t["lpts"], t["pts"], t["nl"])
+        out.backward(t["up"])
+        return out
+
+    _, dt, ms = _time_steps(step, args)
+    alg = {"gol_sg_eval_fwd": 40 * B * N, "gol_sg_eval_bwd": 56 * B * N}
+    _secondary_line("sgutils evaluate_gaussian Gaussians/sec (fwd+bwd), 8 lights", "Gaussians/s", B * N, args, dt, ms, alg,
+                    {"workload": cfg["workload"], "gaussians": N, "views": B, "lights": L})
+
+
 def mvp_main(args):
     """Secondary workload (BASELINE config 5): MVP ray march fwd+bwd, 1 view of 2048x1334 per step."""
     from goliath_amd import _lib, mvp
@@ -234,34 +343,135 @@ def mvp_main(args):
         (out - t["target"]).abs().mean().backward()
         return out
 
+    out, dt, ms = _time_steps(step, args)
+    P = H * W
+    tpl_bytes = t["template"].numel() * 4
+    alg = {"gol_mvp_march_fwd": 32 * P + 28 * P + tpl_bytes, "gol_mvp_march_bwd": 32 * P + 28 * P + 3 * tpl_bytes}
+    _secondary_line("MVP ray-march views/sec (fwd+bwd) at 2048x1334, 4096 primitives", "views/s", 1, args, dt, ms, alg,
+                    {"workload": cfg["workload"], "prims": cfg["prims"], "template": list(cfg["tdim"]),
+                     "image": [H, W], "stepsize": 1.0 / 64, "mean_alpha": float(out[..., 3].mean())})
+
+
+E2E_CFG = dict(workload="rgca_e2e_native_slab1024", slab=1024, height=2048, width=1334, views_per_gpu=8, focal=3000.0,
+               cam_radius_mm=700.0, n_mips=4, seed=4321)
+
+
+def e2e_main(args):
+    """SURVEY 8d mode B at the reference-native size: 1024^2 = 1,048,576 Gaussians, 8 views of 2048x1334 per
+    step, random-init decoder of the reference architecture (goliath_amd.decoder) -> shading tail -> render ->
+    L1 loss -> backward -> Adam step (rgca_example.yml: torch.optim.Adam, lr 5e-4).  Geometry (postex / tn)
+    is synthetic input: the mesh -> uv rasteriser is outside the path.  --fused-tail folds the two last
+    transposed-conv layers into the shading kernel (SURVEY 8f #1)."""
+    from goliath_amd import decoder, losses, parallel, render_gs, shade, splat
+
+    cfg = dict(E2E_CFG, views_per_gpu=args.views)
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
+    torch.cuda.set_device(dev)
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+    torch.manual_seed(cfg["seed"])  # same initial weights on every rank
+    dec = decoder.PrimDecoderConvs(base=cfg["slab"] // 128).to(dev)
+    B, S, H, W = cfg["views_per_gpu"], cfg["slab"], cfg["height"], cfg["width"]
+    N = S * S
+    small = make_inputs(dict(CFG, slab=8, views_per_gpu=B), "cpu", rank)  # cameras, lights, env map
+    g = torch.Generator(device=dev).manual_seed(cfg["seed"] + 1000 * rank)
+    d = F.normalize(torch.randn(N, 3, device=dev, generator=g), dim=-1)
+    pos = d * torch.rand(N, 1, device=dev, generator=g) ** (1 / 3) * torch.tensor([90.0, 120.0, 100.0], device=dev)
+    t = {k: small[k].detach().to(dev) for k in ("light_sh", "K", "Rt", "campos", "lightrot")}
+    t["mips"] = [m.to(dev) for m in small["mips"]]
+    t["postex"] = pos.t().reshape(1, 3, S, S).expand(B, -1, -1, -1).contiguous()
+    t["tn"] = F.normalize(pos, dim=-1).t().reshape(1, 3, S, S).expand(B, -1, -1, -1).contiguous()
+    t["embs"] = torch.randn(B, 256, device=dev, generator=g)
+    t["target"] = torch.rand(B, 3, H, W, device=dev, generator=g)
+    albedo = torch.nn.Parameter(0.2 + 0.6 * torch.rand(1, N, 3, device=dev, generator=g))
+    params = list(dec.parameters()) + [albedo]
+    opt = torch.optim.Adam(params, lr=5e-4, fused=True)  # one multi-tensor kernel: same math as the default
+    sync = parallel.GradSync(params)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        ev[0].record()
+        if args.fused_tail:
+            from goliath_amd import tail
+
+            x_vn, x_vc = dec.trunk(t["embs"], t["campos"])
+            ev[1].record()
+            preds = tail.fused_tail(dec.vnocond_mod[-1], dec.vcond_mod[-1], x_vn, x_vc, t["postex"], t["tn"], albedo, t["light_sh"], t["campos"],
+                                    preconv_envmap=t["mips"], lightrot=t["lightrot"])
+        else:
+            f_vn, f_vc = dec(t["embs"], t["campos"])
+            ev[1].record()
+            preds = shade.shading_tail(f_vn, f_vc, t["postex"], t["tn"], albedo, t["light_sh"], t["campos"],
+                                       preconv_envmap=t["mips"], lightrot=t["lightrot"])
+        rgb, alpha, depth = render_gs.render_batch(t["K"], t["Rt"], preds, H, W)
+        loss = losses.l1_image(rgb, t["target"])
+        loss.backward()
+        ev[2].record()
+        if world > 1:
+            sync.sync()
+        opt.step()
+        ev[3].record()
+        return loss
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    from goliath_amd import _lib
+
     for _ in range(args.warmup):
-        out = step()
-    torch.cuda.synchronize()
+        step()
+    barrier()
     _lib.TIMING = []
+    seg = [0.0, 0.0, 0.0]
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        out = step()
-    torch.cuda.synchronize()
+        step()
+        if args.segments:  # per-segment event times need a sync per step: off in the headline number
+            torch.cuda.synchronize()
+            for i in range(3):
+                seg[i] += ev[i].elapsed_time(ev[i + 1])
+    barrier()
     dt = time.perf_counter() - t0
     timing, _lib.TIMING = _lib.TIMING, None
+    splat.PLANNER.poll(block=True)
+    if world > 1:
+        import torch.distributed as dist
+
+        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax)
     per = {}
     for name, e0, e1 in timing:
         per.setdefault(name, []).append(e0.elapsed_time(e1))
     ms = {k: sum(v) / len(v) for k, v in per.items()}
-    P = H * W
-    tpl_bytes = t["template"].numel() * 4
-    alg = {"gol_mvp_march_fwd": 32 * P + 28 * P + tpl_bytes, "gol_mvp_march_bwd": 32 * P + 28 * P + 3 * tpl_bytes}
-    dom = max(ms, key=ms.get)
-    ach = alg.get(dom, 0) / (ms[dom] * 1e-3) / 1e9
-    print(json.dumps({
-        "metric": "MVP ray-march views/sec (fwd+bwd) at 2048x1334, 4096 primitives", "value": args.steps / dt,
-        "unit": "views/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": cfg["workload"], "prims": cfg["prims"], "template": list(cfg["tdim"]),
-                   "image": [H, W], "stepsize": 1.0 / 64, "mean_alpha": float(out[..., 3].mean())},
-        "kernels_ms_per_call": ms,
-        "roofline": {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": ach / HBM_PEAK_GBS, "traffic": None}}), flush=True)
+    if rank == 0:
+        res = {"metric": "relit views/sec end-to-end (decode + shade + render + loss + backward + Adam) at 2048x1334, "
+                         "1,048,576 Gaussians", "value": B * world * args.steps / dt, "unit": "views/s",
+               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "config": {"workload": cfg["workload"], "gaussians": N, "image": [H, W], "views_per_gpu": B,
+                          "fused_tail": bool(args.fused_tail), "trainable_params": sum(p.numel() for p in params),
+                          "parallelism": f"view-parallel x{world}"},
+               "kernels_ms_per_call": ms, "hot_path_ms_per_step": sum(sum(v) for v in per.values()) / args.steps}
+        if args.segments:
+            res["segments_ms"] = {"decoder_fwd" if not args.fused_tail else "decoder_trunk_fwd": seg[0] / args.steps,
+                                  "tail_render_loss_and_all_backward": seg[1] / args.steps,
+                                  "grad_sync_and_adam": seg[2] / args.steps}
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 def main():
@@ -272,11 +482,13 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--views", type=int, default=CFG["views_per_gpu"])
     ap.add_argument("--micro", type=int, default=2, help="micro-batches (HIP streams) per step")
-    ap.add_argument("--workload", choices=["rgca", "mvp"], default="rgca",
+    ap.add_argument("--workload", choices=["rgca", "mvp", "urhand", "sg", "e2e"], default="rgca",
                     help="rgca = the BASELINE metric (default); mvp = secondary BASELINE config 5 line")
+    ap.add_argument("--fused-tail", action="store_true", help="e2e: fold the last decoder layers into the shade kernel")
+    ap.add_argument("--segments", action="store_true", help="e2e: also report per-segment times (adds a sync per step)")
     args = ap.parse_args()
-    if args.workload == "mvp":
-        return mvp_main(args)
+    if args.workload != "rgca":
+        return {"mvp": mvp_main, "urhand": urhand_main, "sg": sg_main, "e2e": e2e_main}[args.workload](args)
     cfg = dict(CFG, views_per_gpu=args.views)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))

@@ -12,8 +12,11 @@ from typing import Any, Dict, Optional
 import torch as th
 import torch.nn.functional as F
 
+import os
+
 from .render_gs import render_batch
 from .shade import shading_tail
+from .tail import fused_tail
 
 
 def autoencoder_render(self, K: th.Tensor, Rt: th.Tensor, preds: Dict[str, Any]):
@@ -31,6 +34,18 @@ def random_light_sh(sh_fn, n_diff_sh: int, batch: int, device, dtype):
     return light_dir, light_sh
 
 
+def _can_fuse_tail(dec) -> bool:
+    """The last layers are un-fused weight-normalised transposed convs (parameters weight_v / weight_g / bias)
+    inside nn.Sequential stacks, and GOLIATH_FUSED_TAIL is not 0."""
+    if os.environ.get("GOLIATH_FUSED_TAIL", "1") == "0":
+        return False
+    mods = (dec.vnocond_mod, dec.vcond_mod)
+    if not all(isinstance(m, th.nn.Sequential) for m in mods):
+        return False
+    return all(all(hasattr(m[-1], a) for a in ("weight_v", "weight_g", "bias")) and
+               tuple(m[-1].weight_v.shape[2:]) == (4, 4) for m in mods)
+
+
 def prim_decoder_forward(self, embs: th.Tensor, geom: th.Tensor, headrel_campos: th.Tensor,
                          light_intensity: th.Tensor, headrel_light_pos: th.Tensor, headrel_light_sh: th.Tensor,
                          n_lights: th.Tensor, preconv_envmap: Optional[th.Tensor] = None,
@@ -40,9 +55,11 @@ def prim_decoder_forward(self, embs: th.Tensor, geom: th.Tensor, headrel_campos:
     postex = self.geo_fn.to_uv(geom)
     tn = F.normalize(self.geo_fn.to_uv(self.geo_fn.vn(geom)), dim=1)
     z = self.encmod(embs).view(-1, 256, 8, 8)
-    f_vnocond = self.vnocond_mod(z)
     view = self.viewmod(F.normalize(headrel_campos, dim=1))[:, :, None, None].expand(-1, -1, 8, 8)
-    f_vcond = self.vcond_mod(th.cat([z, view], dim=1))
+    zv = th.cat([z, view], dim=1)
+    fuse = _can_fuse_tail(self)
+    if not fuse:
+        f_vnocond, f_vcond = self.vnocond_mod(z), self.vcond_mod(zv)
 
     light_sh_rand, light_dir = None, None
     if self.training:
@@ -50,10 +67,14 @@ def prim_decoder_forward(self, embs: th.Tensor, geom: th.Tensor, headrel_campos:
 
         light_dir, light_sh_rand = random_light_sh(sh.dir2sh_torch, self.diff_sh_degree, B, embs.device,
                                                    headrel_light_pos.dtype)
-    preds = shading_tail(f_vnocond, f_vcond, postex, tn, self.albedo, headrel_light_sh, headrel_campos,
-                         light_intensity=light_intensity, headrel_light_pos=headrel_light_pos, n_lights=n_lights,
-                         preconv_envmap=preconv_envmap, lightrot=lightrot, light_sh_rand=light_sh_rand,
-                         n_color_sh=self.color_sh_degree, n_diff_sh=self.diff_sh_degree)
+    kw = dict(light_intensity=light_intensity, headrel_light_pos=headrel_light_pos, n_lights=n_lights,
+              preconv_envmap=preconv_envmap, lightrot=lightrot, light_sh_rand=light_sh_rand,
+              n_color_sh=self.color_sh_degree, n_diff_sh=self.diff_sh_degree)
+    if fuse:  # the 125-channel activation is never materialised (goliath_amd/tail.py)
+        preds = fused_tail(self.vnocond_mod[-1], self.vcond_mod[-1], self.vnocond_mod[:-1](z), self.vcond_mod[:-1](zv),
+                           postex, tn, self.albedo, headrel_light_sh, headrel_campos, **kw)
+    else:
+        preds = shading_tail(f_vnocond, f_vcond, postex, tn, self.albedo, headrel_light_sh, headrel_campos, **kw)
     if self.training:
         with th.no_grad():
             preds["cos_weight"] = (light_dir * preds["spec_nml"]).sum(dim=-1, keepdim=True)

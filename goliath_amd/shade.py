@@ -158,10 +158,19 @@ def shading_tail(f_vnocond, f_vcond, postex, tn, albedo, headrel_light_sh, headr
     """f_vnocond[B,125,S,S], f_vcond[B,4,S,S] (decoder outputs, NCHW), postex[B,3,S,S]
     (geo_fn.to_uv(geom)), tn[B,3,S,S] (normalised uv normal map), albedo[1,N,3] -> dict with the keys
     and [B,N,k] shapes of rgca.py:574-588 (+ "color_rand" when light_sh_rand[B,3,81] is given)."""
+    ncol = (n_color_sh + 1) ** 2
+    return shading_tail_coefs(f_vnocond, f_vcond, postex, tn, albedo, headrel_light_sh, headrel_campos, ncol,
+                              (n_diff_sh + 1) ** 2 - ncol, light_intensity, headrel_light_pos, n_lights,
+                              preconv_envmap, lightrot, light_sh_rand)
+
+
+def shading_tail_coefs(f_vnocond, f_vcond, postex, tn, albedo, headrel_light_sh, headrel_campos, ncol, nmono,
+                       light_intensity=None, headrel_light_pos=None, n_lights=None, preconv_envmap=None,
+                       lightrot=None, light_sh_rand=None):
+    """shading_tail with the SH layout given as coefficient counts: f_vnocond has 3*ncol colour-SH
+    channels, nmono monochrome ones and the 12 Gaussian-parameter channels; light_sh is [B,3,ncol+nmono]."""
     if not f_vnocond.is_cuda:
         raise _lib.GoliathHipError("shading_tail needs CUDA(HIP) tensors; there is no CPU path")
-    ncol = (n_color_sh + 1) ** 2
-    nmono = (n_diff_sh + 1) ** 2 - ncol
     B, C = f_vnocond.shape[:2]
     if C != 3 * ncol + nmono + 12:
         raise ValueError(f"f_vnocond has {C} channels, expected {3 * ncol + nmono + 12}")

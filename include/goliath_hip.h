@@ -276,6 +276,26 @@ int gol_l1_fwd(int B, int C, int HW, int mask_c, const float* pred, const float*
 int gol_l1_bwd(int B, int C, int HW, int mask_c, const float* pred, const float* target, const float* mask,
                const float* g_loss, float* g_pred, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Light-contracted last decoder layer ("next" row).  Replaces
+ *   ConvTranspose2dWNUB(16 -> C_out, 4, 2, 1)  (ca_code/models/rgca.py:427,455; ca_code/nn/layers.py:331-397)
+ * followed by the SH contraction of rgca.py:506-514,528-530, for weights the host has already contracted
+ * with the light (goliath_amd/tail.py):
+ *   out[b,ch,oy,ox] = sum_{ci,ky,kx} x[b,ci,iy,ix] weff[b',ci,ch,ky,kx]   (oy = 2 iy - 1 + ky, b' = wB==1 ? 0 : b)
+ *                     + (ch < E ? sum_k lc[k,b,ch] bias[k,oy,ox] : bias[nd + ch - E, oy, ox])
+ *   x [B,16,h,w]; weff [wB,16,CH,4,4]; lc [nd,B,E] (E = 0|3|6 contracted channels, nd SH planes; plane-major so a plane's B*E
+ *   coefficients are one contiguous scalar load);
+ *   bias [nd + CH - E, 2h, 2w]; out [B,CH,2h,2w].
+ * bwd (any of g_x / g_weff / g_bias may be NULL = not wanted):
+ *   g_x [B,16,h,w] written; needs weff_t = weff permuted to [wB,CH,4,4,16];
+ *   g_weff [wB,16,CH,4,4] ACCUMULATES (caller zeroes), fp32 MFMA + float atomics; needs x;
+ *   g_bias [nd + CH - E, 2h, 2w] written.
+ * ---------------------------------------------------------------------------------------- */
+int gol_tail_conv_fwd(int B, int Ci, int h, int w, int CH, int E, int nd, int wB, const float* x, const float* weff,
+                      const float* lc, const float* bias, float* out, void* stream);
+int gol_tail_conv_bwd(int B, int Ci, int h, int w, int CH, int E, int nd, int wB, const float* x, const float* weff_t,
+                      const float* lc, const float* g_out, float* g_x, float* g_weff, float* g_bias, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,126 @@
+"""GPU: the light-contracted decoder tail (goliath_amd.tail.fused_tail) == last conv layers followed by the
+shading tail, values and gradients (tolerance: rel-L2 <= 1e-4, the contraction only re-associates fp32 sums)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from scenes import rel_l2
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(B, h, seed, env):
+    from goliath_amd import decoder
+
+    torch.manual_seed(seed)
+    S = 2 * h
+    N = S * S
+    dev = "cuda"
+    vn = decoder.ConvTranspose2dWNUB(16, 125, S, S, alpha=1.0).to(dev)
+    vc = decoder.ConvTranspose2dWNUB(16, 4, S, S, alpha=1.0).to(dev)
+    with torch.no_grad():
+        vn.bias.normal_(0, 0.3)
+        vc.bias.normal_(0, 0.3)
+        vn.weight_g.mul_(3.0)
+    t = dict(x_vn=torch.randn(B, 16, h, h), x_vc=torch.randn(B, 16, h, h),
+             postex=60 * torch.randn(B, 3, S, S), tn=F.normalize(torch.randn(B, 3, S, S), dim=1),
+             albedo=0.2 + 0.6 * torch.rand(1, N, 3), light_sh=0.4 * torch.randn(B, 3, 81), campos=torch.tensor([[0.0, 0, -700]] * B),
+             light_sh_rand=0.4 * torch.randn(B, 3, 81))
+    t = {k: v.to(dev) for k, v in t.items()}
+    if env:
+        kw = dict(preconv_envmap=[torch.rand(B, 3, 32 >> i, 64 >> i, device=dev) for i in range(3)],
+                  lightrot=torch.eye(3, device=dev)[None].repeat(B, 1, 1))
+    else:
+        kw = dict(light_intensity=torch.rand(B, 4, 1, device=dev), headrel_light_pos=1000 * torch.randn(B, 4, 3, device=dev),
+                  n_lights=torch.full((B,), 4, dtype=torch.int32, device=dev))
+    leaves = [t["x_vn"], t["x_vc"], t["postex"], t["tn"], t["albedo"], vn.weight_v, vn.weight_g, vn.bias, vc.weight_v,
+              vc.weight_g, vc.bias]
+    for l in leaves:
+        l.requires_grad_(True)
+    return vn, vc, t, kw, leaves
+
+
+@pytest.mark.parametrize("env,rand", [(True, False), (False, True), (True, True)])
+def test_fused_tail_matches_unfused(env, rand):
+    from goliath_amd import shade, tail
+
+    vn, vc, t, kw, leaves = _setup(2, 9, 5, env)
+    lr = t["light_sh_rand"] if rand else None
+    ref = shade.shading_tail(vn(t["x_vn"]), vc(t["x_vc"]), t["postex"], t["tn"], t["albedo"], t["light_sh"], t["campos"],
+                             light_sh_rand=lr, **kw)
+    got = tail.fused_tail(vn, vc, t["x_vn"], t["x_vc"], t["postex"], t["tn"], t["albedo"], t["light_sh"], t["campos"],
+                          light_sh_rand=lr, **kw)
+    assert set(got) == set(ref)
+    torch.manual_seed(0)
+    ups = {k: torch.randn_like(v) for k, v in ref.items()}
+    for k in ref:
+        assert rel_l2(got[k], ref[k]) < 1e-4, k
+    g_ref = torch.autograd.grad(sum((ref[k] * ups[k]).sum() for k in ref), leaves)
+    g_got = torch.autograd.grad(sum((got[k] * ups[k]).sum() for k in got), leaves)
+    names = "x_vn x_vc postex tn albedo vn.v vn.g vn.bias vc.v vc.g vc.bias".split()
+    for n, a, b in zip(names, g_got, g_ref):
+        assert rel_l2(a, b) < 1e-4, n
+
+
+def test_prim_decoder_forward_fuses_the_tail(monkeypatch):
+    """The model-level drop-in picks the fused tail for weight-normalised Sequential decoders and gives the
+    same predictions as with GOLIATH_FUSED_TAIL=0 (reference-native slab: 1024^2 Gaussians, B=1)."""
+    from goliath_amd import decoder, rgca
+
+    torch.manual_seed(3)
+    dec = decoder.PrimDecoderConvs().cuda()
+    S = dec.slabsize
+    with torch.no_grad():
+        dec.vnocond_mod[-1].bias.normal_(0, 0.2)
+
+    class Geo:
+        def to_uv(self, x):
+            return x
+
+        def vn(self, x):
+            return torch.roll(x, 1, 1)
+
+    dec.geo_fn, dec.albedo = Geo(), torch.nn.Parameter(torch.rand(1, S * S, 3, device="cuda"))
+    dec.color_sh_degree, dec.diff_sh_degree = 3, 8
+    dec.eval()
+    geom = 50 * torch.randn(1, 3, S, S, device="cuda")
+    args = (torch.randn(1, 256, device="cuda"), geom, torch.tensor([[0.0, 0, -700]], device="cuda"),
+            torch.rand(1, 2, 1, device="cuda"), 1000 * torch.randn(1, 2, 3, device="cuda"), 0.3 * torch.randn(1, 3, 81, device="cuda"),
+            torch.full((1,), 2, dtype=torch.int32, device="cuda"))
+    assert rgca._can_fuse_tail(dec)
+    with torch.no_grad():
+        fused = rgca.prim_decoder_forward(dec, *args)
+        monkeypatch.setenv("GOLIATH_FUSED_TAIL", "0")
+        assert not rgca._can_fuse_tail(dec)
+        plain = rgca.prim_decoder_forward(dec, *args)
+    for k in plain:
+        assert rel_l2(fused[k], plain[k]) < 1e-4, k
+
+
+@pytest.mark.parametrize("B,h,w,CH,E,wB", [(2, 9, 9, 15, 3, 2), (3, 8, 20, 18, 6, 3), (2, 7, 5, 4, 0, 1), (9, 4, 6, 15, 3, 9),
+                                           (1, 33, 47, 7, 3, 1)])
+def test_tail_conv_kernels_match_torch(B, h, w, CH, E, wB):
+    """gol_tail_conv_fwd/bwd == grouped F.conv_transpose2d + einsum, values and the three gradients."""
+    from goliath_amd import tail
+
+    torch.manual_seed(B * 100 + CH)
+    nd = 11 if E else 0
+    x = torch.randn(B, 16, h, w, device="cuda", requires_grad=True)
+    weff = (0.2 * torch.randn(wB, 16, CH, 4, 4, device="cuda")).requires_grad_(True)
+    lc = torch.randn(B, E, nd, device="cuda") if E else None
+    bias = torch.randn(nd + CH - E, 2 * h, 2 * w, device="cuda", requires_grad=True)
+    got = tail.tail_conv(x, weff, lc, bias)
+    we = weff.expand(B, -1, -1, -1, -1)
+    ref = F.conv_transpose2d(x.reshape(1, B * 16, h, w), we.reshape(B * 16, CH, 4, 4), None, 2, 1, groups=B).view(
+        B, CH, 2 * h, 2 * w)
+    if E:
+        ref = ref + torch.cat([torch.einsum("bek,kn->ben", lc, bias[:nd].reshape(nd, -1)).view(B, E, 2 * h, 2 * w),
+                               bias[None, nd:].expand(B, -1, -1, -1)], 1)
+    else:
+        ref = ref + bias[None]
+    assert rel_l2(got, ref) < 1e-5
+    up = torch.randn_like(ref)
+    g_got = torch.autograd.grad((got * up).sum(), [x, weff, bias])
+    g_ref = torch.autograd.grad((ref * up).sum(), [x, weff, bias])
+    for n, a, b in zip(("x", "weff", "bias"), g_got, g_ref):
+        assert rel_l2(a, b) < 1e-5, n
