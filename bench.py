@@ -252,8 +252,9 @@ URHAND_CFG = dict(workload="urhand_config4_uvlight", uv=1024, lights=32, frames_
 
 def urhand_main(args):
     """Secondary workload (BASELINE config 4): URHand UV light loops, S=1024, L=32 point lights on a
-    1100 mm sphere, B=1: Phong features (urhand.py:419-445) + GGX shading (:508-567), fwd+bwd."""
-    from goliath_amd import uvlight
+    1100 mm sphere, B=1: shadow-map PCF (shadowmap.py:30-96, depth renders given) + Phong features (urhand.py:419-445) + GGX shading
+    (:508-567), fwd+bwd."""
+    from goliath_amd import shadowmap, uvlight
 
     cfg = URHAND_CFG
     dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
@@ -264,10 +265,15 @@ def urhand_main(args):
     t = dict(p_uv=d * 90.0, nml=F.normalize(d + 0.2 * torch.randn(B, 3, S, S, generator=g), dim=1),
              cam=torch.tensor([[0.0, 0.0, -700.0]] * B),
              lpos=1100.0 * F.normalize(torch.randn(B, L, 3, generator=g), dim=-1),
-             lint=torch.rand(B, L, 1, generator=g), shadow=torch.rand(B, L, 1, S, S, generator=g),
+             lint=torch.rand(B, L, 1, generator=g),
+             depth=650.0 + 150.0 * torch.rand(B * L, 1024, 1024, generator=g),  # light-camera depth renders (input)
              rough=0.3 + 0.5 * torch.rand(B, 1, S, S, generator=g), tex=torch.rand(B, 3, S, S, generator=g),
              u1=torch.randn(B, 1, S, S, generator=g), u2=torch.randn(B, 3, 1, S, S, generator=g),
              u3=torch.randn(B, 4, S, S, generator=g), u4=torch.randn(B, 3, S, S, generator=g))
+    # light cameras looking at the origin, the reference's [R | light_pos] convention (urhand.py:415)
+    z = F.normalize(-t["lpos"].reshape(-1, 3), dim=-1)
+    x = F.normalize(torch.linalg.cross(torch.tensor([0.0, 1.0, 0.0]).expand_as(z), z), dim=-1)
+    t["lrt"] = torch.cat([torch.stack([x, torch.linalg.cross(z, x), z], 1), t["lpos"].reshape(-1, 3, 1)], 2)
     t = {k: v.to(dev).contiguous() for k, v in t.items()}
     for k in ("p_uv", "nml", "rough", "tex"):
         t[k].requires_grad_(True)
@@ -275,16 +281,18 @@ def urhand_main(args):
     def step():
         for k in ("p_uv", "nml", "rough", "tex"):
             t[k].grad = None
-        diff, spec = uvlight.phong_features(t["p_uv"], t["nml"], t["cam"], t["lpos"], t["lint"], t["shadow"])
+        shadow = shadowmap.shadow_pcf(t["depth"], t["lrt"], t["p_uv"], t["nml"], exp_scale=8.0).view(B, L, 1, S, S)
+        diff, spec = uvlight.phong_features(t["p_uv"], t["nml"], t["cam"], t["lpos"], t["lint"], shadow)
         feat, rgb = uvlight.ggx_features(t["p_uv"], t["nml"], t["cam"], t["lpos"], t["lint"], t["rough"], t["tex"],
-                                         t["shadow"])
+                                         shadow)
         torch.autograd.backward([diff, spec, feat, rgb], [t["u1"], t["u2"], t["u3"], t["u4"]])
         return rgb
 
     _, dt, ms = _time_steps(step, args)
     T = B * S * S
     sh = 4 * L * T  # the shadow map is the dominant stream: one float per texel per light
-    alg = {"gol_uvlight_phong_fwd": sh + 24 * T + 16 * T, "gol_uvlight_phong_bwd": sh + 24 * T + 16 * T + 24 * T,
+    alg = {"gol_shadow_pcf": 24 * T + sh + 9 * 4 * L * T,  # texels + shadow out + 9 nearest depth taps per light
+           "gol_uvlight_phong_fwd": sh + 24 * T + 16 * T, "gol_uvlight_phong_bwd": sh + 24 * T + 16 * T + 24 * T,
            "gol_uvlight_ggx_fwd": sh + 40 * T + 28 * T, "gol_uvlight_ggx_bwd": sh + 40 * T + 28 * T + 40 * T}
     _secondary_line("URHand UV light-loop frames/sec (Phong + GGX, fwd+bwd), 1024x1024 texels x 32 lights",
                     "frames/s", B, args, dt, ms, alg,
@@ -359,7 +367,7 @@ E2E_CFG = dict(workload="rgca_e2e_native_slab1024", slab=1024, height=2048, widt
 def e2e_main(args):
     """SURVEY 8d mode B at the reference-native size: 1024^2 = 1,048,576 Gaussians, 8 views of 2048x1334 per
     step, random-init decoder of the reference architecture (goliath_amd.decoder) -> shading tail -> render ->
-    L1 loss -> backward -> Adam step (rgca_example.yml: torch.optim.Adam, lr 5e-4).  Geometry (postex / tn)
+    L1 + SSIM losses (rgca_example.yml:43-52) -> backward -> Adam step (torch.optim.Adam, lr 5e-4).  Geometry (postex / tn)
     is synthetic input: the mesh -> uv rasteriser is outside the path.  --fused-tail folds the two last
     transposed-conv layers into the shading kernel (SURVEY 8f #1)."""
     from goliath_amd import decoder, losses, parallel, render_gs, shade, splat
@@ -409,7 +417,9 @@ def e2e_main(args):
             preds = shade.shading_tail(f_vn, f_vc, t["postex"], t["tn"], albedo, t["light_sh"], t["campos"],
                                        preconv_envmap=t["mips"], lightrot=t["lightrot"])
         rgb, alpha, depth = render_gs.render_batch(t["K"], t["Rt"], preds, H, W)
-        loss = losses.l1_image(rgb, t["target"])
+        loss = 10.0 * losses.l1_image(rgb, t["target"])          # rgca_example.yml:43-47  rgb_l1 weight 1e1
+        if not args.no_ssim:
+            loss = loss + 0.2 * (1.0 - losses.ssim_image(rgb, t["target"]))  # :48-52  rgb_ssim weight 2e-1
         loss.backward()
         ev[2].record()
         if world > 1:
@@ -459,7 +469,8 @@ def e2e_main(args):
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                "config": {"workload": cfg["workload"], "gaussians": N, "image": [H, W], "views_per_gpu": B,
-                          "fused_tail": bool(args.fused_tail), "trainable_params": sum(p.numel() for p in params),
+                          "fused_tail": bool(args.fused_tail), "loss": "10*l1" if args.no_ssim else "10*l1 + 0.2*(1-ssim)",
+                          "trainable_params": sum(p.numel() for p in params),
                           "parallelism": f"view-parallel x{world}"},
                "kernels_ms_per_call": ms, "hot_path_ms_per_step": sum(sum(v) for v in per.values()) / args.steps}
         if args.segments:
@@ -485,6 +496,7 @@ def main():
     ap.add_argument("--workload", choices=["rgca", "mvp", "urhand", "sg", "e2e"], default="rgca",
                     help="rgca = the BASELINE metric (default); mvp = secondary BASELINE config 5 line")
     ap.add_argument("--fused-tail", action="store_true", help="e2e: fold the last decoder layers into the shade kernel")
+    ap.add_argument("--no-ssim", action="store_true", help="e2e: L1 loss only (default: 10*L1 + 0.2*(1-SSIM))")
     ap.add_argument("--segments", action="store_true", help="e2e: also report per-segment times (adds a sync per step)")
     args = ap.parse_args()
     if args.workload != "rgca":

@@ -28,18 +28,21 @@ __device__ __forceinline__ void stplanar(float* __restrict__ p, size_t hw, V3 v)
 
 struct Unit { V3 u; float inv_len; };  // u = x / max(|x|, eps)
 __device__ __forceinline__ Unit normalize(V3 x) {
-  const float il = 1.f / fmaxf(sqrtf(dot(x, x)), kEps);
+  const float il = __builtin_amdgcn_rsqf(fmaxf(dot(x, x), kEps * kEps));  // == 1 / max(|x|, eps): one v_rsq_f32
   return Unit{x * il, il};
 }
+__device__ __forceinline__ float rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 // gradient of normalize: (g - u (u.g)) / |x|
 __device__ __forceinline__ V3 normalize_bwd(const Unit& n, V3 g) { return (g - n.u * dot(n.u, g)) * n.inv_len; }
 
 __device__ __forceinline__ bool in01(float x, float lo, float hi) { return x >= lo && x <= hi; }
 
-// q = min(s^p, 1) and dq/ds
-__device__ __forceinline__ float pow_cap(float s, float p, float& dq) {
-  const float sp = powf(s, p);
-  const float spm1 = (p == 1.f) ? 1.f : powf(s, p - 1.f);
+// q = min(s^p, 1) and dq/ds for s >= 0, with l2s = log2(s) shared by all the powers of a light:
+// s^p = exp2(p log2 s) on the transcendental unit (v_log_f32 / v_exp_f32) instead of the generic powf;
+// log2(0) = -inf gives 0^p = 0 for p > 0 like torch.pow.
+__device__ __forceinline__ float pow_cap(float s, float l2s, float p, float& dq) {
+  const float sp = (p == 1.f) ? s : __builtin_amdgcn_exp2f(p * l2s);
+  const float spm1 = (p == 1.f) ? 1.f : __builtin_amdgcn_exp2f((p - 1.f) * l2s);
   dq = (sp <= 1.f) ? p * spm1 : 0.f;
   return fminf(sp, 1.f);
 }
@@ -78,13 +81,14 @@ __global__ __launch_bounds__(256) void phong_kernel(const gol_uvlight_in in, flo
     const float w = in.light_intensity[(size_t)b * L + l] * sh;
     const float dx = dot(n, Lv.u), sx = dot(ref, Lv.u);
     const float s = fmaxf(sx, 0.f);
+    const float l2s = __builtin_amdgcn_logf(s);  // v_log_f32 = log2
     if (!BWD) {
       D += fminf(fmaxf(dx, 0.f), 1.f) * w;
-      for (int k = 0; k < P; ++k) { float dq; S[k] += pow_cap(s, in.pow[k], dq) * w; }
+      for (int k = 0; k < P; ++k) { float dq; S[k] += pow_cap(s, l2s, in.pow[k], dq) * w; }
     } else {
       const float gd = in01(dx, 0.f, 1.f) ? uD * inv * w : 0.f;
       float gs = 0.f;
-      for (int k = 0; k < P; ++k) { float dq; pow_cap(s, in.pow[k], dq); gs += uS[k] * dq; }
+      for (int k = 0; k < P; ++k) { float dq; pow_cap(s, l2s, in.pow[k], dq); gs += uS[k] * dq; }
       gs = (sx >= 0.f) ? gs * inv * w : 0.f;
       gn = gn + Lv.u * gd;
       gref = gref + Lv.u * gs;
@@ -156,36 +160,38 @@ __global__ __launch_bounds__(256) void ggx_kernel(const gol_uvlight_in in, float
     const float nol = fminf(fmaxf(nol_x, 1e-6f), 1.f), noh = fminf(fmaxf(noh_x, 1e-6f), 1.f),
                 voh = fminf(fmaxf(voh_x, 1e-6f), 1.f);
     const float fmi = (-5.55473f * voh - 6.98316f) * voh;
-    const float e2 = exp2f(fmi);
+    const float e2 = __builtin_amdgcn_exp2f(fmi);
     const float f0 = F0 + (1.f - F0) * e2;
     const float frac = f0 * al2;
     const float nom0 = noh * noh * (al2 - 1.f) + 1.f;
     const float nom2 = nol * (1.f - kk) + kk;
     const float nomx = four_pi * nom0 * nom0 * nom1 * nom2;
     const float nom = fminf(fmaxf(nomx, 1e-6f), four_pi);
-    const float spec = frac / nom;
+    const float inom = rcp(nom);
+    const float spec = frac * inom;
+    const float l2spec = __builtin_amdgcn_logf(spec);
     const float dcx = dot(N0, Lv.u);
     const float dcos = fminf(fmaxf(dcx, 0.f), 1.f), cosine = fmaxf(dcx, 0.f);
     const float lit = dcos > 0.f ? 1.f : 0.f;
     const float wsh = inv * I * sh;
     if (!BWD) {
       feat[0] += dcos * wsh;
-      for (int k = 0; k < P; ++k) { float dq; feat[1 + k] += 10.f * pow_cap(spec, in.pow[k], dq) * wsh * lit; }
+      for (int k = 0; k < P; ++k) { float dq; feat[1 + k] += 10.f * pow_cap(spec, l2spec, in.pow[k], dq) * wsh * lit; }
       const float c = four_pi * invL * I * cosine;
       rgb = rgb + (albedo + v3(spec, spec, spec)) * c;
     } else {
       const float c = four_pi * invL * I;
       const float uRs = uR.x + uR.y + uR.z;
       float g_spec = uRs * c * cosine;
-      for (int k = 0; k < P; ++k) { float dq; pow_cap(spec, in.pow[k], dq); g_spec += uF[1 + k] * 10.f * wsh * lit * dq; }
+      for (int k = 0; k < P; ++k) { float dq; pow_cap(spec, l2spec, in.pow[k], dq); g_spec += uF[1 + k] * 10.f * wsh * lit * dq; }
       const float g_cos = (dcx >= 0.f) ? c * (dot(uR, albedo) + uRs * spec) : 0.f;
       gtex = gtex + uR * (c * cosine * (1.f / (255.f * kPi)));
       const float g_dcx = (in01(dcx, 0.f, 1.f) ? uF[0] * wsh : 0.f) + g_cos;
       gN0 = gN0 + Lv.u * g_dcx;
       V3 gL = N0 * g_dcx;
       // spec = frac / nom
-      const float g_frac = g_spec / nom;
-      const float g_nom = in01(nomx, 1e-6f, four_pi) ? -g_spec * frac / (nom * nom) : 0.f;
+      const float g_frac = g_spec * inom;
+      const float g_nom = in01(nomx, 1e-6f, four_pi) ? -g_spec * frac * inom * inom : 0.f;
       g_al2 += g_frac * f0;
       const float g_voh = in01(voh_x, 1e-6f, 1.f)
                               ? g_frac * al2 * (1.f - F0) * kLn2 * e2 * (2.f * -5.55473f * voh - 6.98316f)

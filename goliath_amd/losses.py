@@ -58,3 +58,52 @@ def rgb_l1(preds, targets, src_key: str = "rendered_rgb", tgt_key: str = "image"
         inv = (~d).float() if d.dtype == torch.bool else (1 - d)
         mask = inv if mask is None else mask * inv
     return l1_image(preds[src_key], targets[tgt_key], None if mask is None else mask.float())
+
+
+class _Ssim(torch.autograd.Function):
+    """Masked-mean SSIM of (target, pred); differentiable in pred (ca_code/utils/ssim.py:25-65)."""
+
+    @staticmethod
+    def forward(ctx, pred, target, mask):
+        B, C, H, W = pred.shape
+        mask_c = 0 if mask is None else mask.shape[1]
+        nb = _lib.load().gol_ssim_blocks(H, W)
+        partial = torch.empty(B * C * nb, device=pred.device)
+        dmap = torch.empty(3, B, C, H, W, device=pred.device) if ctx.needs_input_grad[0] else None
+        with torch.cuda.device(pred.device):
+            _lib.call("gol_ssim_fwd", c_int(B), c_int(C), c_int(H), c_int(W), c_int(mask_c), fptr(target), fptr(pred),
+                      fptr(mask), fptr(partial), fptr(dmap), stream_ptr())
+        if mask is None:
+            denom = torch.full((), float(B * C * H * W), device=pred.device)
+        else:  # ssim.py:44-49: the mask is expanded to the image's channels before it is summed
+            denom = (mask.sum() * (C // mask_c)).clamp(min=1)
+        ctx.save_for_backward(pred, target, dmap, denom)
+        return partial.sum() / denom
+
+    @staticmethod
+    def backward(ctx, g):
+        pred, target, dmap, denom = ctx.saved_tensors
+        B, C, H, W = pred.shape
+        out = torch.empty_like(pred)
+        gs = (g.to(torch.float32) / denom).reshape(1).contiguous()
+        with torch.cuda.device(pred.device):
+            _lib.call("gol_ssim_bwd", c_int(B), c_int(C), c_int(H), c_int(W), fptr(target), fptr(pred), fptr(dmap),
+                      fptr(gs), fptr(out), stream_ptr())
+        return out, None, None
+
+
+def ssim_image(pred: torch.Tensor, target: torch.Tensor, mask: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """ssim(target, pred, mask=mask) of ca_code/utils/ssim.py for [B,C,H,W] images (window 11, size_average)."""
+    if not pred.is_cuda:
+        raise _lib.GoliathHipError("ssim_image needs CUDA(HIP) tensors; there is no CPU path")
+    c = lambda t: None if t is None else t.detach().to(torch.float32).contiguous()
+    return _Ssim.apply(pred.to(torch.float32).contiguous(), c(target), c(mask))
+
+
+def rgb_ssim(preds, targets, src_key: str = "rendered_rgb", tgt_key: str = "image", mask_key: str = "image_mask",
+             normalize_mask: bool = True):
+    """Same semantics as the reference's rgb_ssim (ca_code/loss/__init__.py:478-494)."""
+    mask = targets.get(mask_key, preds.get(mask_key, None))
+    if mask is None or normalize_mask:
+        return 1.0 - ssim_image(preds[src_key], targets[tgt_key], None if mask is None else mask.float())
+    return 1.0 - ssim_image(mask * preds[src_key], mask * targets[tgt_key])

@@ -296,6 +296,34 @@ int gol_tail_conv_fwd(int B, int Ci, int h, int w, int CH, int E, int nd, int wB
 int gol_tail_conv_bwd(int B, int Ci, int h, int w, int CH, int E, int nd, int wB, const float* x, const float* weff_t,
                       const float* lc, const float* g_out, float* g_x, float* g_weff, float* g_bias, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * SSIM image loss ("next" row).  Replaces `ssim` / `_ssim`
+ * (ca_code/utils/ssim.py:25-65) as used by rgb_ssim (ca_code/loss/__init__.py:478-494): 11x11 Gaussian
+ * window (sigma 1.5, zero padding), C1 = 0.01^2, C2 = 0.03^2, masked mean.
+ *   img1 (target), img2 (prediction: the differentiated argument) [B,C,H,W]; mask NULL, [B,1,H,W] or [B,C,H,W]
+ * fwd writes partial[B*C*gol_ssim_blocks(H,W)] = per-workgroup sums of ssim_map*mask (caller: sum / denominator)
+ *     and, when dmap != NULL, dmap[3,B,C,H,W] = mask * d ssim / d (mu2, E[img2^2], E[img1*img2]) for the backward;
+ * bwd writes g_img2 = g_scale[0] * d(sum of ssim_map*mask)/d img2   (g_scale: device scalar, e.g. -g_loss/denominator).
+ * ---------------------------------------------------------------------------------------- */
+int gol_ssim_blocks(int H, int W);
+int gol_ssim_fwd(int B, int C, int H, int W, int mask_c, const float* img1, const float* img2, const float* mask,
+                 float* partial, float* dmap, void* stream);
+int gol_ssim_bwd(int B, int C, int H, int W, const float* img1, const float* img2, const float* dmap,
+                 const float* g_scale, float* g_img2, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * URHand shadow-map lookup with 3x3 PCF.  Replaces the per-texel part of get_shadow_map
+ * (ca_code/utils/shadowmap.py:30-96; projection ca_code/utils/geom.py:599-631): forward only (the reference
+ * calls it under no_grad, ca_code/models/urhand.py:404,492).
+ *   depth [B*L,dh,dw] light-camera depth images (0 = empty; from the mesh rasteriser), Rt [B*L,3,4] = [R | t] with
+ *   p_cam = R p + t, intrinsics fx,fy,cx,cy (the reference uses 1000,1000,dw/2,dh/2), postex [B,3,H,W] texel
+ *   positions, nml [B,3,H,W] or NULL (no back-face term) -> out [B*L,1,H,W] = in_shadow, or exp(-in_shadow/exp_scale)
+ *   when exp_scale > 0 (urhand.py:416 uses 8).
+ * ---------------------------------------------------------------------------------------- */
+int gol_shadow_pcf(int B, int L, int H, int W, int dh, int dw, const float* depth, const float* Rt, float fx, float fy,
+                   float cx, float cy, const float* postex, const float* nml, float exp_scale, float* out,
+                   void* stream);
+
 #ifdef __cplusplus
 }
 #endif

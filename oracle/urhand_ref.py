@@ -69,3 +69,46 @@ def ggx_features(p_uv, nml, cam_pos, light_pos, light_intensity, roughness, tex_
     cosine = (Lv * nml[:, None]).sum(2).clamp(min=0.0)
     rgb = (4 * math.pi * brdf * I * cosine[:, :, None]).mean(1)
     return feat_p[:, :, 0], rgb
+
+
+def shadow_pcf(depth, Rt, postex, nml=None, focal=1000.0):
+    """Restatement of the per-texel part of get_shadow_map (/root/reference/ca_code/utils/shadowmap.py:30-96) for a
+    given depth image [B,h,w] (the reference obtains it from its drtk render layer): Rt [B,3,4], postex [B,3,H,W],
+    nml [B,3,H,W] or None -> in_shadow [B,1,H,W].  Pinned by tests/golden/shadow_golden.npz (reference-generated)."""
+    import math
+
+    import torch.nn.functional as F
+
+    B, _, H, W = postex.shape
+    dh, dw = depth.shape[-2:]
+    K = torch.eye(3)[None].repeat(B, 1, 1)
+    K[:, 0, 0] = K[:, 1, 1] = focal
+    K[:, 0, 2], K[:, 1, 2] = dw / 2, dh / 2
+    p = postex.permute(0, 2, 3, 1).reshape(B, -1, 3)
+    p_cam = p @ Rt[:, :3, :3].mT + Rt[:, :3, 3][:, None]                      # geom.py:619
+    p_pix = p_cam @ K.mT
+    z = p_pix[:, :, 2:]
+    uv = (p_pix[..., :2] / z).view(B, H, W, 2).clone()
+    d1 = z.view(B, H, W, 1).permute(0, 3, 1, 2)
+    uv[..., 0] = (uv[..., 0] - dw / 2.0 - 0.5) / (dw / 2.0)                   # shadowmap.py:55-56
+    uv[..., 1] = (uv[..., 1] - dh / 2.0 - 0.5) / (dh / 2.0)
+    dimg = depth[:, None]
+    sigma = 0.3 * ((3 - 1) * 0.5 - 1) + 0.8
+    vsum, ssum = 0.0, 0.0
+    for x in range(3):
+        for y in range(3):
+            wgt = math.exp(-((x - 1) ** 2 + (y - 1) ** 2) / (2.0 * sigma ** 2))
+            g = uv.clone()
+            g[..., 0] += 2.0 / dw * (x - 1)
+            g[..., 1] += 2.0 / dh * (y - 1)
+            d = F.grid_sample(dimg, g, mode="nearest", align_corners=False)
+            w = F.grid_sample((dimg > 0.0).float(), g, mode="nearest", align_corners=False)
+            valid = wgt * (w > 1e-4).float()
+            vsum = vsum + valid
+            ssum = ssum + valid * (d1 - d / (w + 1e-8)).clamp(min=0)
+    out = ssum / (vsum + 1e-6)
+    if nml is not None:
+        vdir = F.normalize(Rt[:, :, -1][..., None, None] - postex, dim=1)
+        bc = torch.sigmoid(10 * (nml * vdir).sum(1, keepdim=True))
+        out = bc * out + (1.0 - bc) * 1e3
+    return out

@@ -37,3 +37,20 @@ def test_urhand_oracle_reproduces_reference(tag):
     ((f * G[f"{tag}/ggx/w_feat"].reshape(f.shape)).sum() + (rgb * G[f"{tag}/ggx/w_rgb"]).sum()).backward()
     for k, n in (("p_uv", "g_p_uv"), ("nml", "g_nml"), ("roughness", "g_roughness"), ("tex_mean", "g_tex")):
         assert rel_l2(leaf[k].grad, G[f"{tag}/ggx/{n}"]) < 1e-5, k
+
+
+def test_shadow_pcf_oracle_matches_reference_golden():
+    import os
+
+    import numpy as np
+    import torch
+
+    from oracle import urhand_ref
+
+    G = np.load(os.path.join(os.path.dirname(__file__), "golden", "shadow_golden.npz"))
+    for tag in ("a", "b"):
+        c = {k.split("/")[1]: torch.from_numpy(G[k]) for k in G.files if k.startswith(tag + "/")}
+        got = urhand_ref.shadow_pcf(c["depth"], c["Rt"], c["postex"], c.get("nml"))
+        # nearest-neighbour lookups: allow a handful of texels to pick the other side of a rounding tie
+        bad = ((got - c["out"]).abs() > 1e-3 * (1 + c["out"].abs())).float().mean()
+        assert float(bad) < 0.005, tag
