@@ -132,12 +132,14 @@ __global__ __launch_bounds__(256) void project_bwd_kernel(
     const float* __restrict__ compensation, const float* __restrict__ v_xy,
     const float* __restrict__ v_depth, const float* __restrict__ v_conic,
     const float* __restrict__ v_compensation, const float* __restrict__ opacities,
-    const float* __restrict__ v_opac_eff, float* __restrict__ v_mean3d, float* __restrict__ v_scale,
+    const float* __restrict__ v_opac_eff, int gs, float* __restrict__ v_mean3d, float* __restrict__ v_scale,
     float* __restrict__ v_quat, float* __restrict__ v_opacity) {
   const int b = blockIdx.y;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= N) return;
   const size_t e = (size_t)b * N + i;
+  // upstream gradients: dense arrays (gs == 0) or fields of per-Gaussian records of gs floats (rasterize_bwd)
+  const size_t e1 = gs ? e * gs : e, e2 = gs ? e * gs : 2 * e, e3 = gs ? e * gs : 3 * e;
   float vm[3] = {0, 0, 0}, vs[3] = {0, 0, 0}, vq[4] = {0, 0, 0, 0}, vo = 0.f;
   if (radii[e] > 0) {
     const float* V = viewmats + 12 * b;
@@ -149,23 +151,23 @@ __global__ __launch_bounds__(256) void project_bwd_kernel(
     const float comp = compensation[e];
     float v_comp = v_compensation ? v_compensation[e] : 0.f;
     if (opacities) {  // opac_eff = opacity * comp  (render_gsplat.py:72)
-      const float g = v_opac_eff ? v_opac_eff[e] : 0.f;
+      const float g = v_opac_eff ? v_opac_eff[e1] : 0.f;
       v_comp += g * opacities[e];
       vo = g * comp;
     }
     // project_pix vjp
     const float rw = 1.f / (tz + GOL_Z_EPS);
-    const float vpx = v_xy ? fx * v_xy[2 * e] : 0.f, vpy = v_xy ? fy * v_xy[2 * e + 1] : 0.f;
+    const float vpx = v_xy ? fx * v_xy[e2] : 0.f, vpy = v_xy ? fy * v_xy[e2 + 1] : 0.f;
     const float vv0 = vpx * rw, vv1 = vpy * rw, vv2 = -(vpx * tx + vpy * ty) * rw * rw;
 #pragma unroll
     for (int c = 0; c < 3; ++c) vm[c] = V[c] * vv0 + V[4 + c] * vv1 + V[8 + c] * vv2;
-    const float vz = v_depth ? v_depth[e] : 0.f;
+    const float vz = v_depth ? v_depth[e1] : 0.f;
     vm[0] += V[8] * vz; vm[1] += V[9] * vz; vm[2] += V[10] * vz;
 
     // conic (inverse cov2d) vjp: v_Sigma = -X G X
     const float X0 = conics[3 * e], X1 = conics[3 * e + 1], X2 = conics[3 * e + 2];
-    const float G0 = v_conic ? v_conic[3 * e] : 0.f, G1 = v_conic ? 0.5f * v_conic[3 * e + 1] : 0.f,
-                G2 = v_conic ? v_conic[3 * e + 2] : 0.f;
+    const float G0 = v_conic ? v_conic[e3] : 0.f, G1 = v_conic ? 0.5f * v_conic[e3 + 1] : 0.f,
+                G2 = v_conic ? v_conic[e3 + 2] : 0.f;
     const float a00 = X0 * G0 + X1 * G1, a01 = X0 * G1 + X1 * G2;
     const float a10 = X1 * G0 + X2 * G1, a11 = X1 * G1 + X2 * G2;
     float vc0 = -(a00 * X0 + a01 * X1);
@@ -267,9 +269,10 @@ extern "C" int gol_project_bwd(int B, int N, const float* means3d, const float* 
                                const float* cov3d, const int32_t* radii, const float* conics,
                                const float* compensation, const float* v_xy, const float* v_depth,
                                const float* v_conic, const float* v_compensation, const float* opacities,
-                               const float* v_opac_eff, float* v_mean3d, float* v_scale, float* v_quat,
-                               float* v_opacity, void* stream) {
+                               const float* v_opac_eff, int grad_stride, float* v_mean3d, float* v_scale,
+                               float* v_quat, float* v_opacity, void* stream) {
   GOL_REQUIRE(B >= 0 && N >= 0, "negative size");
+  GOL_REQUIRE(grad_stride >= 0, "negative grad_stride");
   if (B == 0 || N == 0) return GOL_OK;
   GOL_REQUIRE(means3d && scales && quats && viewmats && intrins && cov3d && radii && conics && compensation,
               "null input");
@@ -279,7 +282,7 @@ extern "C" int gol_project_bwd(int B, int N, const float* means3d, const float* 
   dim3 grid(gol_cdiv(N, 256), B);
   project_bwd_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(
       N, means3d, scales, glob_scale, quats, viewmats, intrins, cov3d, radii, conics, compensation, v_xy,
-      v_depth, v_conic, v_compensation, opacities, v_opac_eff, v_mean3d, v_scale, v_quat, v_opacity);
+      v_depth, v_conic, v_compensation, opacities, v_opac_eff, grad_stride, v_mean3d, v_scale, v_quat, v_opacity);
   GOL_CHECK_LAUNCH();
   return GOL_OK;
 }

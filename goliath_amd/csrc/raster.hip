@@ -162,8 +162,34 @@ __global__ __launch_bounds__(256) void raster_fwd_kernel(
 constexpr int kBatchB = 64;   // backward batch (smaller: per-wave gradient slots live in LDS)
 constexpr int kAcc = 12;      // r g b v_opacity | Sx Sy Sxx Sxy | Syy extra - -
 
-template <bool EXTRA>
-__global__ __launch_bounds__(256) void raster_bwd_kernel(
+// ---- backward, two pixels per lane -------------------------------------------------------------
+// 128-thread workgroup per tile: wave w owns the 16x8 half (rows 8w..8w+7), lane = (x = lane&15, row pair
+// lane>>4) owns the two vertically adjacent pixels of a column.  The per-pixel recurrences of the two pixels are
+// independent, so the body is written on 2-vectors and maps onto packed fp32 VALU ops (v_pk_fma/mul/add_f32:
+// two pixels per instruction), and the cross-lane reduction of the 10 per-Gaussian sums -- the largest single cost
+// of the one-pixel-per-lane kernel -- is paid once per 128 pixels instead of once per 64.
+typedef float f2 __attribute__((ext_vector_type(2)));
+typedef int i2 __attribute__((ext_vector_type(2)));
+static_assert(kBatchB == 64, "raster_bwd2_kernel ballots one 64-entry chunk per batch");
+
+__device__ __forceinline__ int half_mask(float gx, float gy, float ca, float cb, float cc, float op, float tile_x0,
+                                         float tile_y0) {
+  const float tau = gol_alpha_tau(op);
+  if (!(tau >= 0.f)) return 0;
+  const float det = ca * cc - cb * cb;
+  if (!(det > 0.f) || !(ca > 0.f) || !(cc > 0.f)) return 0x3;
+  int m = 0;
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const float x0 = tile_x0 + 0.5f, y0 = tile_y0 + (float)(q * 8) + 0.5f;
+    const float ms = gol_min_sigma_rect(gx, gy, ca, cb, cc, x0, x0 + 15.f, y0, y0 + 7.f);
+    m |= (ms <= tau) ? (1 << q) : 0;
+  }
+  return m;
+}
+
+template <bool EXTRA, bool PACKED>
+__global__ __launch_bounds__(128) void raster_bwd_kernel(
     int N, int img_h, int img_w, int planar, int tiles_x, int tiles_y, const int2* __restrict__ tile_bins,
     const int32_t* __restrict__ sorted_ids, int64_t capacity, const float* __restrict__ xys,
     const float* __restrict__ conics, const float* __restrict__ colors, const float* __restrict__ extra,
@@ -177,9 +203,9 @@ __global__ __launch_bounds__(256) void raster_bwd_kernel(
   __shared__ float2 s_c[kBatchB];
   __shared__ int32_t s_mask[kBatchB];
   __shared__ int32_t s_id[kBatchB];
-  __shared__ __attribute__((aligned(16))) float s_acc[4][kBatchB][kAcc];  // per-wave partial sums (no atomics)
-  __shared__ int32_t s_touched[4][kBatchB];
-  __shared__ int32_t s_wmax[4];
+  __shared__ __attribute__((aligned(16))) float s_acc[2][kBatchB][kAcc];
+  __shared__ int32_t s_touched[2][kBatchB];
+  __shared__ int32_t s_wmax[2];
   const int T = tiles_x * tiles_y;
   const TileCoord tc = tile_of_block(blockIdx.x, T, tiles_x);
   if (!tc.ok) return;
@@ -187,44 +213,50 @@ __global__ __launch_bounds__(256) void raster_bwd_kernel(
   const int2 range = tile_bins[(size_t)view * T + tc.tile];
   if (range.y <= range.x) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int lx = ((wave & 1) << 3) + (lane & 7), ly = ((wave >> 1) << 3) + (lane >> 3);
-  const int j = tc.tx * 16 + lx, i = tc.ty * 16 + ly;
-  const bool inside = (i < img_h) && (j < img_w);
-  const float px = (float)j + 0.5f, py = (float)i + 0.5f;
-  const size_t p = inside ? ((size_t)view * img_h + i) * img_w + j : 0;
+  const int j = tc.tx * 16 + (lane & 15), i0 = tc.ty * 16 + wave * 8 + (lane >> 4) * 2;
+  const float px = (float)j + 0.5f;
+  const f2 py = {(float)i0 + 0.5f, (float)i0 + 1.5f};
+  const bool in0 = (i0 < img_h) && (j < img_w), in1 = (i0 + 1 < img_h) && (j < img_w);
+  const size_t hw = (size_t)img_h * img_w;
+  const size_t p0 = in0 ? ((size_t)view * img_h + i0) * img_w + j : 0, p1 = in1 ? p0 + img_w : p0;
   const int32_t* ids = sorted_ids + (size_t)view * capacity;
   const size_t goff = (size_t)view * N;
 
-  const float T_final = inside ? final_Ts[p] : 1.f;
-  float T_cur = T_final;
-  // pixels outside the image never contribute; bin_final = range.x - 1 makes every entry "behind" them
-  const int bin_final = inside ? final_idx[p] : (range.x - 1);
-  float vo0 = 0.f, vo1 = 0.f, vo2 = 0.f, vo3 = 0.f, voa = 0.f;
-  if (inside) {
-    const size_t hw = (size_t)img_h * img_w;
-    const size_t o0 = planar ? (size_t)view * 3 * hw + (size_t)i * img_w + j : 3 * p;
+  const f2 T_final = {in0 ? final_Ts[p0] : 1.f, in1 ? final_Ts[p1] : 1.f};
+  f2 T_cur = T_final;
+  const i2 bin_final = {in0 ? final_idx[p0] : (range.x - 1), in1 ? final_idx[p1] : (range.x - 1)};
+  f2 vo0 = {0.f, 0.f}, vo1 = vo0, vo2 = vo0, vo3 = vo0, voa = vo0;
+  {
     const size_t os = planar ? hw : 1;
-    vo0 = v_out_img[o0]; vo1 = v_out_img[o0 + os]; vo2 = v_out_img[o0 + 2 * os];
-    if (EXTRA && v_out_extra) vo3 = v_out_extra[p];
-    if (v_out_alpha) voa = v_out_alpha[p];
+    if (in0) {
+      const size_t o = planar ? (size_t)view * 3 * hw + (size_t)i0 * img_w + j : 3 * p0;
+      vo0.x = v_out_img[o]; vo1.x = v_out_img[o + os]; vo2.x = v_out_img[o + 2 * os];
+      if (EXTRA && v_out_extra) vo3.x = v_out_extra[p0];
+      if (v_out_alpha) voa.x = v_out_alpha[p0];
+    }
+    if (in1) {
+      const size_t o = planar ? (size_t)view * 3 * hw + (size_t)(i0 + 1) * img_w + j : 3 * p1;
+      vo0.y = v_out_img[o]; vo1.y = v_out_img[o + os]; vo2.y = v_out_img[o + 2 * os];
+      if (EXTRA && v_out_extra) vo3.y = v_out_extra[p1];
+      if (v_out_alpha) voa.y = v_out_alpha[p1];
+    }
   }
-  const float bgdot = background[0] * vo0 + background[1] * vo1 + background[2] * vo2;
-  float buf0 = 0.f, buf1 = 0.f, buf2 = 0.f, buf3 = 0.f;
+  const f2 tail = T_final * (voa - (background[0] * vo0 + background[1] * vo1 + background[2] * vo2));
+  f2 buf0 = {0.f, 0.f}, buf1 = buf0, buf2 = buf0, buf3 = buf0;
 
-  // wave / workgroup maxima of bin_final bound the part of the list that matters
-  int wmax = bin_final;
+  int wmax = max(bin_final.x, bin_final.y);
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) wmax = max(wmax, __shfl_xor(wmax, off, 64));
-  wmax = __builtin_amdgcn_readfirstlane(wmax);  // uniform by construction; tell the compiler
+  wmax = __builtin_amdgcn_readfirstlane(wmax);
   if (lane == 0) s_wmax[wave] = wmax;
   __syncthreads();
-  const int bmax = min(max(max(s_wmax[0], s_wmax[1]), max(s_wmax[2], s_wmax[3])), range.y - 1);
+  const int bmax = min(max(s_wmax[0], s_wmax[1]), range.y - 1);
   if (bmax < range.x) return;
 
   const int n_batches = (bmax - range.x + kBatchB) / kBatchB;
   for (int bb = 0; bb < n_batches; ++bb) {
-    __syncthreads();  // previous batch fully consumed
-    const int batch_end = bmax - bb * kBatchB;           // list index of slot 0 (furthest back)
+    __syncthreads();
+    const int batch_end = bmax - bb * kBatchB;
     const int batch_size = min(kBatchB, batch_end + 1 - range.x);
     if (tid < kBatchB) {
       if (tid < batch_size) {
@@ -238,70 +270,97 @@ __global__ __launch_bounds__(256) void raster_bwd_kernel(
         s_a[tid] = make_float4(xy.x, xy.y, ca, cb);
         s_b[tid] = make_float4(cc, op, r, gg);
         s_c[tid] = make_float2(bl, ex);
-        s_mask[tid] = quadrant_mask(xy.x, xy.y, ca, cb, cc, op, (float)(tc.tx * 16), (float)(tc.ty * 16));
+        s_mask[tid] = half_mask(xy.x, xy.y, ca, cb, cc, op, (float)(tc.tx * 16), (float)(tc.ty * 16));
         s_id[tid] = gid;
       } else {
         s_mask[tid] = 0;
       }
     }
-    for (int k = tid; k < 4 * kBatchB; k += 256) (&s_touched[0][0])[k] = 0;
+    (&s_touched[0][0])[tid] = 0;  // 2 * kBatchB == 128 == blockDim
     __syncthreads();
 
-    const int t0 = max(0, batch_end - wmax);  // entries behind every pixel of this wave are skipped
-    for (int chunk = t0 & ~63; chunk < batch_size; chunk += 64) {
-      unsigned long long bits = __ballot((s_mask[chunk + lane] >> wave) & 1);
-      if (chunk < t0) bits &= ~0ull << (t0 - chunk);
-      while (bits) {
-        const int t = chunk + __builtin_ctzll(bits);
-        bits &= bits - 1;
-        const float4 a4 = s_a[t];
-        const float4 b4 = s_b[t];
-        const float2 c2 = s_c[t];
-        bool valid = (batch_end - t) <= bin_final;
-        const float dx = a4.x - px, dy = a4.y - py;
-        const float sigma = 0.5f * (a4.z * dx * dx + b4.x * dy * dy) + a4.w * dx * dy;
-        const float vis = __expf(-sigma);
-        const float alpha = fminf(GOL_ALPHA_CAP_BWD, b4.y * vis);
-        valid = valid && !(sigma < 0.f || alpha < GOL_ALPHA_FLOOR);
-        if (__ballot(valid) == 0ull) continue;
-        // branch-free: lanes that do not see this Gaussian carry fac = 0 and keep their state
-        const float ra = __builtin_amdgcn_rcpf(1.f - alpha);
-        const float T_new = T_cur * ra;
-        const float fac = valid ? alpha * T_new : 0.f;
-        T_cur = valid ? T_new : T_cur;
-        float v_alpha = (b4.z * T_new - buf0 * ra) * vo0 + (b4.w * T_new - buf1 * ra) * vo1 +
-                        (c2.x * T_new - buf2 * ra) * vo2 + T_final * ra * (voa - bgdot);
-        const float g0 = fac * vo0, g1 = fac * vo1, g2 = fac * vo2;
-        float g3 = 0.f;
-        if (EXTRA) {
-          g3 = fac * vo3;
-          v_alpha += (c2.y * T_new - buf3 * ra) * vo3;
-          buf3 += c2.y * fac;
-        }
-        buf0 += b4.z * fac; buf1 += b4.w * fac; buf2 += c2.x * fac;
-        const float gop = valid ? vis * v_alpha : 0.f;
-        const float v_sigma = -b4.y * gop;
-        const float sx = v_sigma * dx, sy = v_sigma * dy;
-        const float sxx = sx * dx, sxy = sx * dy, syy = sy * dy;
-        // three 4-way swap reductions: lanes 15/31/47/63 end up holding the 4 sums of each group
-        const float r0 = gol_wave_sum4(g0, g1, g2, gop);
-        const float r1 = gol_wave_sum4(sx, sy, sxx, sxy);
-        const float r2 = gol_wave_sum4(syy, g3, 0.f, 0.f);
-        if ((lane & 15) == 15) {
-          float* a = &s_acc[wave][t][lane >> 4];
-          a[0] = r0; a[4] = r1; a[8] = r2;
-          s_touched[wave][t] = 1;
-        }
+    const int t0 = max(0, batch_end - wmax);
+    unsigned long long bits = __ballot((s_mask[lane] >> wave) & 1);  // kBatchB == 64: one chunk
+    if (t0 > 0) bits &= ~0ull << t0;
+    while (bits) {
+      const int t = __builtin_ctzll(bits);
+      bits &= bits - 1;
+      const float4 a4 = s_a[t];
+      const float4 b4 = s_b[t];
+      const float2 c2 = s_c[t];
+      const int li = batch_end - t;
+      const float dx = a4.x - px;
+      const f2 dy = a4.y - py;
+      const f2 sigma = 0.5f * (a4.z * dx * dx + b4.x * dy * dy) + (a4.w * dx) * dy;
+      f2 vis;
+      vis.x = __expf(-sigma.x); vis.y = __expf(-sigma.y);
+      f2 alpha = b4.y * vis;
+      alpha.x = fminf(GOL_ALPHA_CAP_BWD, alpha.x); alpha.y = fminf(GOL_ALPHA_CAP_BWD, alpha.y);
+      const bool v0 = (li <= bin_final.x) && !(sigma.x < 0.f || alpha.x < GOL_ALPHA_FLOOR);
+      const bool v1 = (li <= bin_final.y) && !(sigma.y < 0.f || alpha.y < GOL_ALPHA_FLOOR);
+      if (__ballot(v0 || v1) == 0ull) continue;
+      const f2 one_m = 1.f - alpha;
+      f2 ra;
+      ra.x = __builtin_amdgcn_rcpf(one_m.x); ra.y = __builtin_amdgcn_rcpf(one_m.y);
+      const f2 T_new = T_cur * ra;
+      f2 fac = alpha * T_new;
+      fac.x = v0 ? fac.x : 0.f; fac.y = v1 ? fac.y : 0.f;
+      T_cur.x = v0 ? T_new.x : T_cur.x; T_cur.y = v1 ? T_new.y : T_cur.y;
+      f2 v_alpha = (b4.z * T_new - buf0 * ra) * vo0 + (b4.w * T_new - buf1 * ra) * vo1 +
+                   (c2.x * T_new - buf2 * ra) * vo2 + tail * ra;
+      const f2 g0v = fac * vo0, g1v = fac * vo1, g2v = fac * vo2;
+      float g3 = 0.f;
+      if (EXTRA) {
+        const f2 g3v = fac * vo3;
+        g3 = g3v.x + g3v.y;
+        v_alpha += (c2.y * T_new - buf3 * ra) * vo3;
+        buf3 += c2.y * fac;
+      }
+      buf0 += b4.z * fac; buf1 += b4.w * fac; buf2 += c2.x * fac;
+      f2 gopv = vis * v_alpha;
+      gopv.x = v0 ? gopv.x : 0.f; gopv.y = v1 ? gopv.y : 0.f;
+      const f2 vs = -b4.y * gopv;           // d loss / d sigma per pixel
+      const f2 vsy = vs * dy;
+      const float s0 = vs.x + vs.y;         // sum_pix v_sigma
+      const float sy = vsy.x + vsy.y;       // sum v_sigma dy
+      const f2 vsyy = vsy * dy;
+      const float syy = vsyy.x + vsyy.y;
+      const float sx = s0 * dx, sxx = sx * dx, sxy = sy * dx;
+      const float r0 = gol_wave_sum4(g0v.x + g0v.y, g1v.x + g1v.y, g2v.x + g2v.y, gopv.x + gopv.y);
+      const float r1 = gol_wave_sum4(sx, sy, sxx, sxy);
+      const float r2 = gol_wave_sum4(syy, g3, 0.f, 0.f);
+      if ((lane & 15) == 15) {
+        float* a = &s_acc[wave][t][lane >> 4];
+        a[0] = r0; a[4] = r1; a[8] = r2;
+        s_touched[wave][t] = 1;
       }
     }
     __syncthreads();
-    if (tid < batch_size) {
+    if (PACKED) {
+      // gradients live in 64-byte records [r g b | opacity | x y | conic a b c | extra | pad]: 16 consecutive
+      // lanes own one Gaussian's record, so an atomic instruction touches 4 cache lines instead of 64
+      float* rec = v_colors;
+      for (int idx = tid; idx < batch_size * 16; idx += 128) {
+        const int t = idx >> 4, c = idx & 15;
+        const bool t0w = s_touched[0][t] != 0, t1w = s_touched[1][t] != 0;
+        if (!(t0w || t1w) || c > (EXTRA ? 9 : 8)) continue;
+        // component c = w1 * S[k1] + w2 * S[k2] of the wave-summed slots S
+        const float4 a4 = s_a[t];
+        const float cc = s_b[t].x;
+        const int k1 = (c == 5) ? 4 : c, k2 = 5;
+        const float w1 = (c == 4) ? a4.z : (c == 5) ? a4.w : (c == 6 || c == 8) ? 0.5f : 1.f;
+        const float w2 = (c == 4) ? a4.w : (c == 5) ? cc : 0.f;
+        const float s1 = (t0w ? s_acc[0][t][k1] : 0.f) + (t1w ? s_acc[1][t][k1] : 0.f);
+        const float s2 = (t0w ? s_acc[0][t][k2] : 0.f) + (t1w ? s_acc[1][t][k2] : 0.f);
+        atomicAdd(rec + (goff + (size_t)s_id[t]) * 16 + c, w1 * s1 + w2 * s2);
+      }
+    } else if (tid < batch_size) {
       float a[kAcc];
 #pragma unroll
       for (int k = 0; k < kAcc; ++k) a[k] = 0.f;
       bool any = false;
 #pragma unroll
-      for (int w = 0; w < 4; ++w) {
+      for (int w = 0; w < 2; ++w) {
         if (s_touched[w][tid]) {
           any = true;
           const float4* q = reinterpret_cast<const float4*>(&s_acc[w][tid][0]);
@@ -365,7 +424,7 @@ extern "C" int gol_rasterize_bwd(int B, int N, int img_h, int img_w, int block, 
                                  const float* opacities, const float* background, const float* final_Ts,
                                  const int32_t* final_idx, const float* v_out_img, const float* v_out_extra,
                                  const float* v_out_alpha, float* v_xy, float* v_conic, float* v_colors,
-                                 float* v_extra, float* v_opacity, void* stream) {
+                                 float* v_extra, float* v_opacity, int grad_stride, void* stream) {
   GOL_REQUIRE(B >= 0 && N >= 0, "negative size");
   GOL_REQUIRE(block == 16, "only block_width == 16 is implemented (the reference's value, render_gsplat.py:28)");
   GOL_REQUIRE(img_h > 0 && img_w > 0, "empty image");
@@ -375,20 +434,27 @@ extern "C" int gol_rasterize_bwd(int B, int N, int img_h, int img_w, int block, 
   GOL_REQUIRE(xys && conics && colors && opacities, "null Gaussian attribute");
   GOL_REQUIRE(v_xy && v_conic && v_colors && v_opacity, "null gradient output");
   GOL_REQUIRE(!(v_out_extra || v_extra) || extra, "extra-channel gradients need extra");
-  const int tiles_x = (img_w + 15) / 16, tiles_y = (img_h + 15) / 16, T = tiles_x * tiles_y;
+  GOL_REQUIRE(grad_stride == 0 || grad_stride == GOL_GRAD_RECORD, "grad_stride must be 0 (dense arrays) or 16 (records)");
+  const bool packed = grad_stride == GOL_GRAD_RECORD;
+  if (packed)
+    GOL_REQUIRE(v_opacity == v_colors + 3 && v_xy == v_colors + 4 && v_conic == v_colors + 6 &&
+                    (!v_extra || v_extra == v_colors + 9),
+                "record layout is [rgb | opacity | xy | conic | extra | pad] (GOL_GRAD_RECORD floats)");
+  const int tiles_x = (img_w + 15) / 16, tiles_y = (img_h + 15) / 16;
   dim3 grid(8 * ((tiles_y + 7) / 8) * tiles_x, B);
   const int2* bins = reinterpret_cast<const int2*>(tile_bins);
   hipStream_t s = (hipStream_t)stream;
-  if (extra && (v_out_extra || v_extra))
-    raster_bwd_kernel<true><<<grid, 256, 0, s>>>(N, img_h, img_w, planar, tiles_x, tiles_y, bins, sorted_ids, capacity, xys,
-                                                  conics, colors, extra, opacities, background, final_Ts, final_idx,
-                                                  v_out_img, v_out_extra, v_out_alpha, v_xy, v_conic, v_colors,
-                                                  v_extra, v_opacity);
-  else
-    raster_bwd_kernel<false><<<grid, 256, 0, s>>>(N, img_h, img_w, planar, tiles_x, tiles_y, bins, sorted_ids, capacity, xys,
-                                                   conics, colors, nullptr, opacities, background, final_Ts,
-                                                   final_idx, v_out_img, nullptr, v_out_alpha, v_xy, v_conic,
-                                                   v_colors, nullptr, v_opacity);
+  const bool ex = extra && (v_out_extra || v_extra);
+#define GOL_LAUNCH_BWD(EX, PK)                                                                                      \
+  raster_bwd_kernel<EX, PK><<<grid, 128, 0, s>>>(N, img_h, img_w, planar, tiles_x, tiles_y, bins, sorted_ids, capacity, \
+                                                 xys, conics, colors, EX ? extra : nullptr, opacities, background,    \
+                                                 final_Ts, final_idx, v_out_img, EX ? v_out_extra : nullptr,          \
+                                                 v_out_alpha, v_xy, v_conic, v_colors, EX ? v_extra : nullptr, v_opacity)
+  if (ex && packed) GOL_LAUNCH_BWD(true, true);
+  else if (ex) GOL_LAUNCH_BWD(true, false);
+  else if (packed) GOL_LAUNCH_BWD(false, true);
+  else GOL_LAUNCH_BWD(false, false);
+#undef GOL_LAUNCH_BWD
   GOL_CHECK_LAUNCH();
   return GOL_OK;
 }

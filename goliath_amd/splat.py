@@ -12,6 +12,7 @@ Three layers, all backed by libgoliath_hip.so (no CPU fallback):
 Host/device contract: Gaussian attributes are fp32 [B,N,.] tensors resident in HBM; intrinsics and
 view matrices are read by the kernels from device memory.
 """
+import ctypes
 import os
 
 import torch
@@ -20,6 +21,7 @@ from . import _lib
 from ._lib import c_float, c_i64, c_int, fptr, iptr, ptr, stream_ptr
 
 BLOCK = 16  # tile width; the reference's only value (render_gsplat.py:28)
+GRAD_RECORD = 16  # include/goliath_hip.h: GOL_GRAD_RECORD
 
 
 def _tiles(img_h, img_w, block=BLOCK):
@@ -171,7 +173,8 @@ class _ProjectGaussians(torch.autograd.Function):
             _lib.call("gol_project_bwd", c_int(1), c_int(N), fptr(means3d), fptr(scales), c_float(ctx.glob_scale),
                       fptr(quats), fptr(vm), fptr(intr), fptr(cov3d), iptr(radii), fptr(conics), fptr(comp),
                       fptr(c(v_xys)), fptr(c(v_depths)), fptr(c(v_conics)), fptr(c(v_compensation)),
-                      fptr(None), fptr(None), fptr(v_mean), fptr(v_scale), fptr(v_quat), fptr(None), stream_ptr())
+                      fptr(None), fptr(None), c_int(0), fptr(v_mean), fptr(v_scale), fptr(v_quat), fptr(None),
+                      stream_ptr())
         return (v_mean, v_scale, None, v_quat) + (None,) * 9
 
 
@@ -243,7 +246,7 @@ class _RasterizeGaussians(torch.autograd.Function):
                           iptr(ws.tile_bins), iptr(ws.sorted_ids), c_i64(ws.capacity), fptr(xys), fptr(conics),
                           fptr(colors), fptr(None), fptr(opacity), fptr(background), fptr(final_Ts),
                           iptr(final_idx), fptr(_f32c(v_out_img)), fptr(None), fptr(va), fptr(v_xy),
-                          fptr(v_conic), fptr(v_colors), fptr(None), fptr(v_opacity), stream_ptr())
+                          fptr(v_conic), fptr(v_colors), fptr(None), fptr(v_opacity), c_int(0), stream_ptr())
         return (v_xy, None, None, v_conic, None, v_colors, v_opacity[:, None]) + (None,) * 5
 
 
@@ -322,11 +325,10 @@ class _RenderViews(torch.autograd.Function):
         if v_img is None:
             v_img = torch.zeros(B, 3, img_h, img_w, device=dev)
         use_depth = with_depth and v_depth is not None
-        v_xy = torch.zeros(B, N, 2, device=dev)
-        v_conic = torch.zeros(B, N, 3, device=dev)
-        v_colors = torch.zeros(B, N, 3, device=dev)
-        v_opac_eff = torch.zeros(B, N, device=dev)
-        v_depths = torch.zeros(B, N, device=dev) if use_depth else None
+        # one zeroed buffer of 64-byte gradient records per Gaussian (include/goliath_hip.h: GOL_GRAD_RECORD):
+        # a Gaussian's float atomics hit one cache line and are issued by 16 adjacent lanes
+        rec = torch.zeros(B, N, GRAD_RECORD, device=dev)
+        field = lambda k: ctypes.c_void_p(rec.data_ptr() + 4 * k)
         v_mean = torch.empty_like(means)
         v_scale = torch.empty_like(scales)
         v_quat = torch.empty_like(quats)
@@ -337,13 +339,14 @@ class _RenderViews(torch.autograd.Function):
                       fptr(colors), fptr(depths if use_depth else None), fptr(opac_eff), fptr(background),
                       fptr(final_Ts), iptr(final_idx), fptr(_f32c(v_img)),
                       fptr(_f32c(v_depth) if use_depth else None),
-                      fptr(None if v_alpha is None else _f32c(v_alpha)), fptr(v_xy), fptr(v_conic),
-                      fptr(v_colors), fptr(v_depths), fptr(v_opac_eff), stream_ptr())
+                      fptr(None if v_alpha is None else _f32c(v_alpha)), field(4), field(6), field(0),
+                      field(9) if use_depth else fptr(None), field(3), c_int(GRAD_RECORD), stream_ptr())
             _lib.call("gol_project_bwd", c_int(B), c_int(N), fptr(means), fptr(scales), c_float(glob_scale),
                       fptr(quats), fptr(viewmats), fptr(intrins), fptr(cov3d), iptr(radii), fptr(conics),
-                      fptr(comp), fptr(v_xy), fptr(v_depths), fptr(v_conic), fptr(None), fptr(opacity),
-                      fptr(v_opac_eff), fptr(v_mean), fptr(v_scale), fptr(v_quat), fptr(v_opacity), stream_ptr())
-        return (v_mean, v_scale, v_quat, v_opacity, v_colors) + (None,) * 9
+                      fptr(comp), field(4), field(9) if use_depth else fptr(None), field(6), fptr(None), fptr(opacity),
+                      field(3), c_int(GRAD_RECORD), fptr(v_mean), fptr(v_scale), fptr(v_quat), fptr(v_opacity),
+                      stream_ptr())
+        return (v_mean, v_scale, v_quat, v_opacity, rec[..., :3]) + (None,) * 9
 
 
 def render_views(means, scales, quats, opacity, colors, viewmats, intrins, img_h, img_w,

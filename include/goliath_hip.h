@@ -72,13 +72,16 @@ int gol_project_fwd(int B, int N, const float* means3d, const float* scales, flo
                     float* depths, int32_t* radii, float* conics, float* compensation,
                     int32_t* num_tiles_hit, const float* opacities, float* opac_eff, void* stream);
 /* v_* inputs may be NULL (treated as zero).  If opacities != NULL the op also differentiates
- * opac_eff = opacity*compensation: v_opac_eff[B,N] in, v_opacity[B,N] out. */
+ * opac_eff = opacity*compensation: v_opac_eff[B,N] in, v_opacity[B,N] out.
+ * grad_stride = 0: v_xy[B,N,2], v_depth[B,N], v_conic[B,N,3], v_opac_eff[B,N] are dense arrays;
+ * grad_stride = s > 0: they are fields of per-Gaussian records of s floats (element e at pointer + e*s), e.g. the
+ * GOL_GRAD_RECORD-float records gol_rasterize_bwd accumulates into. */
 int gol_project_bwd(int B, int N, const float* means3d, const float* scales, float glob_scale,
                     const float* quats, const float* viewmats, const float* intrins,
                     const float* cov3d, const int32_t* radii, const float* conics,
                     const float* compensation, const float* v_xy, const float* v_depth,
                     const float* v_conic, const float* v_compensation, const float* opacities,
-                    const float* v_opac_eff, float* v_mean3d, float* v_scale, float* v_quat,
+                    const float* v_opac_eff, int grad_stride, float* v_mean3d, float* v_scale, float* v_quat,
                     float* v_opacity, void* stream);
 
 /* ------------------------------------------------------------------------------------------
@@ -113,7 +116,13 @@ int gol_bin_sort(int B, int N, const float* xys, const float* depths, const int3
  *   (index into the view's sorted_ids segment of the last contributing Gaussian, 0 if none).
  * bwd ACCUMULATES into v_xy[B,N,2] v_conic[B,N,3] v_colors[B,N,3] v_opacity[B,N]
  * (and v_extra[B,N]) which the caller zeroes; v_out_alpha / v_out_extra may be NULL.
+ * grad_stride = 0: the five gradient outputs are dense arrays (gsplat's layout);
+ * grad_stride = GOL_GRAD_RECORD: they are fields of ONE zeroed buffer rec[B,N,GOL_GRAD_RECORD] of 64-byte records
+ *   [rgb 0-2 | opacity 3 | xy 4-5 | conic 6-8 | extra 9 | pad], i.e. v_colors = rec, v_opacity = rec+3, v_xy = rec+4,
+ *   v_conic = rec+6, v_extra = rec+9 (checked): the float atomics of a Gaussian then hit one cache line and 16
+ *   consecutive lanes issue them together -- the memory-side atomic units see 1/10 of the requests.
  * ---------------------------------------------------------------------------------------- */
+#define GOL_GRAD_RECORD 16
 int gol_rasterize_fwd(int B, int N, int img_h, int img_w, int block, int planar, const int32_t* tile_bins,
                       const int32_t* sorted_ids, int64_t capacity, const float* xys,
                       const float* conics, const float* colors, const float* extra,
@@ -125,7 +134,7 @@ int gol_rasterize_bwd(int B, int N, int img_h, int img_w, int block, int planar,
                       const float* opacities, const float* background, const float* final_Ts,
                       const int32_t* final_idx, const float* v_out_img, const float* v_out_extra,
                       const float* v_out_alpha, float* v_xy, float* v_conic, float* v_colors,
-                      float* v_extra, float* v_opacity, void* stream);
+                      float* v_extra, float* v_opacity, int grad_stride, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Fused RGCA shading tail.  Replaces the chain of ATen kernels in PrimDecoder.forward after the
