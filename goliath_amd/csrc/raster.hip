@@ -3,22 +3,23 @@
 // Replaces gsplat 0.1.11 rasterize_forward / rasterize_backward_kernel (3-channel specialisation;
 // not in the reference tree; call sites /root/reference/ca_code/utils/render_gsplat.py:65-78 and
 // :91-104; semantics SURVEY.md A.3 / A.4).  CDNA4 design:
-//   * one 256-thread workgroup per 16x16 tile = 4 wave64s, each wave owns an 8x8 pixel quadrant
-//     (compact footprint -> coherent early-out and coherent culling);
-//   * the tile's sorted list is staged through LDS in batches of 256 Gaussians as three float4
-//     records; the per-Gaussian reads in the pixel loop are wave-uniform ds_read_b128 broadcasts;
-//   * at staging time every Gaussian gets a 4-bit quadrant mask from the bounding box of its
-//     alpha >= 1/255 ellipse, so a wave skips (scalar branch) Gaussians that cannot touch its
-//     quadrant -- gsplat's 3-sigma tile bbox is far looser than the 1/255 cut;
+//   * one 128-thread workgroup per 16x16 tile = 2 wave64s, each wave owns a 16x8 half and each lane two
+//     vertically adjacent pixels: the per-pixel recurrences run on 2-vectors, i.e. packed fp32 VALU ops
+//     (v_pk_fma/mul/add_f32), and the cross-lane gradient reduction of the backward is paid once per 128 pixels;
+//   * the tile's sorted list is staged through LDS in batches as three records per Gaussian; the per-Gaussian
+//     reads in the pixel loop are wave-uniform ds_read_b128 broadcasts;
+//   * at staging time every Gaussian gets a 2-bit half mask from the exact ellipse-vs-rectangle test of its
+//     alpha >= 1/255 region, so a wave skips (scalar loop over a 64-bit ballot) Gaussians that cannot touch its
+//     half -- gsplat's 3-sigma tile bbox is far looser than the 1/255 cut;
 //   * colour and the optional 4th "extra" channel (depth) are composited in ONE pass instead of
 //     the reference's two rasterize calls (render_gsplat.py:65-104);
 //   * backward: per-Gaussian gradients are reduced over the 64 lanes four-at-a-time with
-//     v_permlane32_swap / v_permlane16_swap + DPP row adds (10 instructions per 4 sums, no LDS, no
-//     atomics), parked in per-wave LDS slots, merged across the 4 waves once per batch and leave
-//     the workgroup as ONE global atomic per Gaussian per tile per component (gsplat: one per
-//     32-lane warp => 8x more).
-//   * tile -> workgroup mapping is XCD-chunked (blockIdx % 8 selects an eighth of the image) so a
-//     die's L2 sees a spatially compact slice of the Gaussian attribute arrays.
+//     v_permlane32_swap / v_permlane16_swap + DPP row adds (no LDS, no atomics), parked in per-wave LDS
+//     slots, merged across the waves once per batch and leave the workgroup as one float atomic per Gaussian per
+//     tile per component (gsplat: one per 32-lane warp => 8x more); with 64-byte gradient records
+//     (GOL_GRAD_RECORD) the 10 atomics of a Gaussian share a cache line and are issued by 16 adjacent lanes --
+//     the memory-side atomic units, which cost 25 % of the kernel with dense [N,k] arrays, drop out of the profile;
+//   * tile -> workgroup mapping interleaves tile rows over the 8 XCDs (tile_of_block).
 #include "gol_common.h"
 
 namespace {
@@ -44,27 +45,33 @@ __device__ __forceinline__ TileCoord tile_of_block(int bid, int T, int tiles_x) 
   return tc;
 }
 
-// 4-bit mask of the 8x8 quadrants (bit q = qy*2+qx) that the alpha >= 1/255 region of a Gaussian
-// can reach: exact ellipse-vs-rectangle test (minimum of sigma over the quadrant's pixel centres
-// against ln(255*opacity)), conservative only by a rounding margin; degenerate conics -> all.
-__device__ __forceinline__ int quadrant_mask(float gx, float gy, float ca, float cb, float cc, float op,
-                                             float tile_x0, float tile_y0) {
+typedef float f2 __attribute__((ext_vector_type(2)));
+typedef int i2 __attribute__((ext_vector_type(2)));
+
+// 2-bit mask of the 16x8 halves (bit h = rows 8h..8h+7) that the alpha >= 1/255 region of a Gaussian can reach:
+// exact ellipse-vs-rectangle test (minimum of sigma over the half's pixel centres against ln(255*opacity)),
+// conservative only by a rounding margin; degenerate conics -> both.
+__device__ __forceinline__ int half_mask(float gx, float gy, float ca, float cb, float cc, float op, float tile_x0,
+                                         float tile_y0) {
   const float tau = gol_alpha_tau(op);
   if (!(tau >= 0.f)) return 0;  // alpha < 1/255 everywhere (also NaN opacity: skipped by gsplat too)
   const float det = ca * cc - cb * cb;
-  if (!(det > 0.f) || !(ca > 0.f) || !(cc > 0.f)) return 0xf;
+  if (!(det > 0.f) || !(ca > 0.f) || !(cc > 0.f)) return 0x3;
   int m = 0;
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const float x0 = tile_x0 + (float)((q & 1) * 8) + 0.5f, y0 = tile_y0 + (float)((q >> 1) * 8) + 0.5f;
-    const float ms = gol_min_sigma_rect(gx, gy, ca, cb, cc, x0, x0 + 7.f, y0, y0 + 7.f);
+  for (int q = 0; q < 2; ++q) {
+    const float x0 = tile_x0 + 0.5f, y0 = tile_y0 + (float)(q * 8) + 0.5f;
+    const float ms = gol_min_sigma_rect(gx, gy, ca, cb, cc, x0, x0 + 15.f, y0, y0 + 7.f);
     m |= (ms <= tau) ? (1 << q) : 0;
   }
   return m;
 }
 
+// Forward.  128-thread workgroup per 16x16 tile: wave w owns the 16x8 half (rows 8w..8w+7) and every lane two
+// vertically adjacent pixels, so the per-pixel recurrence runs on 2-vectors = packed fp32 VALU ops
+// (v_pk_fma/mul/add_f32), half the instructions per pixel of a one-pixel-per-lane loop.
 template <bool EXTRA>
-__global__ __launch_bounds__(256) void raster_fwd_kernel(
+__global__ __launch_bounds__(128) void raster_fwd_kernel(
     int N, int img_h, int img_w, int planar, int tiles_x, int tiles_y, const int2* __restrict__ tile_bins,
     const int32_t* __restrict__ sorted_ids, int64_t capacity, const float* __restrict__ xys,
     const float* __restrict__ conics, const float* __restrict__ colors, const float* __restrict__ extra,
@@ -73,89 +80,105 @@ __global__ __launch_bounds__(256) void raster_fwd_kernel(
   __shared__ float4 s_a[kBatch];  // x, y, conic.a, conic.b
   __shared__ float4 s_b[kBatch];  // conic.c, opacity, r, g
   __shared__ float2 s_c[kBatch];  // b, extra
-  __shared__ int32_t s_mask[kBatch];  // quadrant mask
+  __shared__ int32_t s_mask[kBatch];  // half mask
   const int T = tiles_x * tiles_y;
   const TileCoord tc = tile_of_block(blockIdx.x, T, tiles_x);
   if (!tc.ok) return;
   const int view = blockIdx.y;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int lx = ((wave & 1) << 3) + (lane & 7), ly = ((wave >> 1) << 3) + (lane >> 3);
-  const int j = tc.tx * 16 + lx, i = tc.ty * 16 + ly;
-  const bool inside = (i < img_h) && (j < img_w);
-  const float px = (float)j + 0.5f, py = (float)i + 0.5f;
+  const int j = tc.tx * 16 + (lane & 15), i0 = tc.ty * 16 + wave * 8 + (lane >> 4) * 2;
+  const bool in0 = (i0 < img_h) && (j < img_w), in1 = (i0 + 1 < img_h) && (j < img_w);
+  const float px = (float)j + 0.5f;
+  const f2 py = {(float)i0 + 0.5f, (float)i0 + 1.5f};
 
   const int2 range = tile_bins[(size_t)view * T + tc.tile];
   const int32_t* ids = sorted_ids + (size_t)view * capacity;
   const size_t goff = (size_t)view * N;
 
-  float T_cur = 1.f;
-  int cur_idx = 0;
-  float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
-  bool done = !inside;
+  f2 T_cur = {1.f, 1.f};
+  i2 cur_idx = {0, 0};
+  f2 acc0 = {0.f, 0.f}, acc1 = acc0, acc2 = acc0, acc3 = acc0;
+  bool done0 = !in0, done1 = !in1;
 
   const int n_batches = (range.y - range.x + kBatch - 1) / kBatch;
   for (int bb = 0; bb < n_batches; ++bb) {
-    if (__syncthreads_and(done)) break;  // also protects the LDS batch from being overwritten early
+    if (__syncthreads_and(done0 && done1)) break;  // also protects the LDS batch from being overwritten early
     const int batch_start = range.x + bb * kBatch;
-    const int idx = batch_start + tid;
-    if (idx < range.y) {
-      const size_t g = goff + (size_t)ids[idx];
-      const float2 xy = *reinterpret_cast<const float2*>(xys + 2 * g);
-      const float ca = conics[3 * g], cb = conics[3 * g + 1], cc = conics[3 * g + 2];
-      const float op = opacities[g];
-      const float r = colors[3 * g], gg = colors[3 * g + 1], bl = colors[3 * g + 2];
-      const float ex = EXTRA ? extra[g] : 0.f;
-      const int qm = quadrant_mask(xy.x, xy.y, ca, cb, cc, op, (float)(tc.tx * 16), (float)(tc.ty * 16));
-      s_a[tid] = make_float4(xy.x, xy.y, ca, cb);
-      s_b[tid] = make_float4(cc, op, r, gg);
-      s_c[tid] = make_float2(bl, ex);
-      s_mask[tid] = qm;
-    } else {
-      s_mask[tid] = 0;
+    for (int k = tid; k < kBatch; k += 128) {
+      const int idx = batch_start + k;
+      if (idx < range.y) {
+        const size_t g = goff + (size_t)ids[idx];
+        const float2 xy = *reinterpret_cast<const float2*>(xys + 2 * g);
+        const float ca = conics[3 * g], cb = conics[3 * g + 1], cc = conics[3 * g + 2];
+        const float op = opacities[g];
+        const float r = colors[3 * g], gg = colors[3 * g + 1], bl = colors[3 * g + 2];
+        const float ex = EXTRA ? extra[g] : 0.f;
+        s_a[k] = make_float4(xy.x, xy.y, ca, cb);
+        s_b[k] = make_float4(cc, op, r, gg);
+        s_c[k] = make_float2(bl, ex);
+        s_mask[k] = half_mask(xy.x, xy.y, ca, cb, cc, op, (float)(tc.tx * 16), (float)(tc.ty * 16));
+      } else {
+        s_mask[k] = 0;
+      }
     }
     __syncthreads();
     const int batch_size = min(kBatch, range.y - batch_start);
-    // Each wave walks ONLY the entries whose alpha >= 1/255 box touches its quadrant: one ballot per
+    // Each wave walks ONLY the entries whose alpha >= 1/255 region touches its half: one ballot per
     // 64 entries, then a scalar loop over the set bits (s_ff1) -- culled entries cost nothing.
     for (int chunk = 0; chunk < batch_size; chunk += 64) {
       unsigned long long bits = __ballot((s_mask[chunk + lane] >> wave) & 1);
       while (bits) {
-        if (__ballot(!done) == 0ull) { chunk = batch_size; break; }  // this wave's quadrant is finished
+        if (__ballot(!(done0 && done1)) == 0ull) { chunk = batch_size; break; }  // this wave's half is finished
         const int t = chunk + __builtin_ctzll(bits);
         bits &= bits - 1;
         const float4 a4 = s_a[t];
         const float4 b4 = s_b[t];
         const float2 c2 = s_c[t];
         // branch-free pixel update: selects instead of exec-mask regions (the loop is issue-bound)
-        const float dx = a4.x - px, dy = a4.y - py;
-        const float sigma = 0.5f * (a4.z * dx * dx + b4.x * dy * dy) + a4.w * dx * dy;
-        const float alpha = fminf(GOL_ALPHA_CAP_FWD, b4.y * __expf(-sigma));
-        const bool contrib = !done && !(sigma < 0.f || alpha < GOL_ALPHA_FLOOR);
-        const float next_T = T_cur * (1.f - alpha);
-        const bool stop = contrib && (next_T <= GOL_T_STOP);
-        const bool take = contrib && !stop;
-        done = done || stop;
-        const float vis = take ? alpha * T_cur : 0.f;
+        const float dx = a4.x - px;
+        const f2 dy = a4.y - py;
+        const f2 sigma = 0.5f * (a4.z * dx * dx + b4.x * dy * dy) + (a4.w * dx) * dy;
+        f2 alpha;
+        alpha.x = fminf(GOL_ALPHA_CAP_FWD, b4.y * __expf(-sigma.x));
+        alpha.y = fminf(GOL_ALPHA_CAP_FWD, b4.y * __expf(-sigma.y));
+        const bool c0 = !done0 && !(sigma.x < 0.f || alpha.x < GOL_ALPHA_FLOOR);
+        const bool c1 = !done1 && !(sigma.y < 0.f || alpha.y < GOL_ALPHA_FLOOR);
+        const f2 next_T = T_cur * (1.f - alpha);
+        const bool stop0 = c0 && (next_T.x <= GOL_T_STOP), stop1 = c1 && (next_T.y <= GOL_T_STOP);
+        const bool take0 = c0 && !stop0, take1 = c1 && !stop1;
+        done0 = done0 || stop0; done1 = done1 || stop1;
+        f2 vis = alpha * T_cur;
+        vis.x = take0 ? vis.x : 0.f; vis.y = take1 ? vis.y : 0.f;
         acc0 += b4.z * vis; acc1 += b4.w * vis; acc2 += c2.x * vis;
         if (EXTRA) acc3 += c2.y * vis;
-        T_cur = take ? next_T : T_cur;
-        cur_idx = take ? (batch_start + t) : cur_idx;
+        T_cur.x = take0 ? next_T.x : T_cur.x; T_cur.y = take1 ? next_T.y : T_cur.y;
+        cur_idx.x = take0 ? (batch_start + t) : cur_idx.x; cur_idx.y = take1 ? (batch_start + t) : cur_idx.y;
       }
     }
   }
 
-  if (inside) {
-    const size_t p = ((size_t)view * img_h + i) * img_w + j;
-    final_Ts[p] = T_cur;
-    final_idx[p] = cur_idx;
-    // planar: [B,3,H,W] (what the model consumes, rgca.py:139); else gsplat's [B,H,W,3]
-    const size_t hw = (size_t)img_h * img_w;
-    const size_t o0 = planar ? (size_t)view * 3 * hw + (size_t)i * img_w + j : 3 * p;
-    const size_t os = planar ? hw : 1;
-    out_img[o0] = acc0 + T_cur * background[0];
-    out_img[o0 + os] = acc1 + T_cur * background[1];
-    out_img[o0 + 2 * os] = acc2 + T_cur * background[2];
-    if (EXTRA) out_extra[p] = acc3;
+  // planar: [B,3,H,W] (what the model consumes, rgca.py:139); else gsplat's [B,H,W,3]
+  const size_t hw = (size_t)img_h * img_w;
+  const size_t os = planar ? hw : 1;
+  if (in0) {
+    const size_t p = ((size_t)view * img_h + i0) * img_w + j;
+    final_Ts[p] = T_cur.x;
+    final_idx[p] = cur_idx.x;
+    const size_t o0 = planar ? (size_t)view * 3 * hw + (size_t)i0 * img_w + j : 3 * p;
+    out_img[o0] = acc0.x + T_cur.x * background[0];
+    out_img[o0 + os] = acc1.x + T_cur.x * background[1];
+    out_img[o0 + 2 * os] = acc2.x + T_cur.x * background[2];
+    if (EXTRA) out_extra[p] = acc3.x;
+  }
+  if (in1) {
+    const size_t p = ((size_t)view * img_h + i0 + 1) * img_w + j;
+    final_Ts[p] = T_cur.y;
+    final_idx[p] = cur_idx.y;
+    const size_t o0 = planar ? (size_t)view * 3 * hw + (size_t)(i0 + 1) * img_w + j : 3 * p;
+    out_img[o0] = acc0.y + T_cur.y * background[0];
+    out_img[o0 + os] = acc1.y + T_cur.y * background[1];
+    out_img[o0 + 2 * os] = acc2.y + T_cur.y * background[2];
+    if (EXTRA) out_extra[p] = acc3.y;
   }
 }
 
@@ -168,25 +191,7 @@ constexpr int kAcc = 12;      // r g b v_opacity | Sx Sy Sxx Sxy | Syy extra - -
 // independent, so the body is written on 2-vectors and maps onto packed fp32 VALU ops (v_pk_fma/mul/add_f32:
 // two pixels per instruction), and the cross-lane reduction of the 10 per-Gaussian sums -- the largest single cost
 // of the one-pixel-per-lane kernel -- is paid once per 128 pixels instead of once per 64.
-typedef float f2 __attribute__((ext_vector_type(2)));
-typedef int i2 __attribute__((ext_vector_type(2)));
-static_assert(kBatchB == 64, "raster_bwd2_kernel ballots one 64-entry chunk per batch");
-
-__device__ __forceinline__ int half_mask(float gx, float gy, float ca, float cb, float cc, float op, float tile_x0,
-                                         float tile_y0) {
-  const float tau = gol_alpha_tau(op);
-  if (!(tau >= 0.f)) return 0;
-  const float det = ca * cc - cb * cb;
-  if (!(det > 0.f) || !(ca > 0.f) || !(cc > 0.f)) return 0x3;
-  int m = 0;
-#pragma unroll
-  for (int q = 0; q < 2; ++q) {
-    const float x0 = tile_x0 + 0.5f, y0 = tile_y0 + (float)(q * 8) + 0.5f;
-    const float ms = gol_min_sigma_rect(gx, gy, ca, cb, cc, x0, x0 + 15.f, y0, y0 + 7.f);
-    m |= (ms <= tau) ? (1 << q) : 0;
-  }
-  return m;
-}
+static_assert(kBatchB == 64, "raster_bwd_kernel ballots one 64-entry chunk per batch");
 
 template <bool EXTRA, bool PACKED>
 __global__ __launch_bounds__(128) void raster_bwd_kernel(
@@ -407,11 +412,11 @@ extern "C" int gol_rasterize_fwd(int B, int N, int img_h, int img_w, int block, 
   const int2* bins = reinterpret_cast<const int2*>(tile_bins);
   hipStream_t s = (hipStream_t)stream;
   if (out_extra)
-    raster_fwd_kernel<true><<<grid, 256, 0, s>>>(N, img_h, img_w, planar, tiles_x, tiles_y, bins, sorted_ids, capacity, xys,
+    raster_fwd_kernel<true><<<grid, 128, 0, s>>>(N, img_h, img_w, planar, tiles_x, tiles_y, bins, sorted_ids, capacity, xys,
                                                   conics, colors, extra, opacities, background, out_img, out_extra,
                                                   final_Ts, final_idx);
   else
-    raster_fwd_kernel<false><<<grid, 256, 0, s>>>(N, img_h, img_w, planar, tiles_x, tiles_y, bins, sorted_ids, capacity, xys,
+    raster_fwd_kernel<false><<<grid, 128, 0, s>>>(N, img_h, img_w, planar, tiles_x, tiles_y, bins, sorted_ids, capacity, xys,
                                                    conics, colors, extra, opacities, background, out_img, out_extra,
                                                    final_Ts, final_idx);
   GOL_CHECK_LAUNCH();
