@@ -258,6 +258,116 @@ __device__ __forceinline__ void bitonic_sort(KeyPtr keys, int n, int tid, int nt
   }
 }
 
+
+// ---- register-blocked bitonic sort ---------------------------------------------------------------------------
+// 256 threads x KPT keys (thread tid owns elements tid*KPT .. tid*KPT+KPT-1, list padded with +inf keys).  A
+// compare-exchange step with partner distance j touches
+//   j < KPT            two registers of the same lane                          (no data movement at all)
+//   KPT <= j < 64 KPT  the same register of lane ^ (j / KPT)                   (cross-lane permute, no barrier)
+//   j >= 64 KPT        another wave                                            (through LDS, two barriers)
+// so of the log2(P)(log2(P)+1)/2 steps (55 for P = 1024) only 3 (P = 1024) need the workgroup barrier that the
+// plain LDS network pays on every step.  The first step of every merge is the "flip" (partner = i ^ (k-1)), which
+// keeps all later steps of the merge ascending (no direction flags); in lane/register terms the flip partner is
+// lane ^ (k/KPT - 1), register KPT-1-r.
+__device__ __forceinline__ uint64_t shfl_xor64(uint64_t v, int mask) {
+  const unsigned lo = __shfl_xor((unsigned)v, mask, 64), hi = __shfl_xor((unsigned)(v >> 32), mask, 64);
+  return ((uint64_t)hi << 32) | lo;
+}
+__device__ __forceinline__ void cex(uint64_t& a, uint64_t& b) {  // a <= b afterwards
+  const bool sw = b < a;
+  const uint64_t t = sw ? b : a;
+  b = sw ? a : b;
+  a = t;
+}
+// keep the smaller (lower == true) or the larger of (self, other): one compare, one 64-bit select
+__device__ __forceinline__ uint64_t pick(uint64_t self, uint64_t other, bool lower) {
+  return ((self < other) == lower) ? self : other;
+}
+
+template <int KPT>
+__device__ __forceinline__ void block_bitonic(uint64_t (&v)[KPT], uint64_t* __restrict__ lds, int tid) {
+  constexpr int P = 256 * KPT;
+  const int lane = tid & 63;
+#pragma unroll
+  for (int k = 2; k <= P; k <<= 1) {
+    // ---- flip step: element i pairs with i ^ (k-1) ----
+    if (k <= KPT) {
+#pragma unroll
+      for (int r = 0; r < KPT; ++r) {
+        const int q = r ^ (k - 1);
+        if (q > r) cex(v[r], v[q]);
+      }
+    } else if (k <= 64 * KPT) {
+      const int m = k / KPT - 1;
+      const bool lower = (lane & (k / KPT / 2)) == 0;
+      uint64_t o[KPT];
+#pragma unroll
+      for (int r = 0; r < KPT; ++r) o[r] = shfl_xor64(v[KPT - 1 - r], m);
+#pragma unroll
+      for (int r = 0; r < KPT; ++r) {
+        v[r] = pick(v[r], o[r], lower);
+      }
+    } else {
+      __syncthreads();
+#pragma unroll
+      for (int r = 0; r < KPT; ++r) lds[tid * KPT + r] = v[r];
+      __syncthreads();
+#pragma unroll
+      for (int r = 0; r < KPT; ++r) {
+        const int i = tid * KPT + r;
+        const uint64_t o = lds[i ^ (k - 1)];
+        const bool lower = (i & (k >> 1)) == 0;
+        v[r] = pick(v[r], o, lower);
+      }
+    }
+    // ---- ascending steps: element i (bit j clear) pairs with i | j ----
+#pragma unroll
+    for (int j = k >> 2; j > 0; j >>= 1) {
+      if (j < KPT) {
+#pragma unroll
+        for (int r = 0; r < KPT; ++r)
+          if ((r & j) == 0) cex(v[r], v[r | j]);
+      } else if (j < 64 * KPT) {
+        const bool lower = (lane & (j / KPT)) == 0;
+#pragma unroll
+        for (int r = 0; r < KPT; ++r) {
+          const uint64_t o = shfl_xor64(v[r], j / KPT);
+          v[r] = pick(v[r], o, lower);
+        }
+      } else {
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < KPT; ++r) lds[tid * KPT + r] = v[r];
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < KPT; ++r) {
+          const int i = tid * KPT + r;
+          const uint64_t o = lds[i ^ j];
+          const bool lower = (i & j) == 0;
+          v[r] = pick(v[r], o, lower);
+        }
+      }
+    }
+  }
+}
+
+template <int KPT>
+__device__ __forceinline__ void sort_tile_regs(const uint64_t* __restrict__ keys, int32_t* __restrict__ out, int n,
+                                               uint64_t* __restrict__ lds, int tid) {
+  uint64_t v[KPT];
+#pragma unroll
+  for (int r = 0; r < KPT; ++r) {
+    const int i = tid * KPT + r;
+    v[r] = i < n ? keys[i] : ~0ull;  // +inf padding sorts to the end
+  }
+  block_bitonic<KPT>(v, lds, tid);
+#pragma unroll
+  for (int r = 0; r < KPT; ++r) {
+    const int i = tid * KPT + r;
+    if (i < n) out[i] = (int32_t)(uint32_t)v[r];
+  }
+}
+
 __global__ __launch_bounds__(256) void sort_kernel(int T, int64_t capacity, int32_t* __restrict__ tile_bins,
                                                    uint64_t* __restrict__ isect_keys,
                                                    int32_t* __restrict__ sorted_ids) {
@@ -279,7 +389,15 @@ __global__ __launch_bounds__(256) void sort_kernel(int T, int64_t capacity, int3
     if (tid == 0) out[0] = (int32_t)(uint32_t)keys[0];
     return;
   }
-  if (n <= kSortLds) {
+  if (n <= 256) {
+    sort_tile_regs<1>(keys, out, n, lds_keys, tid);
+  } else if (n <= 512) {
+    sort_tile_regs<2>(keys, out, n, lds_keys, tid);
+  } else if (n <= 1024) {
+    sort_tile_regs<4>(keys, out, n, lds_keys, tid);
+  } else if (n <= 2048) {
+    sort_tile_regs<8>(keys, out, n, lds_keys, tid);
+  } else if (n <= kSortLds) {
     for (int i = tid; i < n; i += 256) lds_keys[i] = keys[i];
     __syncthreads();
     bitonic_sort(lds_keys, n, tid, 256);

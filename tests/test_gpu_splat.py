@@ -102,16 +102,18 @@ def test_bin_sort_matches_oracle_exactly():
         assert all(g in it for g in sub), t  # order-preserving subsequence
 
 
-def test_bin_sort_long_list_global_path():
-    """> 4096 Gaussians on one tile exercises the global-memory sort path."""
+@pytest.mark.parametrize("N", [2, 63, 200, 256, 257, 500, 513, 1000, 1024, 1025, 2000, 2048, 2049, 3500, 4096, 6000])
+def test_bin_sort_one_tile_every_size_class(N):
+    """All Gaussians on one tile: every size class of the per-tile sort (1/2/4/8 keys per thread in registers,
+    the LDS network up to 4096 keys, the global-memory path beyond), including lengths around the class borders."""
     from goliath_amd import splat
     from oracle import cref
 
-    N = 6000
-    g = torch.Generator().manual_seed(3)
+    g = torch.Generator().manual_seed(3 + N)
     xys = (torch.rand(N, 2, generator=g) * 10 + 3).cuda()  # all inside tile (0,0)
     depths = (torch.rand(N, generator=g) + 1).cuda()
-    depths[100:200] = depths[100]  # equal depths -> tie broken by id
+    if N > 200:
+        depths[100:200] = depths[100]  # equal depths -> tie broken by id
     radii = torch.ones(N, dtype=torch.int32).cuda()
     nth = torch.ones(N, dtype=torch.int32)
     _, ids, bins = cref.bin_and_sort(xys.cpu(), depths.cpu(), radii.cpu(), nth, 64, 64, 16)
