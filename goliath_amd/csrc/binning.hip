@@ -449,7 +449,11 @@ extern "C" int gol_bin_sort(int B, int N, const float* xys, const float* depths,
   if (N > 0) {
     if (lds_path) {
       const size_t lds = sizeof(int32_t) * (size_t)T;
-      if (lds > 48 * 1024) hipFuncSetAttribute((const void*)count_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      static size_t count_lds_max = 48 * 1024;  // raise the limit once per size (not a stream operation: keep it
+      if (lds > count_lds_max) {                // out of the steady state so the call sequence is graph-capturable)
+        hipFuncSetAttribute((const void*)count_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        count_lds_max = lds;
+      }
       count_lds_kernel<<<dim3(nblk, B), 1024, lds, s>>>(a, tile_count);
     } else {
       count_kernel<<<dim3(gol_cdiv(N, 256), B), 256, 0, s>>>(a, tile_count);
@@ -459,7 +463,11 @@ extern "C" int gol_bin_sort(int B, int N, const float* xys, const float* depths,
   if (N > 0 && capacity > 0) {
     if (lds_path) {
       const size_t lds = sizeof(int32_t) * (size_t)T * 2;
-      if (lds > 48 * 1024) hipFuncSetAttribute((const void*)scatter_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      static size_t scatter_lds_max = 48 * 1024;
+      if (lds > scatter_lds_max) {
+        hipFuncSetAttribute((const void*)scatter_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        scatter_lds_max = lds;
+      }
       scatter_lds_kernel<<<dim3(nblk, B), 1024, lds, s>>>(a, capacity, tile_bins, isect_keys);
     } else {
       scatter_kernel<<<dim3(gol_cdiv(N, 256), B), 256, 0, s>>>(a, capacity, tile_bins, isect_keys);

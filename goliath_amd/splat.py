@@ -44,6 +44,16 @@ class CapacityPlanner:
     def __init__(self):
         self.capacity = {}
         self.pending = []  # (event, pinned counts, capacity, key)
+        self.frozen = False      # True while a HIP graph is captured / replayed: no polling, no host copies
+        self.frozen_log = []     # (n_isect tensor, capacity) of the calls made while frozen -> check_frozen()
+
+    def check_frozen(self):
+        """After graph replays: did any captured render overflow the capacity it was captured with?"""
+        for n_isect, capacity in self.frozen_log:
+            worst = int(n_isect.max()) if n_isect.numel() else 0
+            if worst > capacity:
+                raise _lib.GoliathHipError(f"a captured render_views call overflowed its intersection capacity "
+                                           f"({worst} > {capacity}): re-capture with a larger capacity")
 
     def strict(self):
         return os.environ.get("GOLIATH_STRICT_CAPACITY", "0") == "1"
@@ -374,16 +384,22 @@ def render_views(means, scales, quats, opacity, colors, viewmats, intrins, img_h
     calibrate = False
     explicit = capacity is not None  # the caller sized the buffers: overflow is theirs to check (n_isect)
     if capacity is None:
-        PLANNER.poll()
+        if not PLANNER.frozen:
+            PLANNER.poll()
         capacity = PLANNER.get(key, N)
         if capacity is None:
+            if PLANNER.frozen:
+                raise _lib.GoliathHipError("render_views inside a graph capture needs a calibrated capacity: run the "
+                                           "same shapes once eagerly first")
             capacity, calibrate = PLANNER.initial(N, T), True
     out = _RenderViews.apply(means, scales, quats, opacity, colors, viewmats, intrins, background, img_h,
                              img_w, float(glob_scale), float(clip_thresh), bool(with_depth), int(capacity))
     img, alpha, depth, radii, n_isect = out
     if B == 0:
         calibrate = False
-    if (calibrate or PLANNER.strict()) and B > 0:
+    if PLANNER.frozen:
+        PLANNER.frozen_log.append((n_isect, capacity))
+    elif (calibrate or PLANNER.strict()) and B > 0:
         worst = int(n_isect.max().item())  # one blocking read per new shape
         if calibrate:
             PLANNER.set(key, worst)
