@@ -246,7 +246,8 @@ __device__ __forceinline__ Geo make_geo(const float (&g)[12], const float (&fc)[
 
 // specular radiance before the spec_vis factor; ENV: min(sample, 1) (rgca.py:556)
 template <bool ENV>
-__device__ __forceinline__ void spec_forward(const gol_shade_in& in, int b, const Geo& s, float (&spec)[3]) {
+__device__ __forceinline__ void spec_forward(const gol_shade_in& in, int b, const Geo& s, float (&spec)[3],
+                                             EnvSample* keep = nullptr) {
   if constexpr (ENV) {
     const float* R = in.lightrot + 9 * b;
     const float rx = R[0] * s.ref[0] + R[1] * s.ref[1] + R[2] * s.ref[2];
@@ -255,6 +256,7 @@ __device__ __forceinline__ void spec_forward(const gol_shade_in& in, int b, cons
     const float u = atan2f(rx, rz) * (1.f / kPi);
     const float v = 2.f * acosf(fminf(1.f, fmaxf(-1.f, ry))) * (1.f / kPi) - 1.f;
     const EnvSample e = env_lookup(in, b, u, v, 5.f * s.sigma);
+    if (keep) *keep = e;
 #pragma unroll
     for (int c = 0; c < 3; ++c) spec[c] = fminf(e.val[c], 1.f);
   } else {
@@ -333,6 +335,7 @@ __global__ __launch_bounds__(256) void shade_fwd_kernel(const gol_shade_in in, c
 
   float o_color[3][V], o_op[1][V], o_pos[3][V], o_q[4][V], o_sc[3][V], o_sp[3][V], o_sig[1][V], o_vis[1][V];
   float o_n[3][V], o_dn[3][V], o_diff[3][V], o_spec[3][V], o_nb[3][V], o_rand[3][V], o_D[3][V];
+  float o_env[ENV ? 9 : 1][V];
   const float* cam = in.campos + 3 * b;
 #pragma unroll
   for (int v = 0; v < V; ++v) {
@@ -345,7 +348,12 @@ __global__ __launch_bounds__(256) void shade_fwd_kernel(const gol_shade_in in, c
     for (int j = 0; j < 3; ++j) { p3[j] = pb[j][v]; n3[j] = nb[j][v]; }
     const Geo s = make_geo(gg, ff, p3, n3, cam);
     float spec[3];
-    spec_forward<ENV>(in, b, s, spec);
+    EnvSample es;
+    spec_forward<ENV>(in, b, s, spec, ENV ? &es : nullptr);
+    if constexpr (ENV) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) { o_env[c][v] = es.val[c]; o_env[3 + c][v] = es.d_u[c]; o_env[6 + c][v] = es.d_v[c]; }
+    }
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
       const float diff = alb[c][v] * D[c][v];
@@ -381,6 +389,9 @@ __global__ __launch_bounds__(256) void shade_fwd_kernel(const gol_shade_in in, c
   st_aos<V, 3>(out.spec_color, g0, o_spec);
   st_aos<V, 3>(out.primnmlbase, g0, o_nb);
   st_aos<V, 3>(out.diff_sum, g0, o_D);
+  if constexpr (ENV) {
+    if (out.env_saved) st_aos<V, 9>(out.env_saved, g0, o_env);
+  }
   if (RAND) st_aos<V, 3>(out.color_rand, g0, o_rand);
 }
 
@@ -454,7 +465,20 @@ __global__ __launch_bounds__(256) void shade_bwd_kernel(const gol_shade_in in, c
       for (int j = 0; j < 3; ++j) { p3[j] = pb[j][v]; n3[j] = nb[j][v]; }
       const Geo s = make_geo(g1, f1, p3, n3, cam);
       float spec[3];
-      spec_forward<ENV>(in, b, s, spec);  // recomputed: cheaper than saving/re-reading it
+      EnvSample e;
+      bool have_env = false;
+      if constexpr (ENV) {
+        if (saved.env_saved) {  // 36 B re-read instead of 8 texel gathers (two mip levels x 4 taps)
+          float es[9][V];
+          ld_aos<V, 9>(saved.env_saved, g0, es);
+#pragma unroll
+          for (int c = 0; c < 3; ++c) { e.val[c] = es[c][v]; e.d_u[c] = es[3 + c][v]; e.d_v[c] = es[6 + c][v]; }
+#pragma unroll
+          for (int c = 0; c < 3; ++c) spec[c] = fminf(e.val[c], 1.f);
+          have_env = true;
+        }
+      }
+      if (!have_env) spec_forward<ENV>(in, b, s, spec, ENV ? &e : nullptr);
 
       // colour composition (rgca.py:572-575): color_out = max(max(diff,0) + spec*vis, 0)
       float g_spec[3], g_sraw[3], g_vis = u_vis[0][v];
@@ -481,8 +505,7 @@ __global__ __launch_bounds__(256) void shade_bwd_kernel(const gol_shade_in in, c
         const float ry = R[3] * s.ref[0] + R[4] * s.ref[1] + R[5] * s.ref[2];
         const float rz = R[6] * s.ref[0] + R[7] * s.ref[1] + R[8] * s.ref[2];
         const float ryc = fminf(1.f, fmaxf(-1.f, ry));
-        const float uu = atan2f(rx, rz) * (1.f / kPi), vv = 2.f * acosf(ryc) * (1.f / kPi) - 1.f;
-        const EnvSample e = env_lookup(in, b, uu, vv, 5.f * s.sigma);
+        (void)ryc;
         float g_u = 0.f, g_v = 0.f;
 #pragma unroll
         for (int c = 0; c < 3; ++c) {

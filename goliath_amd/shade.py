@@ -32,8 +32,9 @@ class ShadeIn(ctypes.Structure):
 
 OUT_FIELDS = [("color", 3), ("opacity", 1), ("primpos", 3), ("primqvec", 4), ("primscale", 3),
               ("primscale_preclip", 3), ("sigma", 1), ("spec_vis", 1), ("spec_nml", 3), ("spec_dnml", 3),
-              ("diff_color", 3), ("spec_color", 3), ("primnmlbase", 3), ("color_rand", 3), ("diff_sum", 3)]
-GRAD_FIELDS = [n for n, _ in OUT_FIELDS if n != "diff_sum"]
+              ("diff_color", 3), ("spec_color", 3), ("primnmlbase", 3), ("color_rand", 3), ("diff_sum", 3),
+              ("env_saved", 9)]
+GRAD_FIELDS = [n for n, _ in OUT_FIELDS if n not in ("diff_sum", "env_saved")]
 
 
 class ShadeOut(ctypes.Structure):
@@ -97,7 +98,9 @@ class _Shade(torch.autograd.Function):
         N = f_vnocond[0, 0].numel()
         dev = f_vnocond.device
         rand = light_sh_rand is not None
-        outs = {n: torch.empty(B, N, k, device=dev) for n, k in OUT_FIELDS if rand or n != "color_rand"}
+        need_grad = any(ctx.needs_input_grad[:5])
+        outs = {n: torch.empty(B, N, k, device=dev) for n, k in OUT_FIELDS
+                if (rand or n != "color_rand") and (n != "env_saved" or (mips and need_grad))}
         with torch.cuda.device(dev):
             packed = pack_envmap(mips) if mips else None
         sin = _make_in(f_vnocond, f_vcond, postex, tn, albedo, light_sh, light_sh_rand, campos,
@@ -111,7 +114,7 @@ class _Shade(torch.autograd.Function):
         ctx.packed = packed  # not an input/output of the node: plain attribute
         ctx.save_for_backward(f_vnocond, f_vcond, postex, tn, albedo, light_sh, light_sh_rand, campos,
                               light_intensity, light_pos, n_lights, lightrot, outs["diff_sum"],
-                              outs.get("color_rand"), *mips)
+                              outs.get("color_rand"), outs.get("env_saved"), *mips)
         ctx.set_materialize_grads(False)
         names = [n for n in GRAD_FIELDS if n in outs]
         ctx.names = names
@@ -122,8 +125,8 @@ class _Shade(torch.autograd.Function):
         ncol, nmono, n_mips, rand = ctx.cfg
         sv = ctx.saved_tensors
         (f_vnocond, f_vcond, postex, tn, albedo, light_sh, light_sh_rand, campos, light_intensity, light_pos,
-         n_lights, lightrot, diff_sum, color_rand) = sv[:14]
-        mips = list(sv[14:])
+         n_lights, lightrot, diff_sum, color_rand, env_saved) = sv[:15]
+        mips = list(sv[15:])
         B = f_vnocond.shape[0]
         N = f_vnocond[0, 0].numel()
         dev = f_vnocond.device
@@ -132,6 +135,7 @@ class _Shade(torch.autograd.Function):
         saved = ShadeOut()
         saved.diff_sum = _p(diff_sum)
         saved.color_rand = _p(color_rand)
+        saved.env_saved = _p(env_saved)
         up = ShadeOutGrad()
         keep = []
         for n, g in zip(ctx.names, grads):

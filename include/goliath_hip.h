@@ -191,6 +191,8 @@ typedef struct {  /* every field [B,N,k] row-major like the reference's preds (r
   float* primnmlbase;      /* 3 */
   float* color_rand;       /* 3, or NULL when light_sh_rand == NULL */
   float* diff_sum;         /* 3: sum_k sh_k * L_k before albedo (saved for the backward) */
+  float* env_saved;        /* 9, optional (NULL = off), env mode only: the env-map sample (value rgb, d/du rgb, d/dv rgb)
+                              saved so the backward does not repeat the 8 texel gathers per Gaussian */
 } gol_shade_out;
 
 typedef struct {  /* upstream gradients, same shapes as gol_shade_out; any may be NULL (= 0) */
@@ -210,7 +212,7 @@ typedef struct {  /* written in full */
  * dst[B,h,w,4] texel-interleaved, 4th component 0. */
 int gol_envmap_pack(int B, int h, int w, const float* src, float* dst, void* stream);
 int gol_shade_fwd(const gol_shade_in* in, const gol_shade_out* out, void* stream);
-/* `saved` = the gol_shade_out of the forward (reads color_rand, diff_sum). */
+/* `saved` = the gol_shade_out of the forward (reads color_rand, diff_sum, env_saved). */
 int gol_shade_bwd(const gol_shade_in* in, const gol_shade_out* saved, const gol_shade_out_grad* g,
                   const gol_shade_in_grad* gin, void* stream);
 
