@@ -70,7 +70,16 @@ struct BinArgs {
   int N, tiles_x, tiles_y, chunk;
   float inv_block, block;
   const float* xys; const float* depths; const int32_t* radii; const float* conics; const float* opacities;
+  uint64_t* reach;  // optional [B,N]: bit (y-y0)*w + (x-x0) of a Gaussian's tile box = the exact test of pass 1,
+                    // reused by pass 3 (boxes of more than 64 tiles are re-tested there)
 };
+
+// reached(x, y) from the mask pass 1 left behind, or the exact test when there is none
+__device__ __forceinline__ bool reached_cached(const Reach& rc, const TileBox& tb, bool have_mask, uint64_t mask, int x,
+                                               int y, float block) {
+  if (have_mask) return (mask >> ((y - tb.y0) * (tb.x1 - tb.x0) + (x - tb.x0))) & 1ull;
+  return tile_reached(rc, x, y, block);
+}
 
 __device__ __forceinline__ TileBox box_of(const BinArgs& a, size_t e, Reach& rc) {
   const int r = a.radii[e];
@@ -100,9 +109,15 @@ __global__ __launch_bounds__(1024) void count_lds_kernel(BinArgs a, int32_t* __r
   for (int i = blockIdx.x * a.chunk + threadIdx.x; i < i_end; i += 1024) {
     Reach rc;
     const TileBox tb = box_of(a, (size_t)b * a.N + i, rc);
+    const int bw = tb.x1 - tb.x0;
+    uint64_t mask = 0;
     for (int y = tb.y0; y < tb.y1; ++y)
       for (int x = tb.x0; x < tb.x1; ++x)
-        if (tile_reached(rc, x, y, a.block)) atomicAdd(&s_cnt[y * a.tiles_x + x], 1);
+        if (tile_reached(rc, x, y, a.block)) {
+          atomicAdd(&s_cnt[y * a.tiles_x + x], 1);
+          mask |= 1ull << (((y - tb.y0) * bw + (x - tb.x0)) & 63);
+        }
+    if (a.reach) a.reach[(size_t)b * a.N + i] = mask;
   }
   __syncthreads();
   int32_t* tc = tile_count + (size_t)b * T;
@@ -128,9 +143,11 @@ __global__ __launch_bounds__(1024) void scatter_lds_kernel(BinArgs a, int64_t ca
   for (int i = i_begin; i < i_end; i += 1024) {
     Reach rc;
     const TileBox tb = box_of(a, (size_t)b * a.N + i, rc);
+    const bool hm = a.reach && (tb.x1 - tb.x0) * (tb.y1 - tb.y0) <= 64;
+    const uint64_t mask = hm ? a.reach[(size_t)b * a.N + i] : 0;
     for (int y = tb.y0; y < tb.y1; ++y)
       for (int x = tb.x0; x < tb.x1; ++x)
-        if (tile_reached(rc, x, y, a.block)) atomicAdd(&s_cnt[y * a.tiles_x + x], 1);
+        if (reached_cached(rc, tb, hm, mask, x, y, a.block)) atomicAdd(&s_cnt[y * a.tiles_x + x], 1);
   }
   __syncthreads();
   int32_t* bins = tile_bins + (size_t)b * T * 2;
@@ -147,9 +164,11 @@ __global__ __launch_bounds__(1024) void scatter_lds_kernel(BinArgs a, int64_t ca
     const TileBox tb = box_of(a, e, rc);
     if (tb.x1 <= tb.x0 || tb.y1 <= tb.y0) continue;
     const uint64_t key = ((uint64_t)__float_as_uint(a.depths[e]) << 32) | (uint32_t)i;
+    const bool hm = a.reach && (tb.x1 - tb.x0) * (tb.y1 - tb.y0) <= 64;
+    const uint64_t mask = hm ? a.reach[e] : 0;
     for (int y = tb.y0; y < tb.y1; ++y)
       for (int x = tb.x0; x < tb.x1; ++x) {
-        if (!tile_reached(rc, x, y, a.block)) continue;
+        if (!reached_cached(rc, tb, hm, mask, x, y, a.block)) continue;
         const int t = y * a.tiles_x + x;
         const int slot = s_base[t] + atomicAdd(&s_cnt[t], 1);
         if (slot < capacity) keys[slot] = key;
@@ -416,7 +435,7 @@ __global__ __launch_bounds__(256) void sort_kernel(int T, int64_t capacity, int3
 extern "C" int gol_bin_sort(int B, int N, const float* xys, const float* depths, const int32_t* radii,
                             const float* conics, const float* opacities, int img_h, int img_w, int block,
                             int64_t capacity, int32_t* tile_count, int32_t* tile_bins, uint64_t* isect_keys,
-                            int32_t* sorted_ids, int32_t* n_isect, void* stream) {
+                            int32_t* sorted_ids, int32_t* n_isect, uint64_t* reach_scratch, void* stream) {
   GOL_REQUIRE(B >= 0 && N >= 0, "negative size");
   GOL_REQUIRE(block > 1 && block <= 16, "block_width must be between 2 and 16");
   GOL_REQUIRE(img_h > 0 && img_w > 0, "empty image");
@@ -442,6 +461,7 @@ extern "C" int gol_bin_sort(int B, int N, const float* xys, const float* depths,
   if (a.chunk < 1024) a.chunk = 1024;
   const int nblk = N > 0 ? gol_cdiv(N, a.chunk) : 1;
   const bool lds_path = (size_t)T * 8 <= 128 * 1024;
+  a.reach = (lds_path && conics) ? reach_scratch : nullptr;
   if (hipMemsetAsync(tile_count, 0, sizeof(int32_t) * (size_t)B * T, s) != hipSuccess) {
     gol_set_error("gol_bin_sort: hipMemsetAsync failed");
     return GOL_ERR_LAUNCH;

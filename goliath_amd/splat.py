@@ -111,6 +111,7 @@ class _Workspace:
         self.keys = torch.empty(B, max(capacity, 1), dtype=torch.int64, device=device)
         self.sorted_ids = torch.empty(B, max(capacity, 1), dtype=torch.int32, device=device)
         self.n_isect = torch.empty(B, dtype=torch.int32, device=device)
+        self.reach = torch.empty(B, max(N, 1), dtype=torch.int64, device=device)  # pass-1 -> pass-3 tile masks
 
 
 def _bin_sort(B, N, xys, depths, radii, img_h, img_w, ws, conics=None, opacities=None):
@@ -119,7 +120,7 @@ def _bin_sort(B, N, xys, depths, radii, img_h, img_w, ws, conics=None, opacities
     _lib.call("gol_bin_sort", c_int(B), c_int(N), fptr(xys), fptr(depths), iptr(radii), fptr(conics),
               fptr(opacities), c_int(img_h), c_int(img_w), c_int(BLOCK), c_i64(ws.capacity),
               iptr(ws.tile_count), iptr(ws.tile_bins), ptr(ws.keys, torch.int64), iptr(ws.sorted_ids),
-              iptr(ws.n_isect), stream_ptr())
+              iptr(ws.n_isect), ptr(ws.reach, torch.int64), stream_ptr())
 
 
 def _project_fwd(B, N, means, scales, glob_scale, quats, viewmats, intrins, img_h, img_w, clip,

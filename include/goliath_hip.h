@@ -99,11 +99,13 @@ int gol_project_bwd(int B, int N, const float* means3d, const float* scales, flo
  *   sorted_ids[B,capacity] out: Gaussian ids, tile by tile, front to back
  *   n_isect[B] out: number of intersections found (> capacity means overflow: the excess
  *                   intersections were dropped and the render is incomplete)
+ *   reach_scratch[B,N] optional scratch (NULL = off): the counting pass leaves each Gaussian's exact
+ *                   tile-reach bit mask there so the scatter pass does not repeat the ellipse tests
  * ---------------------------------------------------------------------------------------- */
 int gol_bin_sort(int B, int N, const float* xys, const float* depths, const int32_t* radii,
                  const float* conics, const float* opacities, int img_h, int img_w, int block,
                  int64_t capacity, int32_t* tile_count, int32_t* tile_bins, uint64_t* isect_keys,
-                 int32_t* sorted_ids, int32_t* n_isect, void* stream);
+                 int32_t* sorted_ids, int32_t* n_isect, uint64_t* reach_scratch, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Tile rasterizer.  Replaces gsplat: rasterize_forward / rasterize_backward, 3-channel
