@@ -333,10 +333,13 @@ __global__ __launch_bounds__(128) void raster_bwd_kernel(
       const float sx = s0 * dx, sxx = sx * dx, sxy = sy * dx;
       const float r0 = gol_wave_sum4(g0v.x + g0v.y, g1v.x + g1v.y, g2v.x + g2v.y, gopv.x + gopv.y);
       const float r1 = gol_wave_sum4(sx, sy, sxx, sxy);
-      const float r2 = gol_wave_sum4(syy, g3, 0.f, 0.f);
+      // the 9th (and 10th) sum: a 6-instruction DPP ladder each (total in lane 63) instead of a third 4-way reduction
+      const float r2 = gol_wave_sum_to_lane63(syy);
+      const float r3 = EXTRA ? gol_wave_sum_to_lane63(g3) : 0.f;
       if ((lane & 15) == 15) {
         float* a = &s_acc[wave][t][lane >> 4];
-        a[0] = r0; a[4] = r1; a[8] = r2;
+        a[0] = r0; a[4] = r1;
+        if (lane == 63) { s_acc[wave][t][8] = r2; s_acc[wave][t][9] = r3; }
         s_touched[wave][t] = 1;
       }
     }
