@@ -416,6 +416,8 @@ __global__ __launch_bounds__(256) void sort_kernel(int T, int64_t capacity, int3
     sort_tile_regs<4>(keys, out, n, lds_keys, tid);
   } else if (n <= 2048) {
     sort_tile_regs<8>(keys, out, n, lds_keys, tid);
+  } else if (n <= 4096) {
+    sort_tile_regs<16>(keys, out, n, lds_keys, tid);
   } else if (n <= kSortLds) {
     for (int i = tid; i < n; i += 256) lds_keys[i] = keys[i];
     __syncthreads();
