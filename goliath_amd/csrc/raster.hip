@@ -76,7 +76,8 @@ __global__ __launch_bounds__(128) void raster_fwd_kernel(
     const int32_t* __restrict__ sorted_ids, int64_t capacity, const float* __restrict__ xys,
     const float* __restrict__ conics, const float* __restrict__ colors, const float* __restrict__ extra,
     const float* __restrict__ opacities, const float* __restrict__ background, float* __restrict__ out_img,
-    float* __restrict__ out_extra, float* __restrict__ final_Ts, int32_t* __restrict__ final_idx) {
+    float* __restrict__ out_extra, float* __restrict__ final_Ts, int32_t* __restrict__ final_idx,
+    float* __restrict__ out_alpha, float* __restrict__ out_extra_norm, float norm_lo) {
   __shared__ float4 s_a[kBatch];  // x, y, conic.a, conic.b
   __shared__ float4 s_b[kBatch];  // conic.c, opacity, r, g
   __shared__ float2 s_c[kBatch];  // b, extra
@@ -169,6 +170,9 @@ __global__ __launch_bounds__(128) void raster_fwd_kernel(
     out_img[o0 + os] = acc1.x + T_cur.x * background[1];
     out_img[o0 + 2 * os] = acc2.x + T_cur.x * background[2];
     if (EXTRA) out_extra[p] = acc3.x;
+    // optional fused epilogue of AutoEncoder.render (rgca.py:137,144-145): alpha = 1 - T, depth / clamp(alpha, lo, 1)
+    if (out_alpha) out_alpha[p] = 1.f - T_cur.x;
+    if (EXTRA && out_extra_norm) out_extra_norm[p] = acc3.x / fminf(fmaxf(1.f - T_cur.x, norm_lo), 1.f);
   }
   if (in1) {
     const size_t p = ((size_t)view * img_h + i0 + 1) * img_w + j;
@@ -179,6 +183,8 @@ __global__ __launch_bounds__(128) void raster_fwd_kernel(
     out_img[o0 + os] = acc1.y + T_cur.y * background[1];
     out_img[o0 + 2 * os] = acc2.y + T_cur.y * background[2];
     if (EXTRA) out_extra[p] = acc3.y;
+    if (out_alpha) out_alpha[p] = 1.f - T_cur.y;
+    if (EXTRA && out_extra_norm) out_extra_norm[p] = acc3.y / fminf(fmaxf(1.f - T_cur.y, norm_lo), 1.f);
   }
 }
 
@@ -400,7 +406,8 @@ extern "C" int gol_rasterize_fwd(int B, int N, int img_h, int img_w, int block, 
                                  const int32_t* sorted_ids, int64_t capacity, const float* xys,
                                  const float* conics, const float* colors, const float* extra,
                                  const float* opacities, const float* background, float* out_img,
-                                 float* out_extra, float* final_Ts, int32_t* final_idx, void* stream) {
+                                 float* out_extra, float* final_Ts, int32_t* final_idx, float* out_alpha,
+                                 float* out_extra_norm, float norm_lo, void* stream) {
   GOL_REQUIRE(B >= 0 && N >= 0, "negative size");
   GOL_REQUIRE(block == 16, "only block_width == 16 is implemented (the reference's value, render_gsplat.py:28)");
   GOL_REQUIRE(img_h > 0 && img_w > 0, "empty image");
@@ -410,6 +417,7 @@ extern "C" int gol_rasterize_fwd(int B, int N, int img_h, int img_w, int block, 
   GOL_REQUIRE(capacity == 0 || sorted_ids, "null sorted_ids");
   GOL_REQUIRE(N == 0 || (xys && conics && colors && opacities), "null Gaussian attribute");
   GOL_REQUIRE(N == 0 || ((extra == nullptr) == (out_extra == nullptr)), "extra and out_extra go together");
+  GOL_REQUIRE(!out_extra_norm || out_extra, "out_extra_norm needs the extra channel");
   const int tiles_x = (img_w + 15) / 16, tiles_y = (img_h + 15) / 16, T = tiles_x * tiles_y;
   dim3 grid(8 * ((tiles_y + 7) / 8) * tiles_x, B);
   const int2* bins = reinterpret_cast<const int2*>(tile_bins);
@@ -417,11 +425,11 @@ extern "C" int gol_rasterize_fwd(int B, int N, int img_h, int img_w, int block, 
   if (out_extra)
     raster_fwd_kernel<true><<<grid, 128, 0, s>>>(N, img_h, img_w, planar, tiles_x, tiles_y, bins, sorted_ids, capacity, xys,
                                                   conics, colors, extra, opacities, background, out_img, out_extra,
-                                                  final_Ts, final_idx);
+                                                  final_Ts, final_idx, out_alpha, out_extra_norm, norm_lo);
   else
     raster_fwd_kernel<false><<<grid, 128, 0, s>>>(N, img_h, img_w, planar, tiles_x, tiles_y, bins, sorted_ids, capacity, xys,
                                                    conics, colors, extra, opacities, background, out_img, out_extra,
-                                                   final_Ts, final_idx);
+                                                   final_Ts, final_idx, out_alpha, nullptr, norm_lo);
   GOL_CHECK_LAUNCH();
   return GOL_OK;
 }

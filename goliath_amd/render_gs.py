@@ -38,7 +38,5 @@ def render_batch(K: th.Tensor, Rt: th.Tensor, preds: Dict[str, Any], height: int
     intr = th.stack([K[:, 0, 0], K[:, 1, 1], K[:, 0, 2], K[:, 1, 2]], dim=-1)
     out = render_views(preds["primpos"], preds["primscale"], preds["primqvec"], preds["opacity"],
                        preds["color"], Rt, intr, height, width, with_depth=True)
-    rgb = out["render"]
-    alpha = out["alpha"].detach()
-    depth = out["depth"] / alpha.clamp(0.05, 1.0)
-    return rgb, alpha, depth
+    # alpha = 1 - T.detach() and depth / alpha.clamp(0.05, 1) are written by the raster kernel's epilogue
+    return out["render"], out["alpha"].detach(), out["depth_norm"]

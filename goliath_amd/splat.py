@@ -230,7 +230,8 @@ class _RasterizeGaussians(torch.autograd.Function):
                 _lib.call("gol_rasterize_fwd", c_int(1), c_int(N), c_int(img_height), c_int(img_width),
                           c_int(BLOCK), c_int(0), iptr(ws.tile_bins), iptr(ws.sorted_ids), c_i64(ws.capacity), fptr(xys),
                           fptr(conics), fptr(colors), fptr(None), fptr(opacity), fptr(background),
-                          fptr(out_img), fptr(None), fptr(final_Ts), iptr(final_idx), stream_ptr())
+                          fptr(out_img), fptr(None), fptr(final_Ts), iptr(final_idx), fptr(None), fptr(None),
+                          c_float(0.0), stream_ptr())
             ctx.ws = ws
             ctx.save_for_backward(xys, conics, colors, opacity, background, final_Ts, final_idx)
             out_img, final_Ts = out_img[0], final_Ts[0]
@@ -294,7 +295,7 @@ def rasterize_gaussians(xys, depths, radii, conics, num_tiles_hit, colors, opaci
 class _RenderViews(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means, scales, quats, opacity, colors, viewmats, intrins, background, img_h, img_w,
-                glob_scale, clip_thresh, with_depth, capacity):
+                glob_scale, clip_thresh, with_depth, capacity, depth_norm_lo):
         B, N = means.shape[:2]
         dev = means.device
         T = _tiles(img_h, img_w)
@@ -308,31 +309,36 @@ class _RenderViews(torch.autograd.Function):
             out_depth = torch.empty(B, img_h, img_w, device=dev) if with_depth else None
             final_Ts = torch.empty(B, img_h, img_w, device=dev)
             final_idx = torch.empty(B, img_h, img_w, dtype=torch.int32, device=dev)
+            # alpha = 1 - T and depth / clamp(alpha, lo, 1) come out of the raster epilogue (rgca.py:137,144-145)
+            alpha = torch.empty(B, img_h, img_w, device=dev)
+            depth_norm = torch.empty(B, img_h, img_w, device=dev) if with_depth else None
             _lib.call("gol_rasterize_fwd", c_int(B), c_int(N), c_int(img_h), c_int(img_w), c_int(BLOCK), c_int(1),
                       iptr(ws.tile_bins), iptr(ws.sorted_ids), c_i64(ws.capacity), fptr(xys), fptr(conics),
                       fptr(colors), fptr(depths if with_depth else None), fptr(opac_eff), fptr(background),
-                      fptr(out_img), fptr(out_depth), fptr(final_Ts), iptr(final_idx), stream_ptr())
+                      fptr(out_img), fptr(out_depth), fptr(final_Ts), iptr(final_idx), fptr(alpha), fptr(depth_norm),
+                      c_float(depth_norm_lo), stream_ptr())
         ctx.ws = ws
-        ctx.cfg = (img_h, img_w, glob_scale, with_depth)
+        ctx.cfg = (img_h, img_w, glob_scale, with_depth, depth_norm_lo)
         ctx.save_for_backward(means, scales, quats, opacity, colors, viewmats, intrins, background, cov3d, xys,
                               depths, radii, conics, comp, opac_eff, final_Ts, final_idx)
-        ctx.mark_non_differentiable(radii, ws.n_isect)
+        ctx.alpha = alpha  # plain attribute (an output of the node)
+        ctx.mark_non_differentiable(radii, ws.n_isect, final_Ts)
         ctx.set_materialize_grads(False)
-        alpha = 1 - final_Ts
-        if with_depth:
-            return out_img, alpha, out_depth, radii, ws.n_isect
-        return out_img, alpha, None, radii, ws.n_isect
+        return out_img, alpha, out_depth, depth_norm, radii, ws.n_isect, final_Ts
 
     @staticmethod
-    def backward(ctx, v_img, v_alpha, v_depth, _v_radii, _v_n):
+    def backward(ctx, v_img, v_alpha, v_depth, v_depth_norm, _v_radii, _v_n, _v_T):
         (means, scales, quats, opacity, colors, viewmats, intrins, background, cov3d, xys, depths, radii,
          conics, comp, opac_eff, final_Ts, final_idx) = ctx.saved_tensors
-        img_h, img_w, glob_scale, with_depth = ctx.cfg
+        img_h, img_w, glob_scale, with_depth, depth_norm_lo = ctx.cfg
         B, N = means.shape[:2]
         dev = means.device
         ws = ctx.ws
+        if v_depth_norm is not None:  # depth_norm = depth / clamp(alpha.detach(), lo, 1)
+            g = v_depth_norm / ctx.alpha.clamp(depth_norm_lo, 1.0)
+            v_depth = g if v_depth is None else v_depth + g
         if v_img is None and v_alpha is None and v_depth is None:
-            return (None,) * 14
+            return (None,) * 15
         if v_img is None:
             v_img = torch.zeros(B, 3, img_h, img_w, device=dev)
         use_depth = with_depth and v_depth is not None
@@ -357,17 +363,18 @@ class _RenderViews(torch.autograd.Function):
                       fptr(comp), field(4), field(9) if use_depth else fptr(None), field(6), fptr(None), fptr(opacity),
                       field(3), c_int(GRAD_RECORD), fptr(v_mean), fptr(v_scale), fptr(v_quat), fptr(v_opacity),
                       stream_ptr())
-        return (v_mean, v_scale, v_quat, v_opacity, rec[..., :3]) + (None,) * 9
+        return (v_mean, v_scale, v_quat, v_opacity, rec[..., :3]) + (None,) * 10
 
 
 def render_views(means, scales, quats, opacity, colors, viewmats, intrins, img_h, img_w,
-                 background=None, glob_scale=1.0, clip_thresh=0.1, with_depth=True, capacity=None):
+                 background=None, glob_scale=1.0, clip_thresh=0.1, with_depth=True, capacity=None, depth_norm_lo=0.05):
     """Render B views in one launch sequence.
 
     means[B,N,3] scales[B,N,3] quats[B,N,4] opacity[B,N] or [B,N,1] colors[B,N,3]  (fp32, GPU)
     viewmats[B,3,4] (or [B,12]; world->camera, row-major), intrins[B,4] = (fx, fy, cx, cy)
     Returns dict(render[B,3,H,W], alpha[B,1,H,W] (= 1 - final_T), depth[B,1,H,W] (un-normalised,
-    like render_gsplat.py:105-106), radii[B,N] int32, n_isect[B] int32).
+    like render_gsplat.py:105-106), depth_norm[B,1,H,W] (= depth / clamp(alpha.detach(), depth_norm_lo, 1),
+    rgca.py:144-145), final_T, radii[B,N] int32, n_isect[B] int32).
     """
     B, N = means.shape[:2]
     dev = means.device
@@ -394,8 +401,9 @@ def render_views(means, scales, quats, opacity, colors, viewmats, intrins, img_h
                                            "same shapes once eagerly first")
             capacity, calibrate = PLANNER.initial(N, T), True
     out = _RenderViews.apply(means, scales, quats, opacity, colors, viewmats, intrins, background, img_h,
-                             img_w, float(glob_scale), float(clip_thresh), bool(with_depth), int(capacity))
-    img, alpha, depth, radii, n_isect = out
+                             img_w, float(glob_scale), float(clip_thresh), bool(with_depth), int(capacity),
+                             float(depth_norm_lo))
+    img, alpha, depth, depth_norm, radii, n_isect, final_T = out
     if B == 0:
         calibrate = False
     if PLANNER.frozen:
@@ -407,11 +415,12 @@ def render_views(means, scales, quats, opacity, colors, viewmats, intrins, img_h
         if worst > capacity:
             new_cap = PLANNER.set(key, worst)
             return render_views(means, scales, quats, opacity, colors, viewmats, intrins, img_h, img_w,
-                                background, glob_scale, clip_thresh, with_depth, capacity=new_cap)
+                                background, glob_scale, clip_thresh, with_depth, capacity=new_cap,
+                                depth_norm_lo=depth_norm_lo)
     elif key in PLANNER.capacity and not explicit and B > 0:
         PLANNER.note(key, n_isect, capacity)
-    res = {"render": img, "alpha": alpha[:, None], "final_T": (1 - alpha)[:, None],
-           "radii": radii, "n_isect": n_isect}
+    res = {"render": img, "alpha": alpha[:, None], "final_T": final_T[:, None], "radii": radii, "n_isect": n_isect}
     if with_depth:
         res["depth"] = depth[:, None]
+        res["depth_norm"] = depth_norm[:, None]  # depth / clamp(alpha.detach(), depth_norm_lo, 1)
     return res

@@ -116,6 +116,8 @@ int gol_bin_sort(int B, int N, const float* xys, const float* depths, const int3
  *   AutoEncoder.render stacks, rgca.py:139 -- saves the permute copy in the backward).
  *   background[3]; out_extra[B,H,W]; final_Ts[B,H,W]; final_idx[B,H,W] int32
  *   (index into the view's sorted_ids segment of the last contributing Gaussian, 0 if none).
+ * fwd optional fused epilogue of AutoEncoder.render (rgca.py:137,144-145), NULL = off: out_alpha[B,H,W] = 1 - final_T and
+ *   out_extra_norm[B,H,W] = out_extra / clamp(1 - final_T, norm_lo, 1)  (the reference divides depth by alpha.clamp(0.05, 1)).
  * bwd ACCUMULATES into v_xy[B,N,2] v_conic[B,N,3] v_colors[B,N,3] v_opacity[B,N]
  * (and v_extra[B,N]) which the caller zeroes; v_out_alpha / v_out_extra may be NULL.
  * grad_stride = 0: the five gradient outputs are dense arrays (gsplat's layout);
@@ -129,7 +131,8 @@ int gol_rasterize_fwd(int B, int N, int img_h, int img_w, int block, int planar,
                       const int32_t* sorted_ids, int64_t capacity, const float* xys,
                       const float* conics, const float* colors, const float* extra,
                       const float* opacities, const float* background, float* out_img,
-                      float* out_extra, float* final_Ts, int32_t* final_idx, void* stream);
+                      float* out_extra, float* final_Ts, int32_t* final_idx, float* out_alpha,
+                      float* out_extra_norm, float norm_lo, void* stream);
 int gol_rasterize_bwd(int B, int N, int img_h, int img_w, int block, int planar, const int32_t* tile_bins,
                       const int32_t* sorted_ids, int64_t capacity, const float* xys,
                       const float* conics, const float* colors, const float* extra,
