@@ -402,9 +402,17 @@ def e2e_main(args):
     t["postex"] = pos.t().reshape(1, 3, S, S).expand(B, -1, -1, -1).contiguous()
     t["tn"] = F.normalize(pos, dim=-1).t().reshape(1, 3, S, S).expand(B, -1, -1, -1).contiguous()
     t["embs"] = torch.randn(B, 256, device=dev, generator=g)
-    t["target"] = torch.rand(B, 3, H, W, device=dev, generator=g)
     albedo = torch.nn.Parameter(0.2 + 0.6 * torch.rand(1, N, 3, device=dev, generator=g))
     params = list(dec.parameters()) + [albedo]
+    with torch.no_grad():
+        # target = the render of a nearby latent code, so the fit stays near the synthetic scene's statistics (fitting
+        # uniform noise makes the optimiser inflate the Gaussians: 7x the intersections within 40 steps)
+        f_vn0, f_vc0 = dec(t["embs"] + 0.3 * torch.randn(B, 256, device=dev, generator=g), t["campos"])
+        p0 = shade.shading_tail(f_vn0, f_vc0, t["postex"], t["tn"], albedo, t["light_sh"], t["campos"],
+                                preconv_envmap=t["mips"], lightrot=t["lightrot"])
+        rgb0 = render_gs.render_batch(t["K"], t["Rt"], p0, H, W)[0]
+        t["target"] = rgb0.clamp(0.0, 1.0)
+        del f_vn0, f_vc0, p0, rgb0
     opt = torch.optim.Adam(params, lr=5e-4, fused=True)  # one multi-tensor kernel: same math as the default
     sync = parallel.GradSync(params)
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
@@ -445,14 +453,30 @@ def e2e_main(args):
 
     from goliath_amd import _lib
 
+    reruns = [0]
+    raw_step = step
+
+    def step():
+        # the documented recovery protocol of the sync-free path: an overflowed intersection capacity is reported
+        # (late) by an exception after the capacity has been raised -- run the step again
+        try:
+            return raw_step()
+        except _lib.GoliathHipError as e:
+            if "capacity" not in str(e):
+                raise
+            reruns[0] += 1
+            return raw_step()
+
+    loss_first = None
     for _ in range(args.warmup):
-        step()
+        l = step()
+        loss_first = l.detach() if loss_first is None else loss_first
     barrier()
     _lib.TIMING = []
     seg = [0.0, 0.0, 0.0]
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step()
+        l = step()
         if args.segments:  # per-segment event times need a sync per step: off in the headline number
             torch.cuda.synchronize()
             for i in range(3):
@@ -460,7 +484,10 @@ def e2e_main(args):
     barrier()
     dt = time.perf_counter() - t0
     timing, _lib.TIMING = _lib.TIMING, None
-    splat.PLANNER.poll(block=True)
+    try:
+        splat.PLANNER.poll(block=True)
+    except _lib.GoliathHipError:
+        reruns[0] += 1  # an overflow in the very last steps: reported, nothing left to re-run
     if world > 1:
         import torch.distributed as dist
 
@@ -480,7 +507,10 @@ def e2e_main(args):
                           "fused_tail": bool(args.fused_tail), "loss": "10*l1" if args.no_ssim else "10*l1 + 0.2*(1-ssim)",
                           "trainable_params": sum(p.numel() for p in params),
                           "parallelism": f"view-parallel x{world}"},
-               "kernels_ms_per_call": ms, "hot_path_ms_per_step": sum(sum(v) for v in per.values()) / args.steps}
+               "kernels_ms_per_call": ms, "hot_path_ms_per_step": sum(sum(v) for v in per.values()) / args.steps,
+               # sanity signal of the whole gradient chain: the training loss on the fixed batch, first vs last step
+               "loss_first_step": float(loss_first) if loss_first is not None else None,
+               "loss_last_step": float(l.detach()), "capacity_overflow_reruns": reruns[0]}
         if args.segments:
             res["segments_ms"] = {"decoder_fwd" if not args.fused_tail else "decoder_trunk_fwd": seg[0] / args.steps,
                                   "tail_render_loss_and_all_backward": seg[1] / args.steps,

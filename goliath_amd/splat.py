@@ -35,7 +35,7 @@ class CapacityPlanner:
     """Per-shape capacity (max Gaussian/tile intersections per view) for the sync-free path.
 
     First call for a shape: one blocking calibration (reads the true count, sizes the buffers
-    with 50 % head-room).  Later calls: no sync; the true counts are copied to pinned host memory
+    with 100 % head-room).  Later calls: no sync; the true counts are copied to pinned host memory
     asynchronously and inspected at the NEXT call -- an overflow then raises (the affected render
     dropped intersections) after growing the capacity so a re-run succeeds.
     Set GOLIATH_STRICT_CAPACITY=1 to verify every call synchronously.
@@ -65,7 +65,8 @@ class CapacityPlanner:
         return int(min(2**31 - 1, max(1 << 16, 16 * N + T)))
 
     def set(self, key, counts_max):
-        self.capacity[key] = int(min(2**31 - 1, max(1 << 16, int(counts_max * 1.5) + 4096)))
+        # 2x head-room: during training the lists grow from step to step and the counts are read a few steps late
+        self.capacity[key] = int(min(2**31 - 1, max(1 << 16, int(counts_max * 2.0) + 4096)))
         return self.capacity[key]
 
     def note(self, key, n_isect, capacity):
@@ -85,7 +86,7 @@ class CapacityPlanner:
                 if worst > capacity:
                     self.set(key, worst)
                     overflow = (worst, capacity, key)
-                elif worst * 1.25 > capacity:  # grow early, before it overflows
+                elif worst * 1.5 > capacity:  # grow early, before it overflows
                     self.set(key, worst)
             else:
                 still.append((ev, host, capacity, key))
