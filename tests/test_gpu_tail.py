@@ -124,3 +124,60 @@ def test_tail_conv_kernels_match_torch(B, h, w, CH, E, wB):
     g_ref = torch.autograd.grad((ref * up).sum(), [x, weff, bias])
     for n, a, b in zip(("x", "weff", "bias"), g_got, g_ref):
         assert rel_l2(a, b) < 1e-5, n
+
+
+def test_whole_decoder_gradients_fused_vs_unfused():
+    """Every decoder parameter (48 tensors) + albedo gets the same gradient through the fused tail as through the
+    layer-by-layer path, for a loss that goes through the renderer (10*L1 + 0.2*(1-SSIM)), slab 128 (16,384 Gaussians)."""
+    import math
+
+    from goliath_amd import decoder, losses, render_gs, shade, tail
+
+    torch.manual_seed(11)
+    dev = "cuda"
+    dec = decoder.PrimDecoderConvs(base=1).to(dev)
+    S = dec.slabsize
+    N, B, H, W = S * S, 2, 160, 128
+    with torch.no_grad():
+        for m in (dec.vnocond_mod[-1], dec.vcond_mod[-1]):
+            m.bias.normal_(0, 0.3)
+        dec.vnocond_mod[-1].bias[113 + 7:113 + 10] += 1.0   # softplus scale ~ 1.3
+    d = F.normalize(torch.randn(N, 3, device=dev), dim=-1)
+    pos = d * torch.rand(N, 1, device=dev) ** (1 / 3) * 40.0
+    postex = pos.t().reshape(1, 3, S, S).expand(B, -1, -1, -1).contiguous()
+    tn = F.normalize(pos, dim=-1).t().reshape(1, 3, S, S).expand(B, -1, -1, -1).contiguous()
+    albedo = torch.nn.Parameter(0.2 + 0.6 * torch.rand(1, N, 3, device=dev))
+    embs, campos = torch.randn(B, 256, device=dev), torch.tensor([[0.0, 0.0, -300.0], [60.0, 0.0, -290.0]], device=dev)
+    K = torch.tensor([[200.0, 0, W / 2], [0, 200.0, H / 2], [0, 0, 1]], device=dev).expand(B, -1, -1).contiguous()
+    Rt = torch.zeros(B, 3, 4, device=dev)
+    for b in range(B):
+        eye = campos[b]
+        fwd = -eye / eye.norm()
+        right = F.normalize(torch.linalg.cross(torch.tensor([0.0, 1.0, 0.0], device=dev), fwd), dim=0)
+        R = torch.stack([right, torch.linalg.cross(fwd, right), fwd])
+        Rt[b] = torch.cat([R, (-R @ eye)[:, None]], 1)
+    kw = dict(light_intensity=torch.rand(B, 3, 1, device=dev), headrel_light_pos=500 * torch.randn(B, 3, 3, device=dev),
+              n_lights=torch.full((B,), 3, dtype=torch.int32, device=dev))
+    light_sh = 0.3 * torch.randn(B, 3, 81, device=dev)
+    light_sh[:, :, 0] = 1.5
+    target = torch.rand(B, 3, H, W, device=dev)
+    params = list(dec.parameters()) + [albedo]
+
+    def grads(fused):
+        x_vn, x_vc = dec.trunk(embs, campos)
+        if fused:
+            preds = tail.fused_tail(dec.vnocond_mod[-1], dec.vcond_mod[-1], x_vn, x_vc, postex, tn, albedo, light_sh, campos, **kw)
+        else:
+            preds = shade.shading_tail(dec.vnocond_mod[-1](x_vn), dec.vcond_mod[-1](x_vc), postex, tn, albedo, light_sh,
+                                       campos, **kw)
+        rgb = render_gs.render_batch(K, Rt, preds, H, W)[0]
+        loss = 10.0 * losses.l1_image(rgb, target) + 0.2 * (1.0 - losses.ssim_image(rgb, target))
+        return float(loss.detach()), torch.autograd.grad(loss, params)
+
+    l0, g0 = grads(False)
+    l1, g1 = grads(True)
+    assert math.isfinite(l0) and abs(l0 - l1) < 1e-5 * max(1.0, abs(l0))
+    names = [n for n, _ in dec.named_parameters()] + ["albedo"]
+    for n, a, b in zip(names, g1, g0):
+        assert float(b.norm()) > 0, n
+        assert rel_l2(a, b) < 2e-3, n   # through the sign() of L1 and float atomics: looser than the per-kernel bound
