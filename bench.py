@@ -544,6 +544,8 @@ def main():
     if args.workload != "rgca":
         return {"mvp": mvp_main, "urhand": urhand_main, "sg": sg_main, "e2e": e2e_main}[args.workload](args)
     cfg = dict(CFG, views_per_gpu=args.views)
+    while args.views % args.micro:  # micro-batches must divide the views of a rank
+        args.micro -= 1
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
