@@ -15,7 +15,6 @@ Python-level hot spots of ca_code.models.rgca for their fused equivalents (same 
 import sys
 import types
 
-import torch
 
 
 def install():
@@ -45,3 +44,32 @@ def patch_rgca(rgca_module=None):
     rgca_module.AutoEncoder.render = fused.autoencoder_render
     rgca_module.PrimDecoder.forward = fused.prim_decoder_forward
     return rgca_module
+
+
+def patch_losses(registry_module=None):
+    """Re-register the image losses of the reference's loss registry (ca_code/loss/registry.py:59-79; rgb_l1 and
+    rgb_ssim, ca_code/loss/__init__.py:391-411, 478-494) with the fused HIP versions, so a `ModularLoss` built from the
+    unchanged config picks them up.  Call after `import ca_code.loss` and before constructing the loss."""
+    from . import losses
+
+    if registry_module is None:
+        import ca_code.loss  # noqa: F401  (registers the reference's own functions first)
+        import ca_code.loss.registry as registry_module
+
+    def factory(fn):
+        return lambda assets=None, **function_args: registry_module.FnLoss(fn, function_args)
+
+    for name, fn in (("rgb_l1", losses.rgb_l1), ("rgb_ssim", losses.rgb_ssim)):
+        registry_module.loss_registry[name] = factory(fn)
+    return registry_module
+
+
+def patch_urhand(urhand_module=None):
+    """Swap the shadow-map lookup of the URHand model (`from ca_code.utils.shadowmap import get_shadow_map`,
+    ca_code/models/urhand.py:44, called at :415 and :503) for the fused PCF kernel."""
+    from . import shadowmap
+
+    if urhand_module is None:
+        import ca_code.models.urhand as urhand_module
+    urhand_module.get_shadow_map = shadowmap.get_shadow_map
+    return urhand_module

@@ -8,7 +8,6 @@ albedo parameter.  The decoder outputs are consumed in their native NCHW layout 
 import ctypes
 
 import torch
-import torch.nn.functional as F
 
 from . import _lib
 from ._lib import stream_ptr

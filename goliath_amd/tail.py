@@ -21,7 +21,6 @@ Autograd: the light contraction of the weights is torch linear algebra on small 
 weight_v / weight_g through the ordinary graph; x, the contracted weights and the untied bias get theirs from
 gol_tail_conv_bwd.
 """
-import ctypes
 
 import torch
 import torch.nn.functional as F

@@ -50,3 +50,29 @@ def test_reference_python_wrappers_import_on_top_of_the_shims():
             inspect.signature(ref_sg.evaluate_gaussian).parameters)
     finally:
         sys.path.remove(REF)
+
+
+def test_patch_losses_and_urhand_on_stand_in_modules():
+    """patch_losses / patch_urhand rebind by name; exercised on stand-ins (the reference's loss package needs
+    `addict` / `omegaconf`, which this image does not have)."""
+    import types
+
+    import torch
+
+    from goliath_amd import dropin, losses, shadowmap
+
+    class FnLoss(torch.nn.Module):  # same contract as ca_code/loss/registry.py:40-56
+        def __init__(self, fn, function_args):
+            super().__init__()
+            self.fn, self.extra_args = fn, function_args
+
+        def forward(self, preds, targets):
+            return self.fn(preds, targets, **self.extra_args)
+
+    reg = types.SimpleNamespace(loss_registry={"rgb_l1": "reference", "kl": "untouched"}, FnLoss=FnLoss)
+    assert dropin.patch_losses(reg) is reg
+    mod = reg.loss_registry["rgb_ssim"](None, src_key="rgb", tgt_key="image", mask_key="image_weight")
+    assert isinstance(mod, FnLoss) and mod.fn is losses.rgb_ssim and mod.extra_args["src_key"] == "rgb"
+    assert reg.loss_registry["rgb_l1"](None).fn is losses.rgb_l1 and reg.loss_registry["kl"] == "untouched"
+    ur = types.SimpleNamespace(get_shadow_map="reference")
+    assert dropin.patch_urhand(ur).get_shadow_map is shadowmap.get_shadow_map

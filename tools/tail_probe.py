@@ -3,7 +3,6 @@
 Usage: python tools/tail_probe.py [B] [h]"""
 import os
 import sys
-import time
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
