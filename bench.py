@@ -376,8 +376,8 @@ def e2e_main(args):
     """SURVEY 8d mode B at the reference-native size: 1024^2 = 1,048,576 Gaussians, 8 views of 2048x1334 per
     step, random-init decoder of the reference architecture (goliath_amd.decoder) -> shading tail -> render ->
     L1 + SSIM losses (rgca_example.yml:43-52) -> backward -> Adam step (torch.optim.Adam, lr 5e-4).  Geometry (postex / tn)
-    is synthetic input: the mesh -> uv rasteriser is outside the path.  --fused-tail folds the two last
-    transposed-conv layers into the shading kernel (SURVEY 8f #1)."""
+    is synthetic input: the mesh -> uv rasteriser is outside the path.  The two last transposed-conv layers run
+    light-contracted on gol_tail_conv_* (SURVEY 8f #1) unless --unfused-tail is given."""
     from goliath_amd import decoder, losses, parallel, render_gs, shade, splat
 
     cfg = dict(E2E_CFG, views_per_gpu=args.views)
@@ -537,7 +537,10 @@ def main():
                          "because per-call HIP events cannot be taken inside a captured graph")
     ap.add_argument("--workload", choices=["rgca", "mvp", "urhand", "sg", "e2e"], default="rgca",
                     help="rgca = the BASELINE metric (default); mvp = secondary BASELINE config 5 line")
-    ap.add_argument("--fused-tail", action="store_true", help="e2e: fold the last decoder layers into the shade kernel")
+    ap.add_argument("--fused-tail", action="store_true", default=True,
+                    help="e2e: light-contracted last decoder layers on gol_tail_conv_* (default)")
+    ap.add_argument("--unfused-tail", dest="fused_tail", action="store_false",
+                    help="e2e: last decoder layers as PyTorch/MIOpen transposed convs + bias adds (the reference's structure)")
     ap.add_argument("--no-ssim", action="store_true", help="e2e: L1 loss only (default: 10*L1 + 0.2*(1-SSIM))")
     ap.add_argument("--segments", action="store_true", help="e2e: also report per-segment times (adds a sync per step)")
     args = ap.parse_args()
