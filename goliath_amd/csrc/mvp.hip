@@ -278,6 +278,19 @@ __device__ __forceinline__ bool load_ray(const MarchArgs& a, int n, Ray& ray, fl
   return ray.live;
 }
 
+
+// |y|^e and |y|^(e-1) of the fade term exp(-fadescale * sum |y_i|^fadeexp) (primsampler.h:52-56).  The reference's models
+// use fadeexp = 8 (hand_mvp.py / render_raymarcher.py): three squarings instead of log2 + exp2 on the quarter-rate
+// transcendental unit; any other exponent takes the generic path.  `e8` is kernel-uniform.
+__device__ __forceinline__ float fade_pow(float ax, float e, bool e8) {
+  if (e8) { const float x2 = ax * ax, x4 = x2 * x2; return x4 * x4; }
+  return __powf(ax, e);
+}
+__device__ __forceinline__ float fade_pow_m1(float ax, float e, bool e8) {
+  if (e8) { const float x2 = ax * ax, x4 = x2 * x2; return x4 * x2 * ax; }
+  return __powf(ax, e - 1.f);
+}
+
 template <bool SHADOW>
 __global__ __launch_bounds__(256) void march_fwd_kernel(MarchArgs a, float* __restrict__ rayrgba,
                                                         float* __restrict__ raysat, float* __restrict__ shadow) {
@@ -312,8 +325,9 @@ __global__ __launch_bounds__(256) void march_fwd_kernel(MarchArgs a, float* __re
       const V3 y0 = xform_fwd(xf, primpos, primrot, primscale, k, ray.pos);
       const bool ev = ray.live && valid_pos(y0) && !sat && ray.t < ray.rt1 + 1e-5f;
       if (ev) {
-        const float fade = __expf(-a.fadescale * (__powf(fabsf(y0.x), a.fadeexp) + __powf(fabsf(y0.y), a.fadeexp) +
-                                                  __powf(fabsf(y0.z), a.fadeexp)));
+        const bool e8 = a.fadeexp == 8.f;
+        const float fade = __expf(-a.fadescale * (fade_pow(fabsf(y0.x), a.fadeexp, e8) + fade_pow(fabsf(y0.y), a.fadeexp, e8) +
+                                                  fade_pow(fabsf(y0.z), a.fadeexp, e8)));
         Tri q;
         tri_setup(q, a.TD, a.TH, a.TW, y0);
         const float4* tp = tplate + (size_t)k * vox;
@@ -407,7 +421,8 @@ __global__ __launch_bounds__(256) void march_bwd_kernel(MarchArgs a, const float
       for (int c = 0; c < 8; ++c) { cidx[c] = -1; cw[c] = 0.f; }
       if (ev) {
         const float ax = fabsf(y0.x), ay = fabsf(y0.y), az = fabsf(y0.z);
-        const float fade = __expf(-fs * (__powf(ax, fe) + __powf(ay, fe) + __powf(az, fe)));
+        const bool e8 = fe == 8.f;
+        const float fade = __expf(-fs * (fade_pow(ax, fe, e8) + fade_pow(ay, fe, e8) + fade_pow(az, fe, e8)));
         Tri q;
         tri_setup(q, a.TD, a.TH, a.TW, y0);
         const float4* tp = tplate + (size_t)k * vox;
@@ -429,8 +444,8 @@ __global__ __launch_bounds__(256) void march_bwd_kernel(MarchArgs a, const float
         accw += weight;
         // PrimSamplerTW::backward (primsampler.h:70-92)
         const float kf = -(fs * fe);
-        dLy = v3(kf * __powf(ax, fe - 1.f) * (y0.x > 0.f ? 1.f : -1.f), kf * __powf(ay, fe - 1.f) * (y0.y > 0.f ? 1.f : -1.f),
-                 kf * __powf(az, fe - 1.f) * (y0.z > 0.f ? 1.f : -1.f)) * (s3 * d3);
+        dLy = v3(kf * fade_pow_m1(ax, fe, e8) * (y0.x > 0.f ? 1.f : -1.f), kf * fade_pow_m1(ay, fe, e8) * (y0.y > 0.f ? 1.f : -1.f),
+                 kf * fade_pow_m1(az, fe, e8) * (y0.z > 0.f ? 1.f : -1.f)) * (s3 * d3);
         d3 *= fade;
         // trilinear backward (utils.h:619-770): position gradient here, template scatter below
         float gix = 0.f, giy = 0.f, giz = 0.f;
