@@ -280,15 +280,17 @@ __device__ __forceinline__ bool load_ray(const MarchArgs& a, int n, Ray& ray, fl
 
 
 // |y|^e and |y|^(e-1) of the fade term exp(-fadescale * sum |y_i|^fadeexp) (primsampler.h:52-56).  The reference's models
-// use fadeexp = 8 (hand_mvp.py / render_raymarcher.py): three squarings instead of log2 + exp2 on the quarter-rate
-// transcendental unit; any other exponent takes the generic path.  `e8` is kernel-uniform.
+// use fadeexp = 8 (hand_mvp.py / render_raymarcher.py): three squarings; any other exponent is exp2(e * log2|y|) on the
+// transcendental unit, which is what CUDA's __powf (the reference's -use_fast_math build) computes -- HIP's __powf
+// expands to the ~180-instruction double-float pow.  log2(0) = -inf gives 0 for e > 0.  `e8` is kernel-uniform.
+__device__ __forceinline__ float fast_pow(float ax, float e) { return __builtin_amdgcn_exp2f(e * __builtin_amdgcn_logf(ax)); }
 __device__ __forceinline__ float fade_pow(float ax, float e, bool e8) {
   if (e8) { const float x2 = ax * ax, x4 = x2 * x2; return x4 * x4; }
-  return __powf(ax, e);
+  return fast_pow(ax, e);
 }
 __device__ __forceinline__ float fade_pow_m1(float ax, float e, bool e8) {
   if (e8) { const float x2 = ax * ax, x4 = x2 * x2; return x4 * x2 * ax; }
-  return __powf(ax, e - 1.f);
+  return fast_pow(ax, e - 1.f);
 }
 
 template <bool SHADOW>
