@@ -482,7 +482,7 @@ __global__ __launch_bounds__(256) void march_bwd_kernel(MarchArgs a, const float
           const bool mine = ev && (cellkey == key);
           const unsigned long long grp = __ballot(mine);
           todo &= ~grp;
-          if (__builtin_popcountll(grp) >= 3) {
+          if (__builtin_popcountll(grp) >= 1) {
 #pragma unroll
             for (int c = 0; c < 8; ++c) {
               const int ic = __builtin_amdgcn_readlane(cidx[c], leader);
