@@ -25,6 +25,7 @@
 
 namespace {
 
+constexpr int kTgSlots = 48;  // hit-list slots with an LDS accumulator for the transform gradients (backward)
 constexpr int kMaxHits = 512;  // per wave (reference: per 32-lane warp, utils.h:993-1012)
 
 struct V3 { float x, y, z; };
@@ -382,10 +383,15 @@ __global__ __launch_bounds__(256) void march_bwd_kernel(MarchArgs a, const float
   __shared__ int s_list[4][kMaxHits];
   __shared__ int s_lo[4][kMaxHits];
   __shared__ int s_hi[4][kMaxHits];
+  // per-wave accumulators of the 15 transform-gradient sums of the first kTgSlots boxes of the hit list: every wave that
+  // crosses a box adds to the SAME 15 global addresses, and memory-side float atomics to one address serialise -- so
+  // they are issued once per (wave, box) at the end instead of once per (wave, box, step)
+  __shared__ float s_tg[4][kTgSlots][16];
   const int n = blockIdx.z;
   const int lane = threadIdx.x & 63;
   Ray ray; float tmin, tmax; size_t r; int wave;
   load_ray(a, n, ray, tmin, tmax, r, wave);
+  for (int i = lane; i < kTgSlots * 16; i += 64) (&s_tg[wave][0][0])[i] = 0.f;
   const size_t vox = (size_t)a.TD * a.TH * a.TW;
   const float* primpos = a.primpos + (size_t)n * a.K * 3;
   const float* primrot = a.primrot + (size_t)n * a.K * 9;
@@ -514,17 +520,36 @@ __global__ __launch_bounds__(256) void march_bwd_kernel(MarchArgs a, const float
       if ((lane & 15) == 15) {
         const int j = lane >> 4;  // 0..3: which of the four sums this lane holds
         // r0: scale.x scale.y scale.z pos.x | r1: pos.y pos.z rot[0] rot[1] | r2: rot[2..5] | r3: rot[6..8]
-        float* p0 = (j < 3) ? (g_scale + 3 * k + j) : (g_pos + 3 * k);
-        atomicAdd(p0, r0);
-        float* p1 = (j < 2) ? (g_pos + 3 * k + 1 + j) : (g_rot + 9 * k + (j - 2));
-        atomicAdd(p1, r1);
-        atomicAdd(g_rot + 9 * k + 2 + j, r2);
-        if (j < 3) atomicAdd(g_rot + 9 * k + 6 + j, r3);
+        if (s < kTgSlots) {  // wave-private LDS slot (in-order LDS ops of one wave: plain read-modify-write)
+          float* t = &s_tg[wave][s][j];
+          t[0] += r0; t[4] += r1; t[8] += r2; t[12] += r3;
+        } else {
+          float* p0 = (j < 3) ? (g_scale + 3 * k + j) : (g_pos + 3 * k);
+          atomicAdd(p0, r0);
+          float* p1 = (j < 2) ? (g_pos + 3 * k + 1 + j) : (g_rot + 9 * k + (j - 2));
+          atomicAdd(p1, r1);
+          atomicAdd(g_rot + 9 * k + 2 + j, r2);
+          if (j < 3) atomicAdd(g_rot + 9 * k + 6 + j, r3);
+        }
       }
     }
     ray.t += a.stepsize;
     ray.pos = ray.pos + ray.dir * a.stepsize;
     ++iter;
+  }
+  // flush: 4 boxes per wave-instruction, lane = (box, component); component order = [scale 0-2 | pos 3-5 | rot 6-14 | -]
+  __builtin_amdgcn_wave_barrier();
+  const int nflush = min(num, kTgSlots);
+  for (int s0 = 0; s0 < nflush; s0 += 4) {
+    const int s = s0 + (lane >> 4), i = lane & 15;
+    if (s < nflush && i < 15) {
+      const float v = s_tg[wave][s][i];
+      if (v != 0.f) {
+        const int k = s_list[wave][s];
+        float* dst = i < 3 ? g_scale + 3 * k + i : (i < 6 ? g_pos + 3 * k + (i - 3) : g_rot + 9 * k + (i - 6));
+        atomicAdd(dst, v);
+      }
+    }
   }
 }
 
