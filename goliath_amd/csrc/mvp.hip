@@ -488,24 +488,19 @@ __global__ __launch_bounds__(256) void march_bwd_kernel(MarchArgs a, const float
           const bool mine = ev && (cellkey == key);
           const unsigned long long grp = __ballot(mine);
           todo &= ~grp;
-          if (__builtin_popcountll(grp) >= 1) {
+          // always reduce (even a one-lane group): memory-side atomics, not instructions, are the cost.  The two
+          // x-neighbour corners of a pair are adjacent 16-byte voxel records, so lanes 14|15 of every DPP row issue them
+          // together: one request covers both corners whenever they share a cache line.
 #pragma unroll
-            for (int c = 0; c < 8; ++c) {
-              const int ic = __builtin_amdgcn_readlane(cidx[c], leader);
-              if (ic < 0) continue;
-              const float wv = mine ? cw[c] : 0.f;
-              const float rsum = gol_wave_sum4(wv * sd0, wv * sd1, wv * sd2, wv * sd3);
-              if ((lane & 15) == 15) atomicAdd(gt + (size_t)ic * 4 + (lane >> 4), rsum);
-            }
-          } else if (mine) {
-#pragma unroll
-            for (int c = 0; c < 8; ++c) {
-              if (cidx[c] >= 0) {
-                float* g = gt + (size_t)cidx[c] * 4;
-                atomicAdd(g, cw[c] * sd0); atomicAdd(g + 1, cw[c] * sd1); atomicAdd(g + 2, cw[c] * sd2);
-                atomicAdd(g + 3, cw[c] * sd3);
-              }
-            }
+          for (int c = 0; c < 8; c += 2) {
+            const int i0 = __builtin_amdgcn_readlane(cidx[c], leader), i1 = __builtin_amdgcn_readlane(cidx[c + 1], leader);
+            if (i0 < 0 && i1 < 0) continue;
+            const float w0 = mine ? cw[c] : 0.f, w1 = mine ? cw[c + 1] : 0.f;
+            const float ra = gol_wave_sum4(w0 * sd0, w0 * sd1, w0 * sd2, w0 * sd3);   // lanes 15, 31, 47, 63
+            const float rb = gol_dpp_mov0<0x101>(gol_wave_sum4(w1 * sd0, w1 * sd1, w1 * sd2, w1 * sd3));  // row_shl:1 -> 14, 30, ..
+            const int l15 = lane & 15;
+            const int idx = (l15 == 15) ? i0 : i1;
+            if (l15 >= 14 && idx >= 0) atomicAdd(gt + (size_t)idx * 4 + (lane >> 4), (l15 == 15) ? ra : rb);
           }
         }
       }
