@@ -177,7 +177,7 @@ __global__ __launch_bounds__(256) void tail_conv_fwd_kernel(TAIL_FWD_ARGS) {
 
 #define TAIL_BWD_ARGS const TailDims p, const float* __restrict__ px, const float* __restrict__ pwt, \
                       const float* __restrict__ plc, const float* __restrict__ pg, float* __restrict__ pgx, \
-                      float* __restrict__ pgw, float* __restrict__ pgbias
+                      float* __restrict__ pgw, float* __restrict__ pgbias, float* __restrict__ pscratch
 
 // gx[b,ci,iy,ix] = sum_{ch,dy,dx} g[b,ch,2iy-1+dy,2ix-1+dx] * w[b,ci,ch,dy,dx];  wt = w as [wB,CH,4,4,16]
 __global__ __launch_bounds__(256) void tail_conv_bwd_x_kernel(TAIL_BWD_ARGS) {
@@ -325,12 +325,36 @@ __global__ __launch_bounds__(256) void tail_conv_bwd_w_kernel(TAIL_BWD_ARGS) {
     }
     __syncthreads();
   }
+  if (pscratch) {
+    // per-workgroup partials [B][NT][NBLK][16 taps][256 = ci*16 + ch_local], summed by tail_conv_bwd_w_reduce_kernel:
+    // hundreds of workgroups adding to the same few thousand addresses with memory-side float atomics cost up to
+    // half of this kernel
+    float* dst = pscratch + ((((size_t)b * gridDim.y + nt) * gridDim.x + blockIdx.x) * 16) * 256 + threadIdx.x;
+#pragma unroll
+    for (int tap = 0; tap < 16; ++tap) dst[(size_t)tap * 256] = s_red[tap][threadIdx.x];
+    return;
+  }
   const int ci = threadIdx.x >> 4, cj = nt * 16 + (threadIdx.x & 15);
   if (cj < CH) {
     float* dst = pgw + (((size_t)(p.wB == 1 ? 0 : b) * kCi + ci) * CH + cj) * 16;
 #pragma unroll
     for (int tap = 0; tap < 16; ++tap) atomicAdd(dst + tap, s_red[tap][threadIdx.x]);
   }
+}
+
+// gw[wb,ci,ch,tap] += sum over workgroups (and over views when the weights are shared) of the partials
+__global__ __launch_bounds__(256) void tail_conv_bwd_w_reduce_kernel(const TailDims p, int NT, int NBLK,
+                                                                     const float* __restrict__ scratch,
+                                                                     float* __restrict__ gw) {
+  const int tap = blockIdx.x, nt = blockIdx.y, b = blockIdx.z;
+  const int ci = threadIdx.x >> 4, cj = nt * 16 + (threadIdx.x & 15);
+  if (cj >= p.CH) return;
+  const float* src = scratch + ((((size_t)b * NT + nt) * NBLK) * 16 + tap) * 256 + threadIdx.x;
+  float acc = 0.f;
+#pragma unroll 8
+  for (int k = 0; k < NBLK; ++k) acc += src[(size_t)k * 16 * 256];
+  if (p.wB == 1) atomicAdd(gw + (((size_t)ci) * p.CH + cj) * 16 + tap, acc);  // shared weights: B adds per address
+  else gw[(((size_t)b * kCi + ci) * p.CH + cj) * 16 + tap] += acc;
 }
 
 // gbias[k,n] = sum_{b,e} lc[k,b,e] g[b,e,n]  (k < nd);  gbias[nd+j,n] = sum_b g[b,E+j,n]
@@ -425,9 +449,20 @@ extern "C" int gol_tail_conv_fwd(int B, int Ci, int h, int w, int CH, int E, int
   return GOL_OK;
 }
 
+static int bwd_w_blocks(int B, int h, int w, int CH) {
+  const int ntiles = h * gol_cdiv(w, kWTile), ntile_ch = gol_cdiv(CH, 16);
+  int nblk = gol_cdiv(768, (long long)ntile_ch * (B > 0 ? B : 1));  // ~3 workgroups per CU
+  return nblk < 1 ? 1 : (nblk > ntiles ? ntiles : nblk);
+}
+
+extern "C" long long gol_tail_conv_bwd_scratch_floats(int B, int h, int w, int CH) {
+  if (B <= 0 || h <= 0 || w <= 0 || CH <= 0) return 0;
+  return (long long)B * gol_cdiv(CH, 16) * bwd_w_blocks(B, h, w, CH) * 16 * 256;
+}
+
 extern "C" int gol_tail_conv_bwd(int B, int Ci, int h, int w, int CH, int E, int nd, int wB, const float* x,
                                  const float* weff_t, const float* lc, const float* g_out, float* g_x, float* g_weff,
-                                 float* g_bias, void* stream) {
+                                 float* g_bias, float* w_scratch, void* stream) {
   const int rc = check_common(B, Ci, h, w, CH, E, nd, wB);
   if (rc != GOL_OK) return rc;
   if (B == 0) return GOL_OK;
@@ -438,21 +473,23 @@ extern "C" int gol_tail_conv_bwd(int B, int Ci, int h, int w, int CH, int E, int
   const TailDims p{B, h, w, CH, E, nd, wB};
   hipStream_t s = (hipStream_t)stream;
   if (g_x) {
-    tail_conv_bwd_x_kernel<<<dim3(gol_cdiv(w, 256), h, B), 256, 0, s>>>(p, x, weff_t, lc, g_out, g_x, g_weff, g_bias);
+    tail_conv_bwd_x_kernel<<<dim3(gol_cdiv(w, 256), h, B), 256, 0, s>>>(p, x, weff_t, lc, g_out, g_x, g_weff, g_bias, nullptr);
     GOL_CHECK_LAUNCH();
   }
   if (g_weff) {
-    const int ntiles = h * gol_cdiv(w, kWTile), ntile_ch = gol_cdiv(CH, 16);
-    int nblk = gol_cdiv(768, (long long)ntile_ch * B);  // ~3 workgroups per CU; each ends with 4096 atomics
-    nblk = nblk < 1 ? 1 : (nblk > ntiles ? ntiles : nblk);
-    tail_conv_bwd_w_kernel<<<dim3(nblk, ntile_ch, B), 256, 0, s>>>(p, x, weff_t, lc, g_out, g_x, g_weff, g_bias);
+    const int ntile_ch = gol_cdiv(CH, 16), nblk = bwd_w_blocks(B, h, w, CH);
+    tail_conv_bwd_w_kernel<<<dim3(nblk, ntile_ch, B), 256, 0, s>>>(p, x, weff_t, lc, g_out, g_x, g_weff, g_bias, w_scratch);
     GOL_CHECK_LAUNCH();
+    if (w_scratch) {
+      tail_conv_bwd_w_reduce_kernel<<<dim3(16, ntile_ch, B), 256, 0, s>>>(p, ntile_ch, nblk, w_scratch, g_weff);
+      GOL_CHECK_LAUNCH();
+    }
   }
   if (g_bias) {
     const dim3 grid(gol_cdiv((long long)2 * h * w, 256));
-    if (E == 0) tail_bias_bwd_kernel<0><<<grid, 256, 0, s>>>(p, x, weff_t, lc, g_out, g_x, g_weff, g_bias);
-    else if (E == 3) tail_bias_bwd_kernel<3><<<grid, 256, 0, s>>>(p, x, weff_t, lc, g_out, g_x, g_weff, g_bias);
-    else tail_bias_bwd_kernel<6><<<grid, 256, 0, s>>>(p, x, weff_t, lc, g_out, g_x, g_weff, g_bias);
+    if (E == 0) tail_bias_bwd_kernel<0><<<grid, 256, 0, s>>>(p, x, weff_t, lc, g_out, g_x, g_weff, g_bias, nullptr);
+    else if (E == 3) tail_bias_bwd_kernel<3><<<grid, 256, 0, s>>>(p, x, weff_t, lc, g_out, g_x, g_weff, g_bias, nullptr);
+    else tail_bias_bwd_kernel<6><<<grid, 256, 0, s>>>(p, x, weff_t, lc, g_out, g_x, g_weff, g_bias, nullptr);
     GOL_CHECK_LAUNCH();
   }
   return GOL_OK;

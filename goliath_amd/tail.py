@@ -22,6 +22,8 @@ weight_v / weight_g through the ordinary graph; x, the contracted weights and th
 gol_tail_conv_bwd.
 """
 
+import ctypes
+
 import torch
 import torch.nn.functional as F
 
@@ -57,10 +59,15 @@ class _TailConv(torch.autograd.Function):
         g_w = torch.zeros_like(weff) if need_w else None
         g_b = torch.empty(bshape, device=x.device) if need_b else None
         wt = weff.permute(0, 2, 3, 4, 1).contiguous() if need_x else None   # [wB,CH,4,4,16]
+        scratch = None
+        if need_w:  # per-workgroup partial sums of the weight gradient (reduced by a second kernel: no float atomics)
+            fn = _lib.load().gol_tail_conv_bwd_scratch_floats
+            fn.restype = ctypes.c_longlong
+            scratch = torch.empty(int(fn(c_int(B), c_int(h), c_int(w), c_int(CH))), device=x.device)
         with torch.cuda.device(x.device):
             _lib.call("gol_tail_conv_bwd", c_int(B), c_int(Ci), c_int(h), c_int(w), c_int(CH), c_int(E), c_int(nd),
                       c_int(wB), fptr(x, "x"), fptr(wt, "weff_t"), fptr(lc, "lc"), fptr(g, "g_out"), fptr(g_x),
-                      fptr(g_w), fptr(g_b), stream_ptr())
+                      fptr(g_w), fptr(g_b), fptr(scratch), stream_ptr())
         return g_x, g_w, None, g_b
 
 

@@ -304,13 +304,17 @@ int gol_l1_bwd(int B, int C, int HW, int mask_c, const float* pred, const float*
  *   bias [nd + CH - E, 2h, 2w]; out [B,CH,2h,2w].
  * bwd (any of g_x / g_weff / g_bias may be NULL = not wanted):
  *   g_x [B,16,h,w] written; needs weff_t = weff permuted to [wB,CH,4,4,16];
- *   g_weff [wB,16,CH,4,4] ACCUMULATES (caller zeroes), fp32 MFMA + float atomics; needs x;
+ *   g_weff [wB,16,CH,4,4] ACCUMULATES (caller zeroes), fp32 MFMA; needs x; w_scratch (optional, see below) avoids atomics;
  *   g_bias [nd + CH - E, 2h, 2w] written.
  * ---------------------------------------------------------------------------------------- */
 int gol_tail_conv_fwd(int B, int Ci, int h, int w, int CH, int E, int nd, int wB, const float* x, const float* weff,
                       const float* lc, const float* bias, float* out, void* stream);
 int gol_tail_conv_bwd(int B, int Ci, int h, int w, int CH, int E, int nd, int wB, const float* x, const float* weff_t,
-                      const float* lc, const float* g_out, float* g_x, float* g_weff, float* g_bias, void* stream);
+                      const float* lc, const float* g_out, float* g_x, float* g_weff, float* g_bias, float* w_scratch,
+                      void* stream);
+/* floats of optional scratch for g_weff: with it the per-workgroup partial sums are written out and reduced by a second
+ * kernel instead of being added with float atomics (NULL = atomics). */
+long long gol_tail_conv_bwd_scratch_floats(int B, int h, int w, int CH);
 
 /* ------------------------------------------------------------------------------------------
  * SSIM image loss ("next" row).  Replaces `ssim` / `_ssim`

@@ -37,10 +37,11 @@ def main():
         out = torch.empty(B, CH, 2 * h, 2 * w, device=dev)
         g = torch.randn_like(out)
         gx, gw, gb = torch.empty_like(x), torch.zeros_like(weff), torch.empty_like(bias)
+        scratch = torch.empty(8 * 2 * 768 * 4096 // 8, device=dev)
         dims = (c_int(B), c_int(16), c_int(h), c_int(w), c_int(CH), c_int(E), c_int(nd), c_int(wB))
         fwd = lambda: _lib.call("gol_tail_conv_fwd", *dims, fptr(x), fptr(weff), fptr(lc), fptr(bias), fptr(out), stream_ptr())
         bwd = lambda a, b2, c: (lambda: _lib.call("gol_tail_conv_bwd", *dims, fptr(x), fptr(wt), fptr(lc), fptr(g), fptr(a),
-                                                  fptr(b2), fptr(c), stream_ptr()))
+                                                  fptr(b2), fptr(c), fptr(scratch if b2 is not None else None), stream_ptr()))
         N = 4 * h * w
         print(f"CH={CH} E={E} B={B} N={N}: fwd {timed(fwd):.3f} ms | bwd_x {timed(bwd(gx, None, None)):.3f} | "
               f"bwd_w {timed(bwd(None, gw, None)):.3f} | bwd_bias {timed(bwd(None, None, gb)):.3f} ms", flush=True)
