@@ -531,10 +531,11 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--views", type=int, default=CFG["views_per_gpu"])
     ap.add_argument("--micro", type=int, default=2, help="micro-batches (HIP streams) per step")
-    ap.add_argument("--graph", action="store_true",
-                    help="time replays of the step captured as one HIP graph instead of eager launches (+3 %%: the ~120 "
-                         "launches of a step cost the host almost as long as the GPU needs to run them).  Not the default "
-                         "because per-call HIP events cannot be taken inside a captured graph")
+    ap.add_argument("--no-graph", action="store_true",
+                    help="time eager launches instead of replays of the step captured as one HIP graph.  The ~120 launches "
+                         "of a step cost the host almost as long as the GPU needs to run them, so the eager number moves "
+                         "with host load (1.7-2.2 k views/s observed); replay is host-independent.  Per-call HIP events "
+                         "cannot be taken inside a graph: they come from an eager pass right after the timed replays")
     ap.add_argument("--workload", choices=["rgca", "mvp", "urhand", "sg", "e2e"], default="rgca",
                     help="rgca = the BASELINE metric (default); mvp = secondary BASELINE config 5 line")
     ap.add_argument("--fused-tail", action="store_true", default=True,
@@ -582,7 +583,7 @@ def main():
         run_step(t, cfg, world)
     barrier()
     graph = None
-    if args.graph:
+    if not args.no_graph:
         # The step is ~60 launches per micro-batch; issued from Python they cost about as much host time as the GPU
         # needs to execute them.  Capture the whole compute step (both streams, forward + backward) in ONE HIP graph
         # and replay it: the timed loop is then launch-overhead-free.  Capacities are frozen at their calibrated
