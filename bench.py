@@ -592,7 +592,8 @@ def main():
         splat.PLANNER.frozen = True
         try:
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
+            # thread_local: other threads (e.g. the RCCL watchdog of a multi-GPU run) may keep issuing HIP calls
+            with torch.cuda.graph(graph, capture_error_mode="thread_local"):
                 step(t, cfg, world)
             run_step(t, cfg, world, graph)  # one untimed replay
         except Exception as e:  # capture is an optimisation: fall back to eager issue
