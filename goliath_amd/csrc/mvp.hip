@@ -301,6 +301,7 @@ __global__ __launch_bounds__(256) void march_fwd_kernel(MarchArgs a, float* __re
   __shared__ int s_lo[4][kMaxHits];
   __shared__ int s_hi[4][kMaxHits];
   const int n = blockIdx.z;
+  const int lane = threadIdx.x & 63;
   Ray ray; float tmin, tmax; size_t r; int wave;
   load_ray(a, n, ray, tmin, tmax, r, wave);
   const size_t vox = (size_t)a.TD * a.TH * a.TW;
@@ -327,6 +328,9 @@ __global__ __launch_bounds__(256) void march_fwd_kernel(MarchArgs a, float* __re
       Xform xf;
       const V3 y0 = xform_fwd(xf, primpos, primrot, primscale, k, ray.pos);
       const bool ev = ray.live && valid_pos(y0) && !sat && ray.t < ray.rt1 + 1e-5f;
+      // shadow splat state of this lane (filled inside the branch, scattered wave-wide after it)
+      int sh_idx[SHADOW ? 8 : 1], sh_key = -1;
+      float sh_w[SHADOW ? 8 : 1], sh_vis = 0.f;
       if (ev) {
         const bool e8 = a.fadeexp == 8.f;
         const float fade = __expf(-a.fadescale * (fade_pow(fabsf(y0.x), a.fadeexp, e8) + fade_pow(fabsf(y0.y), a.fadeexp, e8) +
@@ -344,15 +348,10 @@ __global__ __launch_bounds__(256) void march_fwd_kernel(MarchArgs a, float* __re
         }
         s3 *= fade;
         if (SHADOW) {
-          const float vis = 1.f - acc3;
-          float* sp = shadow_n + (size_t)k * vox * 2;
+          sh_vis = 1.f - acc3;
+          sh_key = ((q.z0 + 1) * (a.TH + 1) + (q.y0 + 1)) * (a.TW + 1) + (q.x0 + 1);
 #pragma unroll
-          for (int c = 0; c < 8; ++c) {
-            if (q.idx[c] >= 0) {
-              atomicAdd(sp + (size_t)q.idx[c] * 2, q.w[c] * vis);
-              atomicAdd(sp + (size_t)q.idx[c] * 2 + 1, q.w[c]);
-            }
-          }
+          for (int c = 0; c < 8; ++c) { sh_idx[c] = q.idx[c]; sh_w[c] = q.w[c]; }
         }
         // PrimAccumAdditive::forward_prim (primaccum.h:63-79)
         const float newalpha = acc3 + s3 * a.stepsize;
@@ -361,6 +360,28 @@ __global__ __launch_bounds__(256) void march_fwd_kernel(MarchArgs a, float* __re
         if (newalpha >= 1.f) {
           if (!sat) { sat0 = s0; sat1 = s1; sat2 = s2; }
           sat = true;
+        }
+      }
+      if (SHADOW) {
+        // PrimSplatterTW (primsplatter.h): (w * visibility, w) into the 8 corner voxels.  Like the template gradient of
+        // the backward: group the wave's lanes by voxel cell, reduce each group, and let lanes 15|31 (corner c) and 47|63
+        // (corner c+1) issue ONE pair of atomics per (cell, corner) -- memory-side float atomics per lane are the cost.
+        float* sp = shadow_n + (size_t)k * vox * 2;
+        unsigned long long todo = __ballot(ev);
+        while (todo) {
+          const int leader = __builtin_ctzll(todo);
+          const int key = __builtin_amdgcn_readlane(sh_key, leader);
+          const bool mine = ev && (sh_key == key);
+          todo &= ~__ballot(mine);
+#pragma unroll
+          for (int c = 0; c < 8; c += 2) {
+            const int i0 = __builtin_amdgcn_readlane(sh_idx[c], leader), i1 = __builtin_amdgcn_readlane(sh_idx[c + 1], leader);
+            if (i0 < 0 && i1 < 0) continue;
+            const float w0 = mine ? sh_w[c] : 0.f, w1 = mine ? sh_w[c + 1] : 0.f;
+            const float rs = gol_wave_sum4(w0 * sh_vis, w0, w1 * sh_vis, w1);  // lanes 15, 31 | 47, 63
+            const int j = lane >> 4, idx = j < 2 ? i0 : i1;
+            if ((lane & 15) == 15 && idx >= 0) atomicAdd(sp + (size_t)idx * 2 + (j & 1), rs);
+          }
         }
       }
     }
