@@ -33,6 +33,8 @@ __global__ __launch_bounds__(256) void sg_fwd_kernel(
   const f3 pp = ld3(prim_pts, e);
   const float sigma = lobe_sigmas[e];
   const float inv_sigma = 1.f / sigma;
+  // lobe normalisation hoisted out of the light loop (one exact division per Gaussian instead of one per light)
+  const float norm = W_TYPE == 0 ? 1.f / (sigma * kSqrt2Pi23) : (W_TYPE == 2 ? 1.f / (sigma * kTwoPi) : 1.f);
   const int nL = n_lights[n];
   const float* lv = light_values + (size_t)n * L * 3;
   const float* lp = light_pts + (size_t)n * L * 3;
@@ -43,11 +45,11 @@ __global__ __launch_bounds__(256) void sg_fwd_kernel(
     const float c = fminf(1.f, fmaxf(-1.f, (lx * dir.x + ly * dir.y + lz * dir.z) * rn));
     float w;
     if (W_TYPE == 0) {
-      w = __expf(-0.5f * sqr(acosf(c) * inv_sigma)) / (sigma * kSqrt2Pi23);
+      w = __expf(-0.5f * sqr(acosf(c) * inv_sigma)) * norm;
     } else if (W_TYPE == 1) {
       w = __expf(-0.5f * sqr(acosf(c) * inv_sigma));
     } else if (W_TYPE == 2) {
-      w = __expf((c - 1.f) * inv_sigma) / (sigma * kTwoPi);
+      w = __expf((c - 1.f) * inv_sigma) * norm;
     } else {
       w = __expf((c - 1.f) * inv_sigma);
     }
@@ -72,6 +74,9 @@ __global__ __launch_bounds__(256) void sg_bwd_kernel(
   const f3 pp = ld3(prim_pts, e);
   const float sigma = lobe_sigmas[e];
   const float s2 = sigma * sigma;
+  // per-Gaussian reciprocals: the light loop multiplies (five exact divisions per light otherwise)
+  const float inv_sigma = 1.f / sigma, inv_s2 = 1.f / s2, inv_s3 = 1.f / (s2 * sigma), inv_s4 = 1.f / (s2 * s2);
+  const float norm0 = 1.f / (sigma * kSqrt2Pi23), norm2 = 1.f / (sigma * kTwoPi);
   const int nL = n_lights[n];
   const float* lv = light_values + (size_t)n * L * 3;
   const float* lp = light_pts + (size_t)n * L * 3;
@@ -87,28 +92,28 @@ __global__ __launch_bounds__(256) void sg_bwd_kernel(
     float weight, dc;
     if (W_TYPE == 0 || W_TYPE == 1) {
       const float angle = acosf(cc);
-      const float ex = __expf(-0.5f * sqr(angle / sigma));
+      const float ex = __expf(-0.5f * sqr(angle * inv_sigma));
       // sg.cu:129,139: d acos/dc = -1/sqrt(1-c^2) inside (-1,1), the constant -20 outside
-      const float dacos = (c > -1.f && c < 1.f) ? (-1.f / sqrtf(1.f - c * c)) : -20.f;
+      const float dacos = (c > -1.f && c < 1.f) ? -rsqrtf(1.f - c * c) : -20.f;
       if (W_TYPE == 0) {
-        weight = ex / (sigma * kSqrt2Pi23);
-        gs += dw * ((ex * kInvSqrt2Pi23 * (sqr(angle) - s2)) / (s2 * s2));
-        dc = dw * -((kInvSqrt2Pi23 * angle * ex) / (s2 * sigma)) * dacos;
+        weight = ex * norm0;
+        gs += dw * ((ex * kInvSqrt2Pi23 * (sqr(angle) - s2)) * inv_s4);
+        dc = dw * -((kInvSqrt2Pi23 * angle * ex) * inv_s3) * dacos;
       } else {
         weight = ex;
-        gs += dw * ((ex * sqr(angle)) / (sigma * s2));
-        dc = dw * -((angle * ex) / s2) * dacos;
+        gs += dw * ((ex * sqr(angle)) * inv_s3);
+        dc = dw * -((angle * ex) * inv_s2) * dacos;
       }
     } else {
-      const float ex = __expf((cc - 1.f) / sigma);
+      const float ex = __expf((cc - 1.f) * inv_sigma);
       if (W_TYPE == 2) {
-        weight = ex / (sigma * kTwoPi);
-        gs += dw * ((ex * kInv2Pi * ((1.f - cc) - sigma)) / (sigma * s2));
-        dc = dw * kInv2Pi * ex / s2;
+        weight = ex * norm2;
+        gs += dw * ((ex * kInv2Pi * ((1.f - cc) - sigma)) * inv_s3);
+        dc = dw * kInv2Pi * ex * inv_s2;
       } else {
         weight = ex;
-        gs += dw * ((ex * (1.f - cc) / s2));
-        dc = dw * ex / sigma;
+        gs += dw * ((ex * (1.f - cc) * inv_s2));
+        dc = dw * ex * inv_sigma;
       }
     }
     gx += dc * lx; gy += dc * ly; gz += dc * lz;

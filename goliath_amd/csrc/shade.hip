@@ -529,6 +529,7 @@ __global__ __launch_bounds__(256) void shade_bwd_kernel(const gol_shade_in in, c
         const float* lv = in.light_intensity + (size_t)b * in.L * 3;
         const float* lp = in.light_pos + (size_t)b * in.L * 3;
         const float sg = s.sigma, s2 = sg * sg;
+        const float inv_sg = 1.f / sg, inv_s3 = 1.f / (s2 * sg), inv_s4 = 1.f / (s2 * s2);  // per Gaussian, not per light
         float gx = 0.f, gy = 0.f, gz = 0.f, gs = 0.f;
         for (int l = 0; l < nL; ++l) {
           float dx = lp[3 * l] - s.pos[0], dy = lp[3 * l + 1] - s.pos[1], dz = lp[3 * l + 2] - s.pos[2];
@@ -537,11 +538,11 @@ __global__ __launch_bounds__(256) void shade_bwd_kernel(const gol_shade_in in, c
           const float c = dx * lx + dy * ly + dz * lz;
           const float cc = fminf(1.f, fmaxf(-1.f, c));
           const float angle = acosf(cc);
-          const float ex = __expf(-0.5f * (angle / sg) * (angle / sg));
+          const float ex = __expf(-0.5f * (angle * inv_sg) * (angle * inv_sg));
           const float dw = g_sraw[0] * lv[3 * l] + g_sraw[1] * lv[3 * l + 1] + g_sraw[2] * lv[3 * l + 2];
-          const float dacos = (c > -1.f && c < 1.f) ? (-1.f / sqrtf(1.f - c * c)) : -20.f;
-          gs += dw * ((ex * kInvSqrt2Pi23 * (angle * angle - s2)) / (s2 * s2));
-          const float dc = dw * -((kInvSqrt2Pi23 * angle * ex) / (s2 * sg)) * dacos;
+          const float dacos = (c > -1.f && c < 1.f) ? -rsqrtf(1.f - c * c) : -20.f;
+          gs += dw * ((ex * kInvSqrt2Pi23 * (angle * angle - s2)) * inv_s4);
+          const float dc = dw * -((kInvSqrt2Pi23 * angle * ex) * inv_s3) * dacos;
           gx += dc * dx; gy += dc * dy; gz += dc * dz;
         }
         g_sigma += gs;
