@@ -14,7 +14,7 @@ namespace {
 
 struct ShadowDims {
   int B, L, HW, dh, dw;
-  float fx, fy, cx, cy, exp_scale;
+  float fx, fy, cx, cy, exp_scale, inv_exp_scale;
   float wgt[9];  // exp(-((x-1)^2 + (y-1)^2) / (2 sigma^2)), index 3*x + y (shadowmap.py:73-77)
 };
 
@@ -44,7 +44,8 @@ __global__ __launch_bounds__(256) void shadow_pcf_kernel(const ShadowDims p, con
     const float Y = M[4] * px + M[5] * py + M[6] * pz + M[7];
     const float Z = M[8] * px + M[9] * py + M[10] * pz + M[11];
     // p_pix = p_cam @ K^T, then / depth  (geom.py:619-622)
-    const float u = (p.fx * X + p.cx * Z) / Z, v = (p.fy * Y + p.cy * Z) / Z;
+    const float iz = 1.f / Z;  // one exact division per (texel, light); everything below multiplies
+    const float u = (p.fx * X + p.cx * Z) * iz, v = (p.fy * Y + p.cy * Z) * iz;
     const float gx = (u - (float)p.dw / 2.0f - 0.5f) / ((float)p.dw / 2.0f);  // shadowmap.py:55-56
     const float gy = (v - (float)p.dh / 2.0f - 0.5f) / ((float)p.dh / 2.0f);
     const float* D = depth + bl * (size_t)p.dh * p.dw;
@@ -57,11 +58,11 @@ __global__ __launch_bounds__(256) void shadow_pcf_kernel(const ShadowDims p, con
         const bool in = ix >= 0 && ix < p.dw && iy >= 0 && iy < p.dh;
         const float d = D[(size_t)min(max(iy, 0), p.dh - 1) * p.dw + min(max(ix, 0), p.dw - 1)];
         const float dd = in ? d : 0.f;
-        const float w = dd > 0.f ? 1.f : 0.f;                    // sample of (depth > 0).float()
-        const float d2 = dd / (w + 1e-8f);
-        const float valid = p.wgt[3 * x + y] * (w > 1e-4f ? 1.f : 0.f);
+        // w = sample of (depth > 0).float() is 0 or 1: d / (w + 1e-8) is d itself when w = 1 (1 + 1e-8 == 1 in fp32) and
+        // is multiplied by valid = 0 when w = 0, so the division of shadowmap.py:82 drops out exactly
+        const float valid = dd > 0.f ? p.wgt[3 * x + y] : 0.f;
         vsum += valid;
-        ssum += valid * fmaxf(Z - d2, 0.f);
+        ssum += valid * fmaxf(Z - dd, 0.f);
       }
     float sh = ssum / (vsum + 1e-6f);
     if (nml) {
@@ -72,7 +73,7 @@ __global__ __launch_bounds__(256) void shadow_pcf_kernel(const ShadowDims p, con
       const float bc = 1.f / (1.f + expf(-10.f * nv));
       sh = bc * sh + (1.f - bc) * 1e3f;
     }
-    out[bl * p.HW + n] = p.exp_scale > 0.f ? expf(-sh / p.exp_scale) : sh;
+    out[bl * p.HW + n] = p.exp_scale > 0.f ? expf(-sh * p.inv_exp_scale) : sh;
   }
 }
 
@@ -88,6 +89,7 @@ extern "C" int gol_shadow_pcf(int B, int L, int H, int W, int dh, int dw, const 
   ShadowDims p;
   p.B = B; p.L = L; p.HW = H * W; p.dh = dh; p.dw = dw;
   p.fx = fx; p.fy = fy; p.cx = cx; p.cy = cy; p.exp_scale = exp_scale;
+  p.inv_exp_scale = exp_scale > 0.f ? 1.f / exp_scale : 0.f;
   const double sigma = 0.3 * ((3 - 1) * 0.5 - 1) + 0.8;  // shadowmap.py:66
   for (int x = 0; x < 3; ++x)
     for (int y = 0; y < 3; ++y)
