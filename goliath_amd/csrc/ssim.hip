@@ -164,7 +164,7 @@ __global__ __launch_bounds__(256) void ssim_fwd_kernel(int C, int H, int W, int 
         const float s11 = q[2] - m1 * m1, s22 = q[3] - m2 * m2, s12 = q[4] - m1 * m2;
         const float a1 = 2.f * m1 * m2 + kC1, a2 = 2.f * s12 + kC2;
         const float b1 = m1 * m1 + m2 * m2 + kC1, b2 = s11 + s22 + kC2;
-        const float ib = 1.f / (b1 * b2);
+        const float ib1 = __builtin_amdgcn_rcpf(b1), ib2 = __builtin_amdgcn_rcpf(b2), ib = ib1 * ib2;  // v_rcp_f32, 1 ulp
         const float f = a1 * a2 * ib;
         const size_t o = (size_t)gy * W + gx;
         float mk = 1.f;
@@ -173,8 +173,8 @@ __global__ __launch_bounds__(256) void ssim_fwd_kernel(int C, int H, int W, int 
         if (dmap) {
           // derivatives with the raw moments (mu2, E[y^2], E[xy]) as independent variables
           const float d_e12 = 2.f * a1 * ib;
-          const float d_e22 = -f / b2;
-          const float d_m2 = 2.f * m1 * a2 * ib - m1 * d_e12 - 2.f * m2 * f / b1 - 2.f * m2 * d_e22;
+          const float d_e22 = -f * ib2;
+          const float d_m2 = 2.f * m1 * a2 * ib - m1 * d_e12 - 2.f * m2 * f * ib1 - 2.f * m2 * d_e22;
           float* d = dmap + (size_t)bc * HW + o;
           d[0] = mk * d_m2; d[plane_total] = mk * d_e22; d[2 * plane_total] = mk * d_e12;
         }
