@@ -616,10 +616,14 @@ def main():
         splat.PLANNER.frozen = False
         # HIP events cannot bracket nodes inside a captured graph: the per-call durations come from an eager,
         # instrumented pass of the same K steps right after the timed replays (same buffers, same streams)
+        # (the micro-batches are issued on ONE stream here, so a call's events bracket that kernel sequence alone and the
+        # durations agree with rocprofv3's per-kernel trace; with two streams in flight they would include time-sharing)
+        streams, t["streams"] = t["streams"], [torch.cuda.current_stream()] * len(t["streams"])
         _lib.TIMING = []
         for _ in range(args.steps):
             run_step(t, cfg, world)
         barrier()
+        t["streams"] = streams
     timing, _lib.TIMING = _lib.TIMING, None
     splat.PLANNER.poll(block=True)  # raises if any step overflowed its intersection capacity
 
