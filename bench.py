@@ -147,7 +147,7 @@ def algorithmic_bytes(name, N, I, P, n_mips_bytes):
 def cpu_baseline(cfg):
     """Times the CPU oracle (a PORT: there is no reference CPU path for gsplat/sgutils) on ONE view of
     the same workload, forward + backward, on the host cores."""
-    from oracle import cref, shade_ref
+    from oracle import chain, cref
 
     threads = min(32, os.cpu_count() or 1)  # more threads only add contention on the atomics
     torch.set_num_threads(threads)
@@ -156,37 +156,13 @@ def cpu_baseline(cfg):
     for v in range(n_views):
         t = make_inputs(dict(cfg, views_per_gpu=1), "cpu", rank=v)
         t0 = time.perf_counter()
-        _cpu_view(t, cfg, cref, shade_ref)
+        chain.cpu_view(t, cfg["height"], cfg["width"])
         dt += time.perf_counter() - t0
     return {"value": n_views / dt, "unit": "views/s", "cores": threads, "kind": "port",
-            "sample": f"{n_views} full views (250k Gaussians, 2048x1334, env relight) fwd+bwd through oracle/ "
-                      f"(C + OpenMP projection/raster, torch shading tail) in {dt:.1f} s"}
-
-
-def _cpu_view(t, cfg, cref, shade_ref):
-    H, W = cfg["height"], cfg["width"]
-    preds = shade_ref.shade(t["f_vn"], t["f_vc"], t["postex"], t["tn"], t["albedo"], t["light_sh"], t["campos"],
-                            envmips=t["mips"], lightrot=t["lightrot"])
-    means, scales, quats = preds["primpos"][0].detach(), preds["primscale"][0].detach(), preds["primqvec"][0].detach()
-    K, vm = t["K"][0], t["Rt"][0]
-    fx, fy, cx, cy = float(K[0, 0]), float(K[1, 1]), float(K[0, 2]), float(K[1, 2])
-    xys, depths, radii, conics, comp, nth, cov3d = cref.project_gaussians(means, scales, 1.0, quats, vm, fx, fy, cx,
-                                                                           cy, H, W, 16, 0.1)
-    _, ids, bins = cref.bin_and_sort(xys, depths, radii, nth, H, W, 16)
-    opac = (preds["opacity"][0, :, 0].detach() * comp).contiguous()
-    col4 = torch.cat([preds["color"][0].detach(), depths[:, None]], 1).contiguous()  # colour + depth in one pass
-    bg = torch.zeros(4)
-    img, Ts, idx = cref.rasterize_forward(ids, bins, xys, conics, col4, opac, H, W, 16, bg)
-    v_out = torch.zeros(H, W, 4)
-    v_out[..., :3] = torch.sign(img[..., :3] - t["target"][0].permute(1, 2, 0)) / (3 * H * W)
-    v_xy, v_conic, v_col, v_op = cref.rasterize_backward(ids, bins, xys, conics, col4, opac, H, W, 16, bg, Ts, idx, v_out)
-    v_comp = v_op[:, 0] * preds["opacity"][0, :, 0].detach()
-    _, _, v_mean, v_scale, v_quat = cref.project_gaussians_backward(means, scales, 1.0, quats, vm, fx, fy, cov3d,
-                                                                    radii, conics, comp, v_xy, v_col[:, 3].contiguous(),
-                                                                    v_conic, v_comp)
-    (preds["primpos"][0] * v_mean).sum().add((preds["primscale"][0] * v_scale).sum()).add(
-        (preds["primqvec"][0] * v_quat).sum()).add((preds["color"][0] * v_col[:, :3]).sum()).add(
-        (preds["opacity"][0, :, 0] * v_op[:, 0] * comp).sum()).backward()
+            "sample": f"{n_views} full views (250k Gaussians, 2048x1334, env relight) fwd+bwd through oracle/chain.py "
+                      f"in {dt:.1f} s: C + OpenMP restatement of gsplat 0.1.11 project/bin/raster (no reference CPU path "
+                      f"exists for it) and oracle/shade_ref.py, the torch restatement of rgca.py:505-588 pinned to the "
+                      f"reference's own PrimDecoder.forward (/root/reference is not on the bench box)"}
 
 
 MVP_CFG = dict(workload="mvp_config5", prims=4096, tdim=(8, 16, 16), height=2048, width=1334, views_per_gpu=1,

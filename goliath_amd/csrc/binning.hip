@@ -12,6 +12,8 @@
 //     binning time (output-preserving, see tile_box) and the per-tile counters live in LDS during
 //     the two walks over the Gaussians, so hot tiles do not serialise on global atomics.
 // Traffic: 8 B written + 8 B read + 4 B written per intersection, everything else stays in LDS.
+#include <atomic>
+
 #include "gol_common.h"
 
 namespace {
@@ -432,6 +434,21 @@ __global__ __launch_bounds__(256) void sort_kernel(int T, int64_t capacity, int3
   }
 }
 
+// Largest dynamic-LDS size already granted to kernel `which` on the CURRENT device (the attribute is per device and
+// per function).  The only process-wide state of the library besides the last-error string: a monotone cache,
+// updated with atomics, so concurrent callers at worst repeat an idempotent hipFuncSetAttribute.
+bool lds_limit_needs_raise(int which, size_t bytes) {
+  constexpr int kMaxDev = 64;
+  static std::atomic<size_t> granted[2][kMaxDev];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDev) return true;
+  size_t cur = granted[which][dev].load(std::memory_order_relaxed);
+  if (cur == 0) cur = 48 * 1024;  // the default limit
+  if (bytes <= cur) return false;
+  granted[which][dev].store(bytes, std::memory_order_relaxed);
+  return true;
+}
+
 }  // namespace
 
 extern "C" int gol_bin_sort(int B, int N, const float* xys, const float* depths, const int32_t* radii,
@@ -471,11 +488,10 @@ extern "C" int gol_bin_sort(int B, int N, const float* xys, const float* depths,
   if (N > 0) {
     if (lds_path) {
       const size_t lds = sizeof(int32_t) * (size_t)T;
-      static size_t count_lds_max = 48 * 1024;  // raise the limit once per size (not a stream operation: keep it
-      if (lds > count_lds_max) {                // out of the steady state so the call sequence is graph-capturable)
+      // raise the dynamic-LDS limit once per (device, size): not a stream operation, so it is kept out of the
+      // steady state and the call sequence stays graph-capturable
+      if (lds_limit_needs_raise(0, lds))
         hipFuncSetAttribute((const void*)count_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        count_lds_max = lds;
-      }
       count_lds_kernel<<<dim3(nblk, B), 1024, lds, s>>>(a, tile_count);
     } else {
       count_kernel<<<dim3(gol_cdiv(N, 256), B), 256, 0, s>>>(a, tile_count);
@@ -485,11 +501,8 @@ extern "C" int gol_bin_sort(int B, int N, const float* xys, const float* depths,
   if (N > 0 && capacity > 0) {
     if (lds_path) {
       const size_t lds = sizeof(int32_t) * (size_t)T * 2;
-      static size_t scatter_lds_max = 48 * 1024;
-      if (lds > scatter_lds_max) {
+      if (lds_limit_needs_raise(1, lds))
         hipFuncSetAttribute((const void*)scatter_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        scatter_lds_max = lds;
-      }
       scatter_lds_kernel<<<dim3(nblk, B), 1024, lds, s>>>(a, capacity, tile_bins, isect_keys);
     } else {
       scatter_kernel<<<dim3(gol_cdiv(N, 256), B), 256, 0, s>>>(a, capacity, tile_bins, isect_keys);

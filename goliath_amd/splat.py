@@ -29,23 +29,31 @@ def _tiles(img_h, img_w, block=BLOCK):
 
 
 # --------------------------------------------------------------------------------------------
-# Intersection-capacity planning (replaces the host sync on the intersection count).
+# Intersection-capacity planning (replaces gsplat's host sync on the intersection count).
 # --------------------------------------------------------------------------------------------
 class CapacityPlanner:
-    """Per-shape capacity (max Gaussian/tile intersections per view) for the sync-free path.
+    """Per-shape capacity (max Gaussian/tile intersections per view) of the batched render path.
 
-    First call for a shape: one blocking calibration (reads the true count, sizes the buffers
-    with 100 % head-room).  Later calls: no sync; the true counts are copied to pinned host memory
-    asynchronously and inspected at the NEXT call -- an overflow then raises (the affected render
-    dropped intersections) after growing the capacity so a re-run succeeds.
-    Set GOLIATH_STRICT_CAPACITY=1 to verify every call synchronously.
+    mode "verify" (default): every render_views call launches the whole forward at the planned
+        capacity, then waits on an event recorded right after binning (the true counts land in a
+        pre-allocated pinned buffer).  The wait is normally free -- the raster kernels are still
+        queued behind it -- and if a view overflowed, binning + raster are re-run at a grown
+        capacity INSIDE the same call, in stream order, before any consumer can read the image.
+        No exception ever reaches the caller (ca_code/utils/train.py:170-214 knows none of ours).
+    mode "async": nothing waits; the counts are inspected at the NEXT call and an overflow raises
+        (after growing the capacity) -- for benchmark loops that must not block the host.
+    frozen: while a HIP graph is captured / replayed: no host copies; check_frozen() afterwards.
+    Capacities only grow (a stale, smaller observation never shrinks them).
     """
 
     def __init__(self):
         self.capacity = {}
-        self.pending = []  # (event, pinned counts, capacity, key)
+        self.mode = os.environ.get("GOLIATH_CAPACITY_MODE", "verify")
+        self.pending = []        # async mode: (event, pinned counts, capacity, key)
         self.frozen = False      # True while a HIP graph is captured / replayed: no polling, no host copies
         self.frozen_log = []     # (n_isect tensor, capacity) of the calls made while frozen -> check_frozen()
+        self.reruns = 0          # verify mode: forwards that had to be re-run at a grown capacity
+        self._pinned = {}        # B -> free list of pinned int32[B] buffers (allocated once, recycled)
 
     def check_frozen(self):
         """After graph replays: did any captured render overflow the capacity it was captured with?"""
@@ -55,25 +63,49 @@ class CapacityPlanner:
                 raise _lib.GoliathHipError(f"a captured render_views call overflowed its intersection capacity "
                                            f"({worst} > {capacity}): re-capture with a larger capacity")
 
-    def strict(self):
-        return os.environ.get("GOLIATH_STRICT_CAPACITY", "0") == "1"
+    def verify(self):
+        return self.mode != "async" or os.environ.get("GOLIATH_STRICT_CAPACITY", "0") == "1"
 
-    def get(self, key, N):
+    def get(self, key):
         return self.capacity.get(key)
 
     def initial(self, N, T):
         return int(min(2**31 - 1, max(1 << 16, 16 * N + T)))
 
     def set(self, key, counts_max):
-        # 2x head-room: during training the lists grow from step to step and the counts are read a few steps late
-        self.capacity[key] = int(min(2**31 - 1, max(1 << 16, int(counts_max * 2.0) + 4096)))
+        """Plan for `counts_max` intersections per view with 2x head-room (lists grow from step to step during
+        training); never shrinks an existing plan."""
+        want = int(min(2**31 - 1, max(1 << 16, int(counts_max * 2.0) + 4096)))
+        self.capacity[key] = max(self.capacity.get(key, 0), want)
         return self.capacity[key]
 
-    def note(self, key, n_isect, capacity):
-        host = torch.empty(n_isect.shape, dtype=torch.int32, pin_memory=True)
+    def observe(self, key, worst, capacity):
+        """Grow early, before it overflows."""
+        if key not in self.capacity or worst * 1.5 > capacity:
+            self.set(key, worst)
+
+    def _take_pinned(self, B):
+        free = self._pinned.setdefault(B, [])
+        return free.pop() if free else torch.empty(B, dtype=torch.int32, pin_memory=True)
+
+    def fetch(self, n_isect):
+        """Blocking read of the per-view counts through a recycled pinned buffer: waits only for the work queued
+        BEFORE this point of the current stream (binning), not for what the caller enqueued after it."""
+        B = n_isect.numel()
+        host = self._take_pinned(B)
         host.copy_(n_isect, non_blocking=True)
         ev = torch.cuda.Event()
         ev.record()
+        return host, ev
+
+    def finish(self, host, ev):
+        ev.synchronize()
+        worst = int(host.max()) if host.numel() else 0
+        self._pinned[host.numel()].append(host)
+        return worst
+
+    def note(self, key, n_isect, capacity):
+        host, ev = self.fetch(n_isect)
         self.pending.append((ev, host, capacity, key))
 
     def poll(self, block=False):
@@ -83,11 +115,12 @@ class CapacityPlanner:
                 ev.synchronize()
             if ev.query():
                 worst = int(host.max()) if host.numel() else 0
+                self._pinned[host.numel()].append(host)
                 if worst > capacity:
                     self.set(key, worst)
                     overflow = (worst, capacity, key)
-                elif worst * 1.5 > capacity:  # grow early, before it overflows
-                    self.set(key, worst)
+                else:
+                    self.observe(key, worst, capacity)
             else:
                 still.append((ev, host, capacity, key))
         self.pending = still
@@ -96,7 +129,7 @@ class CapacityPlanner:
             raise _lib.GoliathHipError(
                 f"a previous render_views call overflowed its intersection capacity ({worst} > {capacity}); "
                 f"its image is incomplete. Capacity was raised to {self.capacity[key]} -- re-run the step "
-                f"(or set GOLIATH_STRICT_CAPACITY=1).")
+                f"(GOLIATH_CAPACITY_MODE=verify, the default, recovers inside the call instead).")
 
 
 PLANNER = CapacityPlanner()
@@ -181,10 +214,12 @@ class _ProjectGaussians(torch.autograd.Function):
         v_scale = torch.empty_like(scales)
         v_quat = torch.empty_like(quats)
         c = lambda t: None if t is None else _f32c(t)
+        # converted gradients are bound to locals so they outlive the launch
+        g_xy, g_depth, g_conic, g_comp = c(v_xys), c(v_depths), c(v_conics), c(v_compensation)
         with torch.cuda.device(means3d.device):
             _lib.call("gol_project_bwd", c_int(1), c_int(N), fptr(means3d), fptr(scales), c_float(ctx.glob_scale),
                       fptr(quats), fptr(vm), fptr(intr), fptr(cov3d), iptr(radii), fptr(conics), fptr(comp),
-                      fptr(c(v_xys)), fptr(c(v_depths)), fptr(c(v_conics)), fptr(c(v_compensation)),
+                      fptr(g_xy), fptr(g_depth), fptr(g_conic), fptr(g_comp),
                       fptr(None), fptr(None), c_int(0), fptr(v_mean), fptr(v_scale), fptr(v_quat), fptr(None),
                       stream_ptr())
         return (v_mean, v_scale, None, v_quat) + (None,) * 9
@@ -254,12 +289,14 @@ class _RasterizeGaussians(torch.autograd.Function):
             H, W = ctx.dims
             ws = ctx.ws
             va = None if v_out_alpha is None else _f32c(v_out_alpha)
+            vo = _f32c(v_out_img)
             with torch.cuda.device(xys.device):
                 _lib.call("gol_rasterize_bwd", c_int(1), c_int(N), c_int(H), c_int(W), c_int(BLOCK), c_int(0),
                           iptr(ws.tile_bins), iptr(ws.sorted_ids), c_i64(ws.capacity), fptr(xys), fptr(conics),
                           fptr(colors), fptr(None), fptr(opacity), fptr(background), fptr(final_Ts),
-                          iptr(final_idx), fptr(_f32c(v_out_img)), fptr(None), fptr(va), fptr(v_xy),
+                          iptr(final_idx), fptr(vo), fptr(None), fptr(va), fptr(v_xy),
                           fptr(v_conic), fptr(v_colors), fptr(None), fptr(v_opacity), c_int(0), stream_ptr())
+            ctx.ws = None
         return (v_xy, None, None, v_conic, None, v_colors, v_opacity[:, None]) + (None,) * 5
 
 
@@ -296,16 +333,14 @@ def rasterize_gaussians(xys, depths, radii, conics, num_tiles_hit, colors, opaci
 class _RenderViews(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means, scales, quats, opacity, colors, viewmats, intrins, background, img_h, img_w,
-                glob_scale, clip_thresh, with_depth, capacity, depth_norm_lo):
+                glob_scale, clip_thresh, with_depth, capacity, depth_norm_lo, plan_key):
         B, N = means.shape[:2]
         dev = means.device
         T = _tiles(img_h, img_w)
-        ws = _Workspace(B, N, T, capacity, dev)
         with torch.cuda.device(dev):
             cov3d, xys, depths, radii, conics, comp, nth, opac_eff = _project_fwd(
                 B, N, means, scales, glob_scale, quats, viewmats, intrins, img_h, img_w, clip_thresh,
                 opacities=opacity)
-            _bin_sort(B, N, xys, depths, radii, img_h, img_w, ws, conics, opac_eff)
             out_img = torch.empty(B, 3, img_h, img_w, device=dev)  # planar, as the model consumes it
             out_depth = torch.empty(B, img_h, img_w, device=dev) if with_depth else None
             final_Ts = torch.empty(B, img_h, img_w, device=dev)
@@ -313,36 +348,60 @@ class _RenderViews(torch.autograd.Function):
             # alpha = 1 - T and depth / clamp(alpha, lo, 1) come out of the raster epilogue (rgca.py:137,144-145)
             alpha = torch.empty(B, img_h, img_w, device=dev)
             depth_norm = torch.empty(B, img_h, img_w, device=dev) if with_depth else None
-            _lib.call("gol_rasterize_fwd", c_int(B), c_int(N), c_int(img_h), c_int(img_w), c_int(BLOCK), c_int(1),
-                      iptr(ws.tile_bins), iptr(ws.sorted_ids), c_i64(ws.capacity), fptr(xys), fptr(conics),
-                      fptr(colors), fptr(depths if with_depth else None), fptr(opac_eff), fptr(background),
-                      fptr(out_img), fptr(out_depth), fptr(final_Ts), iptr(final_idx), fptr(alpha), fptr(depth_norm),
-                      c_float(depth_norm_lo), stream_ptr())
+
+            def bin_and_raster(cap):
+                ws = _Workspace(B, N, T, cap, dev)
+                _bin_sort(B, N, xys, depths, radii, img_h, img_w, ws, conics, opac_eff)
+                pending = PLANNER.fetch(ws.n_isect) if plan_key is not None and B > 0 else None
+                _lib.call("gol_rasterize_fwd", c_int(B), c_int(N), c_int(img_h), c_int(img_w), c_int(BLOCK), c_int(1),
+                          iptr(ws.tile_bins), iptr(ws.sorted_ids), c_i64(ws.capacity), fptr(xys), fptr(conics),
+                          fptr(colors), fptr(depths if with_depth else None), fptr(opac_eff), fptr(background),
+                          fptr(out_img), fptr(out_depth), fptr(final_Ts), iptr(final_idx), fptr(alpha),
+                          fptr(depth_norm), c_float(depth_norm_lo), stream_ptr())
+                return ws, pending
+
+            ws, pending = bin_and_raster(capacity)
+            if pending is not None:
+                # the counts were final after the tile scan; the raster is still queued behind this wait
+                worst = PLANNER.finish(*pending)
+                if worst > capacity:
+                    # some lists were truncated: grow and redo binning + raster into the SAME output buffers, in
+                    # stream order, before anything downstream can read them
+                    capacity = PLANNER.set(plan_key, worst)
+                    PLANNER.reruns += 1
+                    ws, pending = bin_and_raster(capacity)
+                    PLANNER.finish(*pending)
+                else:
+                    PLANNER.observe(plan_key, worst, capacity)
         ctx.ws = ws
         ctx.cfg = (img_h, img_w, glob_scale, with_depth, depth_norm_lo)
         ctx.save_for_backward(means, scales, quats, opacity, colors, viewmats, intrins, background, cov3d, xys,
                               depths, radii, conics, comp, opac_eff, final_Ts, final_idx)
-        ctx.alpha = alpha  # plain attribute (an output of the node)
-        ctx.mark_non_differentiable(radii, ws.n_isect, final_Ts)
+        ctx.mark_non_differentiable(radii, ws.n_isect, final_Ts, final_idx, ws.sorted_ids, ws.tile_bins)
         ctx.set_materialize_grads(False)
-        return out_img, alpha, out_depth, depth_norm, radii, ws.n_isect, final_Ts
+        return out_img, alpha, out_depth, depth_norm, radii, ws.n_isect, final_Ts, final_idx, ws.sorted_ids, ws.tile_bins
 
     @staticmethod
-    def backward(ctx, v_img, v_alpha, v_depth, v_depth_norm, _v_radii, _v_n, _v_T):
+    def backward(ctx, v_img, v_alpha, v_depth, v_depth_norm, *_non_differentiable):
         (means, scales, quats, opacity, colors, viewmats, intrins, background, cov3d, xys, depths, radii,
          conics, comp, opac_eff, final_Ts, final_idx) = ctx.saved_tensors
         img_h, img_w, glob_scale, with_depth, depth_norm_lo = ctx.cfg
         B, N = means.shape[:2]
         dev = means.device
         ws = ctx.ws
-        if v_depth_norm is not None:  # depth_norm = depth / clamp(alpha.detach(), lo, 1)
-            g = v_depth_norm / ctx.alpha.clamp(depth_norm_lo, 1.0)
+        if v_depth_norm is not None:  # depth_norm = depth / clamp(alpha.detach(), lo, 1), alpha = 1 - final_T
+            g = v_depth_norm / (1.0 - final_Ts).clamp(depth_norm_lo, 1.0)
             v_depth = g if v_depth is None else v_depth + g
         if v_img is None and v_alpha is None and v_depth is None:
-            return (None,) * 15
+            ctx.ws = None
+            return (None,) * 16
         if v_img is None:
             v_img = torch.zeros(B, 3, img_h, img_w, device=dev)
         use_depth = with_depth and v_depth is not None
+        # converted upstream gradients stay bound to locals until the launches below are issued
+        v_img_c = _f32c(v_img)
+        v_depth_c = _f32c(v_depth) if use_depth else None
+        v_alpha_c = None if v_alpha is None else _f32c(v_alpha)
         # one zeroed buffer of 64-byte gradient records per Gaussian (include/goliath_hip.h: GOL_GRAD_RECORD):
         # a Gaussian's float atomics hit one cache line and are issued by 16 adjacent lanes
         rec = torch.zeros(B, N, GRAD_RECORD, device=dev)
@@ -355,16 +414,16 @@ class _RenderViews(torch.autograd.Function):
             _lib.call("gol_rasterize_bwd", c_int(B), c_int(N), c_int(img_h), c_int(img_w), c_int(BLOCK), c_int(1),
                       iptr(ws.tile_bins), iptr(ws.sorted_ids), c_i64(ws.capacity), fptr(xys), fptr(conics),
                       fptr(colors), fptr(depths if use_depth else None), fptr(opac_eff), fptr(background),
-                      fptr(final_Ts), iptr(final_idx), fptr(_f32c(v_img)),
-                      fptr(_f32c(v_depth) if use_depth else None),
-                      fptr(None if v_alpha is None else _f32c(v_alpha)), field(4), field(6), field(0),
+                      fptr(final_Ts), iptr(final_idx), fptr(v_img_c), fptr(v_depth_c), fptr(v_alpha_c),
+                      field(4), field(6), field(0),
                       field(9) if use_depth else fptr(None), field(3), c_int(GRAD_RECORD), stream_ptr())
             _lib.call("gol_project_bwd", c_int(B), c_int(N), fptr(means), fptr(scales), c_float(glob_scale),
                       fptr(quats), fptr(viewmats), fptr(intrins), fptr(cov3d), iptr(radii), fptr(conics),
                       fptr(comp), field(4), field(9) if use_depth else fptr(None), field(6), fptr(None), fptr(opacity),
                       field(3), c_int(GRAD_RECORD), fptr(v_mean), fptr(v_scale), fptr(v_quat), fptr(v_opacity),
                       stream_ptr())
-        return (v_mean, v_scale, v_quat, v_opacity, rec[..., :3]) + (None,) * 10
+        ctx.ws = None  # the tile lists (the largest buffers of a step) go back to the allocator now
+        return (v_mean, v_scale, v_quat, v_opacity, rec[..., :3]) + (None,) * 11
 
 
 def render_views(means, scales, quats, opacity, colors, viewmats, intrins, img_h, img_w,
@@ -375,7 +434,9 @@ def render_views(means, scales, quats, opacity, colors, viewmats, intrins, img_h
     viewmats[B,3,4] (or [B,12]; world->camera, row-major), intrins[B,4] = (fx, fy, cx, cy)
     Returns dict(render[B,3,H,W], alpha[B,1,H,W] (= 1 - final_T), depth[B,1,H,W] (un-normalised,
     like render_gsplat.py:105-106), depth_norm[B,1,H,W] (= depth / clamp(alpha.detach(), depth_norm_lo, 1),
-    rgca.py:144-145), final_T, radii[B,N] int32, n_isect[B] int32).
+    rgca.py:144-145), final_T, radii[B,N] int32, n_isect[B] int32, final_idx[B,H,W], sorted_ids[B,cap], tile_bins[B,T,2]).
+    `capacity` given: the caller sized the intersection buffers and checks `n_isect` itself; omitted: planned
+    (CapacityPlanner) -- an overflow is repaired inside this call and never surfaces.
     """
     B, N = means.shape[:2]
     dev = means.device
@@ -390,37 +451,31 @@ def render_views(means, scales, quats, opacity, colors, viewmats, intrins, img_h
     background = _f32c(background)
     T = _tiles(img_h, img_w)
     key = (B, N, img_h, img_w, dev.index)
-    calibrate = False
-    explicit = capacity is not None  # the caller sized the buffers: overflow is theirs to check (n_isect)
+    plan_key, deferred = None, False
     if capacity is None:
-        if not PLANNER.frozen:
-            PLANNER.poll()
-        capacity = PLANNER.get(key, N)
-        if capacity is None:
-            if PLANNER.frozen:
+        planned = PLANNER.get(key)
+        if PLANNER.frozen:
+            if planned is None:
                 raise _lib.GoliathHipError("render_views inside a graph capture needs a calibrated capacity: run the "
                                            "same shapes once eagerly first")
-            capacity, calibrate = PLANNER.initial(N, T), True
+        elif planned is None or PLANNER.verify():
+            plan_key = key       # the forward waits for its own counts and repairs an overflow in place
+        else:
+            PLANNER.poll()       # async mode: raises if an EARLIER call overflowed
+            planned = PLANNER.get(key)
+            deferred = True
+        capacity = planned if planned is not None else PLANNER.initial(N, T)
     out = _RenderViews.apply(means, scales, quats, opacity, colors, viewmats, intrins, background, img_h,
                              img_w, float(glob_scale), float(clip_thresh), bool(with_depth), int(capacity),
-                             float(depth_norm_lo))
-    img, alpha, depth, depth_norm, radii, n_isect, final_T = out
-    if B == 0:
-        calibrate = False
+                             float(depth_norm_lo), plan_key)
+    img, alpha, depth, depth_norm, radii, n_isect, final_T, final_idx, sorted_ids, tile_bins = out
     if PLANNER.frozen:
         PLANNER.frozen_log.append((n_isect, capacity))
-    elif (calibrate or PLANNER.strict()) and B > 0:
-        worst = int(n_isect.max().item())  # one blocking read per new shape
-        if calibrate:
-            PLANNER.set(key, worst)
-        if worst > capacity:
-            new_cap = PLANNER.set(key, worst)
-            return render_views(means, scales, quats, opacity, colors, viewmats, intrins, img_h, img_w,
-                                background, glob_scale, clip_thresh, with_depth, capacity=new_cap,
-                                depth_norm_lo=depth_norm_lo)
-    elif key in PLANNER.capacity and not explicit and B > 0:
+    elif deferred and B > 0:
         PLANNER.note(key, n_isect, capacity)
-    res = {"render": img, "alpha": alpha[:, None], "final_T": final_T[:, None], "radii": radii, "n_isect": n_isect}
+    res = {"render": img, "alpha": alpha[:, None], "final_T": final_T[:, None], "radii": radii, "n_isect": n_isect,
+           # per-pixel index of the last contributor in its view's depth-sorted list, and that list (diagnostics)
+           "final_idx": final_idx, "sorted_ids": sorted_ids, "tile_bins": tile_bins}
     if with_depth:
         res["depth"] = depth[:, None]
         res["depth_norm"] = depth_norm[:, None]  # depth / clamp(alpha.detach(), depth_norm_lo, 1)

@@ -65,8 +65,9 @@ class _Phong(torch.autograd.Function):
         p_uv = ctx.args[0]
         s = _mk(*ctx.args, ctx.powers)
         g_p, g_n = torch.empty_like(p_uv), torch.empty_like(p_uv)
+        u_diff, u_spec = _c(u_diff), _c(u_spec)  # bound to locals: must outlive the launch
         with torch.cuda.device(p_uv.device):
-            _lib.call("gol_uvlight_phong_bwd", ctypes.byref(s), _lib.fptr(_c(u_diff)), _lib.fptr(_c(u_spec)),
+            _lib.call("gol_uvlight_phong_bwd", ctypes.byref(s), _lib.fptr(u_diff), _lib.fptr(u_spec),
                       _lib.fptr(g_p), _lib.fptr(g_n), stream_ptr())
         return g_p, g_n, None, None, None, None, None
 
@@ -91,8 +92,9 @@ class _Ggx(torch.autograd.Function):
         s = _mk(*ctx.args, ctx.powers, **ctx.extra)
         g_p, g_n = torch.empty_like(p_uv), torch.empty_like(p_uv)
         g_r, g_t = torch.empty_like(ctx.extra["roughness"]), torch.empty_like(ctx.extra["tex_mean"])
+        u_feat, u_rgb = _c(u_feat), _c(u_rgb)  # bound to locals: must outlive the launch
         with torch.cuda.device(p_uv.device):
-            _lib.call("gol_uvlight_ggx_bwd", ctypes.byref(s), _lib.fptr(_c(u_feat)), _lib.fptr(_c(u_rgb)),
+            _lib.call("gol_uvlight_ggx_bwd", ctypes.byref(s), _lib.fptr(u_feat), _lib.fptr(u_rgb),
                       _lib.fptr(g_p), _lib.fptr(g_n), _lib.fptr(g_r), _lib.fptr(g_t), stream_ptr())
         return g_p, g_n, g_r, g_t, None, None, None, None, None, None
 

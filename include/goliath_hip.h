@@ -9,7 +9,9 @@
  *     gol_status; outputs are caller-owned and pre-allocated, exactly like the reference's
  *     pybind entry points (sg.cu:177-283, mvpraymarch.cpp:107-409, utils.cpp:46-137);
  *   - "[B,N,3]" = row-major, B views (batch elements) x N Gaussians;
- *   - re-entrant given distinct streams and distinct output/scratch buffers; no global state.
+ *   - re-entrant given distinct streams and distinct output/scratch buffers.  Process-wide state is limited to
+ *     the thread-local last-error text and a monotone per-device cache of the dynamic-LDS limits already
+ *     granted to the binning kernels (atomics; a race only repeats an idempotent hipFuncSetAttribute).
  *
  * Each entry cites the reference interface it replaces (paths relative to /root/reference,
  * "gsplat:" = the third-party gsplat==0.1.11 the reference calls).

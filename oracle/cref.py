@@ -207,6 +207,12 @@ def evaluate_gaussian_bwd(lobe_dirs, lobe_sigmas, light_values, light_pts, prim_
 
 
 # --------------------------------------------------------------------------- mvpraymarch / raydirs
+def mvp_set_footprint(w=0, h=0, cap=0):
+    """Hit-list semantics of mvp_forward / mvp_backward: (0, 0, 0) = per ray, uncapped (default);
+    (8, 4, 512) = the reference's warp footprint and cap; (8, 8, 512) = csrc/mvp.hip's wave footprint."""
+    lib().orc_mvp_set_footprint(c_int(w), c_int(h), c_int(cap))
+
+
 def mvp_forward(raypos, raydir, stepsize, tminmax, primpos, primrot, primscale, template, fadescale=8.0,
                 fadeexp=8.0, want_raysat=True, with_shadow=False):
     """mvpraymarchlib.raymarch_forward semantics (algo 0, chlast).  template[N,K,TD,TH,TW,4].

@@ -16,8 +16,12 @@
  * PINNED: tests/test_oracle_mvp.py checks it against golden vectors produced by the reference's own
  * in-tree PyTorch ray marcher (mvpraymarch.py:581-669) and raydirs (utils.py:127-143), see
  * tests/golden/make_mvp_golden.py.
- * Differences from the CUDA kernels, all without effect on the result: the hit list is per ray, not
- * the union over a 32-lane warp (extra boxes fail the per-sample valid() test), and has no 512 cap.
+ * Hit list: by default per ray and uncapped -- equal to the CUDA kernels' result whenever no warp footprint
+ * collects more than 512 boxes (extra boxes of the warp-wide union fail the per-sample valid() test).
+ * orc_mvp_set_footprint(w, h, cap) switches to the kernels' exact list semantics: ONE list per w x h pixel block
+ * (the union of the boxes any ray of the block hits, in DFS leaf order, truncated to the first `cap`;
+ * utils.h:976-1012 with sync = true).  (8, 4, 512) is the reference's 32-lane warp of its (8, 16) thread block
+ * (mvpraymarch.py:334, mvpraymarch_kernel.cu:39); (8, 8, 512) is the wave64 footprint of csrc/mvp.hip.
  */
 #include <limits.h>
 #include <math.h>
@@ -119,6 +123,44 @@ static void collect_hits(int K, const int* order, f3 raypos, f3 raydir, const fl
   }
 }
 
+/* footprint mode (see the header): 0 = per ray, uncapped */
+static int g_fp_w = 0, g_fp_h = 0, g_fp_cap = 0;
+void orc_mvp_set_footprint(int w, int h, int cap) { g_fp_w = w; g_fp_h = h; g_fp_cap = cap; }
+
+/* one list per footprint block: L[blk * (cap + 1)] = count, then the box ids; NULL in per-ray mode */
+static int* build_block_lists(int N, int H, int W, int K, const int* order, const float* rayposim,
+                              const float* raydirim, const float* primpos_, const float* primrot_,
+                              const float* primscale_, int* nbx_out, int* nby_out) {
+  if (g_fp_w <= 0 || g_fp_h <= 0) return NULL;
+  const int nbx = (W + g_fp_w - 1) / g_fp_w, nby = (H + g_fp_h - 1) / g_fp_h, cap = g_fp_cap;
+  int* L = (int*)calloc((size_t)N * nbx * nby * (cap + 1), sizeof(int));
+#pragma omp parallel
+  {
+    hits_t h; h.k = (int*)malloc(sizeof(int) * K);
+    unsigned char* any = (unsigned char*)malloc((size_t)K);
+#pragma omp for schedule(dynamic, 4)
+    for (int blk = 0; blk < N * nbx * nby; ++blk) {
+      int n = blk / (nbx * nby), by = (blk / nbx) % nby, bx = blk % nbx;
+      const float* primpos = primpos_ + (size_t)n * K * 3; const float* primrot = primrot_ + (size_t)n * K * 9;
+      const float* primscale = primscale_ + (size_t)n * K * 3;
+      memset(any, 0, (size_t)K);
+      for (int y = by * g_fp_h; y < (by + 1) * g_fp_h && y < H; ++y)
+        for (int x = bx * g_fp_w; x < (bx + 1) * g_fp_w && x < W; ++x) {
+          size_t r = ((size_t)n * H + y) * W + x;
+          collect_hits(K, order, ld3(rayposim + 3 * r), ld3(raydirim + 3 * r), primpos, primrot, primscale, &h);
+          for (int s = 0; s < h.n; ++s) any[h.k[s]] = 1;
+        }
+      int* out = L + (size_t)blk * (cap + 1);
+      int cnt = 0;
+      for (int j = 0; j < K && cnt < cap; ++j) if (any[order[j]]) out[1 + cnt++] = order[j];
+      out[0] = cnt;
+    }
+    free(h.k); free(any);
+  }
+  *nbx_out = nbx; *nby_out = nby;
+  return L;
+}
+
 /* ---------------------------------------------------------------------------------------------- *
  * forward: rayrgba[N,H,W,4]; raysat[N,H,W,3] (may be NULL); shadow[N,K,TD,TH,TW,2] (may be NULL,
  * accumulated).  template[N,K,TD,TH,TW,4].
@@ -130,6 +172,8 @@ void orc_mvp_fwd(int N, int H, int W, int K, const float* rayposim, const float*
   int* order = (int*)malloc(sizeof(int) * K);
   dfs_leaf_order(K, order);
   const size_t vox = (size_t)TD * TH * TW;
+  int nbx = 0, nby = 0;
+  int* lists = build_block_lists(N, H, W, K, order, rayposim, raydirim, primpos_, primrot_, primscale_, &nbx, &nby);
 #pragma omp parallel
   {
     hits_t h; h.k = (int*)malloc(sizeof(int) * K);
@@ -141,7 +185,13 @@ void orc_mvp_fwd(int N, int H, int W, int K, const float* rayposim, const float*
       float* shadow = shadow_ ? shadow_ + (size_t)n * K * vox * 2 : NULL;
       f3 raypos = ld3(rayposim + 3 * (size_t)r), raydir = ld3(raydirim + 3 * (size_t)r);
       float tmin = tminmaxim[2 * (size_t)r], tmax = tminmaxim[2 * (size_t)r + 1];
-      collect_hits(K, order, raypos, raydir, primpos, primrot, primscale, &h);
+      collect_hits(K, order, raypos, raydir, primpos, primrot, primscale, &h);  /* the ray's own hits: rmin, rmax */
+      int hn = h.n; const int* hk = h.k;
+      if (lists) {
+        int y = (r / W) % H, x = r % W;
+        const int* Lb = lists + ((size_t)(n * nby + y / g_fp_h) * nbx + x / g_fp_w) * (g_fp_cap + 1);
+        hn = Lb[0]; hk = Lb + 1;
+      }
       float rt0 = fmaxf(h.rmin, tmin), rt1 = fminf(h.rmax, tmax);
       float t = tmin;
       raypos = add(raypos, scl(raydir, tmin));
@@ -151,8 +201,8 @@ void orc_mvp_fwd(int N, int H, int W, int K, const float* rayposim, const float*
       float acc[4] = {0, 0, 0, 0}, sat3[3] = {-1.f, -1.f, -1.f};
       int sat = 0;
       while (!(t > rt1 + 1e-5f || sat)) {
-        for (int s = 0; s < h.n; ++s) {
-          int k = h.k[s];
+        for (int s = 0; s < hn; ++s) {
+          int k = hk[s];
           xform_t xf;
           f3 y0 = xform_fwd(&xf, primpos, primrot, primscale, k, raypos);
           if (valid_pos(y0) && !sat && t < rt1 + 1e-5f) {
@@ -187,7 +237,7 @@ void orc_mvp_fwd(int N, int H, int W, int K, const float* rayposim, const float*
     }
     free(h.k);
   }
-  free(order);
+  free(order); free(lists);
 }
 
 /* ---------------------------------------------------------------------------------------------- *
@@ -206,6 +256,8 @@ void orc_mvp_bwd(int N, int H, int W, int K, const float* rayposim, const float*
   double* gP = (double*)calloc((size_t)N * K * 3, sizeof(double));
   double* gR = (double*)calloc((size_t)N * K * 9, sizeof(double));
   double* gS = (double*)calloc((size_t)N * K * 3, sizeof(double));
+  int nbx = 0, nby = 0;
+  int* lists = build_block_lists(N, H, W, K, order, rayposim, raydirim, primpos_, primrot_, primscale_, &nbx, &nby);
 #pragma omp parallel
   {
     hits_t h; h.k = (int*)malloc(sizeof(int) * K);
@@ -219,6 +271,12 @@ void orc_mvp_bwd(int N, int H, int W, int K, const float* rayposim, const float*
       const float* dL = grad_rayrgba + 4 * (size_t)r;
       const float* rs = raysat_ + 3 * (size_t)r;
       collect_hits(K, order, raypos, raydir, primpos, primrot, primscale, &h);
+      int hn = h.n; const int* hk = h.k;
+      if (lists) {
+        int y = (r / W) % H, x = r % W;
+        const int* Lb = lists + ((size_t)(n * nby + y / g_fp_h) * nbx + x / g_fp_w) * (g_fp_cap + 1);
+        hn = Lb[0]; hk = Lb + 1;
+      }
       float rt0 = fmaxf(h.rmin, tmin), rt1 = fminf(h.rmax, tmax);
       float t = tmin;
       raypos = add(raypos, scl(raydir, tmin));
@@ -227,8 +285,8 @@ void orc_mvp_bwd(int N, int H, int W, int K, const float* rayposim, const float*
       raypos = add(raypos, scl(scl(raydir, (float)incs), stepsize));
       float accw = 0.f; int sat = 0;
       while (t < rt1 + 1e-5f && !sat) {
-        for (int s = 0; s < h.n; ++s) {
-          int k = h.k[s];
+        for (int s = 0; s < hn; ++s) {
+          int k = hk[s];
           xform_t xf;
           f3 y0 = xform_fwd(&xf, primpos, primrot, primscale, k, raypos);
           if (!(valid_pos(y0) && !sat && t < rt1 + 1e-5f)) continue;
@@ -300,7 +358,7 @@ void orc_mvp_bwd(int N, int H, int W, int K, const float* rayposim, const float*
   for (size_t i = 0; i < (size_t)N * K * vox * 4; ++i) grad_tplate[i] = (float)gT[i];
   for (size_t i = 0; i < (size_t)N * K * 3; ++i) { grad_primpos[i] = (float)gP[i]; grad_primscale[i] = (float)gS[i]; }
   for (size_t i = 0; i < (size_t)N * K * 9; ++i) grad_primrot[i] = (float)gR[i];
-  free(gT); free(gP); free(gR); free(gS); free(order);
+  free(gT); free(gP); free(gR); free(gS); free(order); free(lists);
 }
 
 /* primtransf.h:12-63 + bvh.cu:157-201, fixed-order tree (sortedobjid[k] = k, heap children 2i+1, 2i+2):

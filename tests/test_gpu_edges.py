@@ -51,25 +51,56 @@ def test_capacity_overflow_is_detected_and_recovered():
     g, v = _views(s, B=2)
     ref = splat.render_views(**v, img_h=128, img_w=128)
     need = int(ref["n_isect"].max())
-    # explicit, too small capacity: the count is still exact and exceeds it
+    key = (2, 4000, 128, 128, torch.cuda.current_device())
+    # explicit, too small capacity: the count is still exact and exceeds it (the caller's to check)
     small = splat.render_views(**v, img_h=128, img_w=128, capacity=need // 4)
     assert int(small["n_isect"].max()) == need > need // 4
-    # strict mode re-runs with a sufficient capacity and reproduces the reference image
-    os.environ["GOLIATH_STRICT_CAPACITY"] = "1"
-    try:
-        key = (2, 4000, 128, 128, torch.cuda.current_device())
-        splat.PLANNER.capacity[key] = need // 4
-        again = splat.render_views(**v, img_h=128, img_w=128)
-        assert torch.equal(again["render"], ref["render"])
-    finally:
-        os.environ.pop("GOLIATH_STRICT_CAPACITY")
-    # lazy mode: an overflowing call is reported (loudly) at the next poll
+    # default (verify) mode: a too small planned capacity is repaired INSIDE the call -- no exception, complete image
     splat.PLANNER.capacity[key] = need // 4
-    splat.PLANNER.pending.clear()
-    splat.render_views(**v, img_h=128, img_w=128)
-    with pytest.raises(_lib.GoliathHipError):
-        splat.PLANNER.poll(block=True)
-    assert splat.PLANNER.capacity[key] >= need
+    before = splat.PLANNER.reruns
+    again = splat.render_views(**v, img_h=128, img_w=128)
+    assert torch.equal(again["render"], ref["render"]) and torch.equal(again["alpha"], ref["alpha"])
+    assert splat.PLANNER.reruns == before + 1 and splat.PLANNER.capacity[key] >= need
+    # capacities never shrink
+    cap = splat.PLANNER.capacity[key]
+    splat.PLANNER.set(key, 10)
+    assert splat.PLANNER.capacity[key] == cap
+    # async mode (benchmark loops): an overflowing call is reported (loudly) at the next poll
+    splat.PLANNER.mode = "async"
+    try:
+        splat.PLANNER.capacity[key] = need // 4
+        splat.PLANNER.pending.clear()
+        splat.render_views(**v, img_h=128, img_w=128)
+        with pytest.raises(_lib.GoliathHipError):
+            splat.PLANNER.poll(block=True)
+        assert splat.PLANNER.capacity[key] >= need
+    finally:
+        splat.PLANNER.mode = "verify"
+
+
+def test_growing_gaussians_never_raise_under_the_reference_loop_contract():
+    """the Gaussians grow ~10x in footprint area over the steps of an unmodified training-loop shape
+    (forward -> loss.item() -> backward, ca_code/utils/train.py:185-208): zero exceptions, every image complete
+    (== a render with an explicit, sufficient capacity)."""
+    from goliath_amd import splat
+
+    s = head_scene(3000, 160, 120, seed=8)
+    g, v = _views(s, B=2)
+    splat.PLANNER.capacity.pop((2, 3000, 160, 120, torch.cuda.current_device()), None)
+    grew = []
+    for it in range(12):
+        vv = dict(v)
+        vv["scales"] = (v["scales"] * (1.0 + 0.35 * it)).requires_grad_(True)  # x4.85 linear at the end
+        out = splat.render_views(**vv, img_h=160, img_w=120)
+        loss = out["render"].mean()
+        _ = loss.item()
+        loss.backward()
+        assert torch.isfinite(vv["scales"].grad).all()
+        need = int(out["n_isect"].max())
+        full = splat.render_views(**{k: t.detach() for k, t in vv.items()}, img_h=160, img_w=120, capacity=need + 16)
+        assert torch.equal(out["render"].detach(), full["render"]), it
+        grew.append(need)
+    assert grew[-1] > 8 * grew[0], grew
 
 
 @pytest.mark.parametrize("H,W", [(17, 33), (16, 16), (1, 1), (250, 7)])

@@ -1,0 +1,101 @@
+"""GPU: parity of the BENCHMARKED chain at BASELINE config-2 size (VERDICT r1 "next" #1a, SURVEY.md 8c protocol).
+
+The exact step bench.py times -- env-map relight, 250,000 Gaussians, 2048x1334, B = 4 views per launch:
+shade(env) -> project -> pruned bin/sort -> planar 2-px/lane colour+depth raster -> fused L1 -> packed-record raster
+backward -> project backward -> shade backward -- is compared as a whole with the CPU oracle chain
+(oracle/chain.py): rgb / alpha / depth and EVERY input gradient (f_vnocond, f_vcond, postex, tn, albedo) on whole
+images (the OpenMP oracle needs ~2 s per view on the GPU box's cores, so no tile subsampling is necessary), plus the
+fraction of pixels whose contributing list differs (threshold flips at alpha = 1/255, T = 1e-4, sigma < 0)."""
+import json
+import os
+import sys
+
+import pytest
+import torch
+
+from scenes import rel_l2
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+TOL_OUT = 1e-4     # north_star: outputs within 1e-4 L2
+TOL_GRAD = 5e-4    # sums of ~1e5 signed float atomics per Gaussian + a handful of threshold-flip pixels
+LEAVES = ("f_vn", "f_vc", "postex", "tn", "albedo")
+
+
+def _gpu_step(mb, cfg):
+    from goliath_amd import losses, render_gs, shade, splat
+
+    preds = shade.shading_tail(mb["f_vn"], mb["f_vc"], mb["postex"], mb["tn"], mb["albedo"], mb["light_sh"],
+                               mb["campos"], preconv_envmap=mb["mips"], lightrot=mb["lightrot"])
+    rgb, alpha, depth = render_gs.render_batch(mb["K"], mb["Rt"], preds, cfg["height"], cfg["width"])
+    loss = losses.l1_image(rgb, mb["target"])
+    loss.backward()
+    # the lists of the same views (diagnostics only: last contributor per pixel)
+    with torch.no_grad():
+        intr = torch.stack([mb["K"][:, 0, 0], mb["K"][:, 1, 1], mb["K"][:, 0, 2], mb["K"][:, 1, 2]], -1)
+        d = splat.render_views(preds["primpos"], preds["primscale"], preds["primqvec"], preds["opacity"], preds["color"],
+                               mb["Rt"], intr, cfg["height"], cfg["width"])
+        B = rgb.shape[0]
+        last = torch.gather(d["sorted_ids"], 1, d["final_idx"].reshape(B, -1).long()).reshape(d["final_idx"].shape)
+        last = torch.where(d["final_T"][:, 0] < 1.0, last, torch.full_like(last, -1))
+    return rgb.detach(), alpha, depth.detach(), float(loss), last, d
+
+
+@pytest.mark.parametrize("B", [4])
+def test_bench_step_matches_oracle_chain_at_config2(B):
+    import bench
+    from oracle import chain, cref
+
+    cfg = dict(bench.CFG, views_per_gpu=B)
+    H, W = cfg["height"], cfg["width"]
+    cpu = bench.make_inputs(cfg, "cpu", rank=0)
+    mb = {k: (v.detach().cuda().requires_grad_(v.requires_grad) if torch.is_tensor(v) else [m.cuda() for m in v])
+          for k, v in cpu.items()}
+    rgb, alpha, depth, loss, last, diag = _gpu_step(mb, cfg)
+
+    cref.set_threads(min(32, os.cpu_count() or 1))
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    ref_grads = {k: [] for k in LEAVES}
+    report = {"views": B, "gaussians": cfg["gaussians"], "image": [H, W], "outputs": {}, "grads": {}}
+    flips, big, ref_loss = 0, 0, 0.0
+    worst = {"rgb": 0.0, "alpha": 0.0, "depth": 0.0}
+    for b in range(B):
+        one = {k: (v[b:b + 1].detach().clone().requires_grad_(v.requires_grad) if torch.is_tensor(v) and k != "albedo"
+                   else v) for k, v in cpu.items()}
+        one["albedo"] = cpu["albedo"].detach().clone().requires_grad_(True)
+        one["mips"] = [m[b:b + 1] for m in cpu["mips"]]
+        o = chain.cpu_view(one, H, W, loss_scale=1.0 / (B * 3 * H * W))
+        ref_loss += o["loss"]
+        assert o["n_isect"] > 1_000_000  # config-2 density (the pruned HIP lists are ~2 M, the 3-sigma lists ~3.6 M)
+        worst["rgb"] = max(worst["rgb"], rel_l2(rgb[b], o["rgb"]))
+        worst["alpha"] = max(worst["alpha"], rel_l2(alpha[b, 0], o["alpha"]))
+        worst["depth"] = max(worst["depth"], rel_l2(depth[b, 0], o["depth_norm"]))
+        # threshold flips: the last contributor differs, or the transmittance differs by more than rounding
+        T_h, T_o = diag["final_T"][b, 0].cpu(), o["final_T"]
+        flip = (last[b].cpu() != o["last_id"]) | ((T_h - T_o).abs() > 1e-3 * T_o.clamp(min=1e-4))
+        flips += int(flip.sum())
+        big += int(((rgb[b].cpu() - o["rgb"]).abs().amax(0) > 1e-3).sum())
+        for k in LEAVES:
+            ref_grads[k].append(one[k].grad)
+    report["outputs"] = worst
+    report["flip_pixel_fraction"] = flips / (B * H * W)
+    report["pixels_off_by_more_than_1e-3"] = big / (B * H * W)
+    report["loss"] = {"hip": loss, "oracle": ref_loss}
+    for k in LEAVES:
+        ref = torch.stack(ref_grads[k]).sum(0) if k == "albedo" else torch.cat(ref_grads[k], 0)
+        report["grads"][k] = rel_l2(mb[k].grad, ref)
+    print("\nFULLSIZE_PARITY " + json.dumps(report))
+    out_dir = os.path.join(ROOT, "gpurun_out")
+    if os.path.isdir(out_dir):
+        with open(os.path.join(out_dir, "fullsize_parity.json"), "w") as f:
+            json.dump(report, f, indent=1)
+    assert abs(loss - ref_loss) < 1e-5 * abs(ref_loss)
+    for k, v in worst.items():
+        assert v < TOL_OUT, (k, v)
+    assert report["flip_pixel_fraction"] < 1e-3, report["flip_pixel_fraction"]  # expected << 0.1 %
+    for k, v in report["grads"].items():
+        assert v < TOL_GRAD, (k, v)
