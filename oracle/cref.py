@@ -24,12 +24,11 @@ ALPHA_CAP_BWD = 0.99  # gsplat 0.1.11 backward.cu
 
 
 def build(force=False):
-    srcs = [os.path.join(_HERE, f) for f in os.listdir(_HERE) if f.endswith(".c")]
-    stale = force or not os.path.exists(_SO) or any(
-        os.path.getmtime(s) > os.path.getmtime(_SO) for s in srcs
-    )
-    if stale:
-        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    """Build oracle/_build/liboracle.so (our restatements) and, where /root/reference exists, oracle/_ref/libref.so (the
+    reference's own sgutils / raydirs kernels compiled for the host).  `make` decides what is stale."""
+    if force:
+        subprocess.check_call(["make", "-C", _HERE, "-s", "clean"])
+    subprocess.check_call(["make", "-C", _HERE, "-s"])
     return _SO
 
 

@@ -66,6 +66,13 @@ def test_raydirs_and_aabb_vs_golden_and_oracle():
     H, W = G["pixelcoords"].shape[1:3]
     rp2, rd2, tm2 = mvp.compute_raydirs(c(G["viewpos"]), c(G["viewrot"]), c(G["focal"]), c(G["princpt"]), (W, H), 1.0)
     assert torch.equal(rd2, rd) and torch.equal(tm2, tm) and torch.equal(rp2, rp)
+    from oracle import refso
+
+    if refso.available():  # the reference's own compute_raydirs kernel compiled for the host (oracle/_ref)
+        for pc_gpu, pc_cpu in ((c(G["pixelcoords"]), G["pixelcoords"]), ((W, H), (W, H))):
+            got = mvp.compute_raydirs(c(G["viewpos"]), c(G["viewrot"]), c(G["focal"]), c(G["princpt"]), pc_gpu, 1.0)
+            want = refso.compute_raydirs(G["viewpos"], G["viewrot"], G["focal"], G["princpt"], pc_cpu, 1.0)
+            assert rel_l2(got[1], want[1]) < 1e-6 and rel_l2(got[2], want[2]) < 1e-5
     case = _random_case(2, 8, 8, 27, (4, 4, 4), 3)
     _, _, aabb = mvp.build_accel((c(case["primpos"]), c(case["primrot"]), c(case["primscale"])))
     assert rel_l2(aabb, cref.mvp_aabb(case["primpos"], case["primrot"], case["primscale"])) < 1e-6

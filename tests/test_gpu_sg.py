@@ -78,3 +78,24 @@ def test_sg_full_size_linearity():
     first = sg.evaluate_gaussian(dirs, sig, lv[:, :3].contiguous(), lp[:, :3].contiguous(), pp, torch.full_like(nl, 3))
     rest = sg.evaluate_gaussian(dirs, sig, lv[:, 3:].contiguous(), lp[:, 3:].contiguous(), pp, torch.full_like(nl, 5))
     assert rel_l2(first + rest, a) < 1e-5
+
+
+@pytest.mark.parametrize("w_type", [0, 1, 2, 3])
+def test_sg_matches_reference_kernels_compiled_for_the_host(w_type):
+    """R6 pinned: the HIP kernels against the reference's OWN sg.cu kernels (oracle/_ref/libref.so, built from
+    /root/reference/extensions/sgutils/sg.cu by oracle/Makefile), incl. the clamped-cosine / -20 branch."""
+    from goliath_amd import sg
+    from oracle import refso
+
+    if not refso.available():
+        pytest.skip("oracle/_ref/libref.so not built")
+    dirs, sig, lv, lp, pp, nl = sg_inputs(N=2, D=2000, L=9, seed=21)
+    dirs = dirs * (1.0 + 0.3 * torch.rand(2, 2000, 1, generator=torch.Generator().manual_seed(2)))  # |cos| can exceed 1
+    ref = refso.evaluate_gaussian_fwd(dirs, sig, lv, lp, pp, nl, w_type)
+    go = torch.randn(ref.shape, generator=torch.Generator().manual_seed(4))
+    gd_ref, gs_ref, gl_ref = refso.evaluate_gaussian_bwd(dirs, sig, lv, lp, pp, nl, go, w_type, want_light_grad=True)
+    d, s, v = (t.cuda().requires_grad_(True) for t in (dirs, sig, lv))
+    out = sg.evaluate_gaussian(d, s, v, lp.cuda(), pp.cuda(), nl.cuda(), w_type=w_type, normalize_lobe_dirs=False)
+    assert rel_l2(out, ref) < TOL
+    out.backward(go.cuda())
+    assert rel_l2(d.grad, gd_ref) < TOL and rel_l2(s.grad, gs_ref) < TOL and rel_l2(v.grad, gl_ref) < TOL
