@@ -21,7 +21,7 @@ _SYMBOLS = [
     "gol_mvp_march_bwd", "gol_envmap_pack", "gol_uvlight_phong_fwd", "gol_uvlight_phong_bwd",
     "gol_uvlight_ggx_fwd", "gol_uvlight_ggx_bwd", "gol_l1_blocks", "gol_l1_fwd", "gol_l1_bwd",
     "gol_tail_conv_fwd", "gol_tail_conv_bwd", "gol_tail_conv_bwd_scratch_floats", "gol_ssim_blocks", "gol_ssim_fwd", "gol_ssim_bwd",
-    "gol_shadow_pcf", "gol_raster_contrib_words",
+    "gol_shadow_pcf",
 ]
 
 
@@ -41,7 +41,6 @@ def load():
         lib = ctypes.CDLL(LIB_PATH)
         lib.gol_version.restype = ctypes.c_char_p
         lib.gol_last_error.restype = ctypes.c_char_p
-        lib.gol_raster_contrib_words.restype = ctypes.c_int64
         for name in _SYMBOLS:
             getattr(lib, name)  # AttributeError if the ABI and the build disagree
         _lib = lib

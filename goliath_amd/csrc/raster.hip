@@ -19,26 +19,15 @@
 //     tile per component (gsplat: one per 32-lane warp => 8x more); with 64-byte gradient records
 //     (GOL_GRAD_RECORD) the 10 atomics of a Gaussian share a cache line and are issued by 16 adjacent lanes --
 //     the memory-side atomic units, which cost 25 % of the kernel with dense [N,k] arrays, drop out of the profile;
-//   * tile -> workgroup mapping interleaves tile rows over the 8 XCDs (tile_of_block);
-//   * the forward leaves one bit per (list entry, half): "some pixel of this half took the entry".  The backward walks
-//     ONLY those entries (the set of entries a pixel took in the forward is exactly the set it replays), so the ~50 % of
-//     its visits that used to evaluate the Gaussian for 128 pixels just to find nothing to do are gone;
-//   * conics are staged pre-multiplied by log2(e): alpha = opacity * 2^(-sigma') is one v_exp_f32 with a negated
-//     operand instead of a multiply + exp per pixel.
+//   * tile -> workgroup mapping interleaves tile rows over the 8 XCDs (tile_of_block).
 #include "gol_common.h"
 
 namespace {
 
 constexpr int kBatch = 256;
+// conics are staged in LDS pre-multiplied by log2(e): alpha = opacity * 2^(-sigma') is one v_exp_f32 with a negated
+// operand instead of a multiply + exp per pixel; ln(2) brings the true conic back where the backward needs it
 constexpr float kLog2e = 1.4426950408889634f, kLn2 = 0.6931471805599453f;
-
-// Contribution words: one 64-bit word per (view, half, 64 consecutive entries of a tile's list, counted from the
-// tile's first entry).  Tile t's words start at (range.x >> 6) + t: consecutive tiles own contiguous list segments,
-// so floor(x / 64) advances by at least ceil(n / 64) - 1 per tile and the "+ t" makes the regions disjoint.
-// gol_raster_contrib_words() = capacity / 64 + T + 2 words per (view, half).
-__device__ __forceinline__ size_t contrib_base(int view, int wave, int64_t words, int range_x, int tile) {
-  return ((size_t)view * 2 + wave) * (size_t)words + (size_t)(range_x >> 6) + tile;
-}
 
 struct TileCoord { int tile, tx, ty; bool ok; };
 
@@ -91,10 +80,9 @@ __global__ __launch_bounds__(128) void raster_fwd_kernel(
     const float* __restrict__ conics, const float* __restrict__ colors, const float* __restrict__ extra,
     const float* __restrict__ opacities, const float* __restrict__ background, float* __restrict__ out_img,
     float* __restrict__ out_extra, float* __restrict__ final_Ts, int32_t* __restrict__ final_idx,
-    float* __restrict__ out_alpha, float* __restrict__ out_extra_norm, float norm_lo,
-    unsigned long long* __restrict__ contrib, int64_t contrib_words) {
-  __shared__ float4 s_a[kBatch];  // x, y, log2e * conic.a, log2e * conic.b
-  __shared__ float4 s_b[kBatch];  // log2e * conic.c, opacity, r, g
+    float* __restrict__ out_alpha, float* __restrict__ out_extra_norm, float norm_lo) {
+  __shared__ float4 s_a[kBatch];  // x, y, conic.a, conic.b
+  __shared__ float4 s_b[kBatch];  // conic.c, opacity, r, g
   __shared__ float2 s_c[kBatch];  // b, extra
   __shared__ int32_t s_mask[kBatch];  // half mask
   const int T = tiles_x * tiles_y;
@@ -115,8 +103,6 @@ __global__ __launch_bounds__(128) void raster_fwd_kernel(
   i2 cur_idx = {0, 0};
   f2 acc0 = {0.f, 0.f}, acc1 = acc0, acc2 = acc0, acc3 = acc0;
   bool done0 = !in0, done1 = !in1;
-
-  unsigned long long* cw = contrib ? contrib + contrib_base(view, wave, contrib_words, range.x, tc.tile) : nullptr;
 
   const int n_batches = (range.y - range.x + kBatch - 1) / kBatch;
   for (int bb = 0; bb < n_batches; ++bb) {
@@ -145,12 +131,9 @@ __global__ __launch_bounds__(128) void raster_fwd_kernel(
     // 64 entries, then a scalar loop over the set bits (s_ff1) -- culled entries cost nothing.
     for (int chunk = 0; chunk < batch_size; chunk += 64) {
       unsigned long long bits = __ballot((s_mask[chunk + lane] >> wave) & 1);
-      unsigned long long taken = 0ull;  // entries of this chunk that some pixel of the half composites
-      bool finished = false;
       while (bits) {
-        if (__ballot(!(done0 && done1)) == 0ull) { finished = true; break; }  // this wave's half is finished
-        const int bit = __builtin_ctzll(bits);
-        const int t = chunk + bit;
+        if (__ballot(!(done0 && done1)) == 0ull) { chunk = batch_size; break; }  // this wave's half is finished
+        const int t = chunk + __builtin_ctzll(bits);
         bits &= bits - 1;
         const float4 a4 = s_a[t];
         const float4 b4 = s_b[t];
@@ -158,9 +141,9 @@ __global__ __launch_bounds__(128) void raster_fwd_kernel(
         // branch-free pixel update: selects instead of exec-mask regions (the loop is issue-bound)
         const float dx = a4.x - px;
         const f2 dy = a4.y - py;
-        const f2 sigma = 0.5f * (a4.z * dx * dx + b4.x * dy * dy) + (a4.w * dx) * dy;  // log2e * gsplat's sigma
+        const f2 sigma = 0.5f * (a4.z * dx * dx + b4.x * dy * dy) + (a4.w * dx) * dy;
         f2 alpha;
-        alpha.x = fminf(GOL_ALPHA_CAP_FWD, b4.y * __builtin_amdgcn_exp2f(-sigma.x));
+        alpha.x = fminf(GOL_ALPHA_CAP_FWD, b4.y * __builtin_amdgcn_exp2f(-sigma.x));  // sigma = log2e * gsplat's
         alpha.y = fminf(GOL_ALPHA_CAP_FWD, b4.y * __builtin_amdgcn_exp2f(-sigma.y));
         const bool c0 = !done0 && !(sigma.x < 0.f || alpha.x < GOL_ALPHA_FLOOR);
         const bool c1 = !done1 && !(sigma.y < 0.f || alpha.y < GOL_ALPHA_FLOOR);
@@ -174,11 +157,7 @@ __global__ __launch_bounds__(128) void raster_fwd_kernel(
         if (EXTRA) acc3 += c2.y * vis;
         T_cur.x = take0 ? next_T.x : T_cur.x; T_cur.y = take1 ? next_T.y : T_cur.y;
         cur_idx.x = take0 ? (batch_start + t) : cur_idx.x; cur_idx.y = take1 ? (batch_start + t) : cur_idx.y;
-        if (__ballot(take0 || take1) != 0ull) taken |= 1ull << bit;
       }
-      // every chunk the wave looks at gets its word (the backward reads the words up to the wave's last taken entry)
-      if (cw && lane == 0) cw[bb * (kBatch / 64) + (chunk >> 6)] = taken;
-      if (finished) break;
     }
   }
 
@@ -212,7 +191,7 @@ __global__ __launch_bounds__(128) void raster_fwd_kernel(
   }
 }
 
-constexpr int kBatchB = 64;   // backward batch = one contribution word (per-wave gradient slots live in LDS)
+constexpr int kBatchB = 64;   // backward batch (smaller: per-wave gradient slots live in LDS)
 constexpr int kAcc = 12;      // r g b v_opacity | Sx Sy Sxx Sxy | Syy extra - -
 
 // ---- backward, two pixels per lane -------------------------------------------------------------
@@ -221,9 +200,7 @@ constexpr int kAcc = 12;      // r g b v_opacity | Sx Sy Sxx Sxy | Syy extra - -
 // independent, so the body is written on 2-vectors and maps onto packed fp32 VALU ops (v_pk_fma/mul/add_f32:
 // two pixels per instruction), and the cross-lane reduction of the 10 per-Gaussian sums -- the largest single cost
 // of the one-pixel-per-lane kernel -- is paid once per 128 pixels instead of once per 64.
-// The list is walked back to front one contribution word (64 entries, aligned like the forward's chunks) at a time;
-// a wave visits only the entries whose bit the forward set for its half (contrib == nullptr: every entry).
-static_assert(kBatchB == 64, "raster_bwd_kernel stages one 64-entry contribution word per batch");
+static_assert(kBatchB == 64, "raster_bwd_kernel ballots one 64-entry chunk per batch");
 
 template <bool EXTRA, bool PACKED>
 __global__ __launch_bounds__(128) void raster_bwd_kernel(
@@ -234,16 +211,15 @@ __global__ __launch_bounds__(128) void raster_bwd_kernel(
     const float* __restrict__ final_Ts, const int32_t* __restrict__ final_idx,
     const float* __restrict__ v_out_img, const float* __restrict__ v_out_extra,
     const float* __restrict__ v_out_alpha, float* __restrict__ v_xy, float* __restrict__ v_conic,
-    float* __restrict__ v_colors, float* __restrict__ v_extra, float* __restrict__ v_opacity,
-    const unsigned long long* __restrict__ contrib, int64_t contrib_words) {
+    float* __restrict__ v_colors, float* __restrict__ v_extra, float* __restrict__ v_opacity) {
   __shared__ float4 s_a[kBatchB];
   __shared__ float4 s_b[kBatchB];
   __shared__ float2 s_c[kBatchB];
+  __shared__ int32_t s_mask[kBatchB];
   __shared__ int32_t s_id[kBatchB];
   __shared__ __attribute__((aligned(16))) float s_acc[2][kBatchB][kAcc];
   __shared__ int32_t s_touched[2][kBatchB];
   __shared__ int32_t s_wmax[2];
-  __shared__ unsigned long long s_bits[2];
   const int T = tiles_x * tiles_y;
   const TileCoord tc = tile_of_block(blockIdx.x, T, tiles_x);
   if (!tc.ok) return;
@@ -291,16 +267,14 @@ __global__ __launch_bounds__(128) void raster_bwd_kernel(
   const int bmax = min(max(s_wmax[0], s_wmax[1]), range.y - 1);
   if (bmax < range.x) return;
 
-  const unsigned long long* cw =
-      contrib ? contrib + contrib_base(view, wave, contrib_words, range.x, tc.tile) : nullptr;
-  for (int word = (bmax - range.x) >> 6; word >= 0; --word) {
+  const int n_batches = (bmax - range.x + kBatchB) / kBatchB;
+  for (int bb = 0; bb < n_batches; ++bb) {
     __syncthreads();
-    const int base = range.x + 64 * word;        // list index of bit 0 of this word
-    const int top = min(bmax, base + 63);         // highest list index staged: slot t holds entry base + 63 - t
+    const int batch_end = bmax - bb * kBatchB;
+    const int batch_size = min(kBatchB, batch_end + 1 - range.x);
     if (tid < kBatchB) {
-      const int li = base + 63 - tid;
-      if (li <= top) {
-        const int gid = ids[li];
+      if (tid < batch_size) {
+        const int gid = ids[batch_end - tid];
         const size_t g = goff + (size_t)gid;
         const float2 xy = *reinterpret_cast<const float2*>(xys + 2 * g);
         const float ca = conics[3 * g], cb = conics[3 * g + 1], cc = conics[3 * g + 2];
@@ -310,39 +284,35 @@ __global__ __launch_bounds__(128) void raster_bwd_kernel(
         s_a[tid] = make_float4(xy.x, xy.y, ca * kLog2e, cb * kLog2e);
         s_b[tid] = make_float4(cc * kLog2e, op, r, gg);
         s_c[tid] = make_float2(bl, ex);
+        s_mask[tid] = half_mask(xy.x, xy.y, ca, cb, cc, op, (float)(tc.tx * 16), (float)(tc.ty * 16));
         s_id[tid] = gid;
+      } else {
+        s_mask[tid] = 0;
       }
     }
-    if (lane == 0) s_bits[wave] = cw ? cw[word] : ~0ull;
     (&s_touched[0][0])[tid] = 0;  // 2 * kBatchB == 128 == blockDim
     __syncthreads();
 
-    // slot t <-> list index base + 63 - t: bit-reverse the forward's word; drop what lies behind this wave's last
-    // taken entry (li > wmax, which also covers the unstaged slots li > top)
-    const unsigned long long wbits = s_bits[wave];
-    unsigned long long bits = __builtin_bitreverse64(
-        ((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(wbits >> 32)) << 32) |
-        (unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)wbits));
-    const int t0 = base + 63 - wmax;
-    if (t0 >= 64) bits = 0ull;
-    else if (t0 > 0) bits &= ~0ull << t0;
+    const int t0 = max(0, batch_end - wmax);
+    unsigned long long bits = __ballot((s_mask[lane] >> wave) & 1);  // kBatchB == 64: one chunk
+    if (t0 > 0) bits &= ~0ull << t0;
     while (bits) {
       const int t = __builtin_ctzll(bits);
       bits &= bits - 1;
       const float4 a4 = s_a[t];
       const float4 b4 = s_b[t];
       const float2 c2 = s_c[t];
-      const int li = base + 63 - t;
+      const int li = batch_end - t;
       const float dx = a4.x - px;
       const f2 dy = a4.y - py;
-      const f2 sigma = 0.5f * (a4.z * dx * dx + b4.x * dy * dy) + (a4.w * dx) * dy;  // log2e * gsplat's sigma
+      const f2 sigma = 0.5f * (a4.z * dx * dx + b4.x * dy * dy) + (a4.w * dx) * dy;
       f2 vis;
-      vis.x = __builtin_amdgcn_exp2f(-sigma.x); vis.y = __builtin_amdgcn_exp2f(-sigma.y);
+      vis.x = __builtin_amdgcn_exp2f(-sigma.x); vis.y = __builtin_amdgcn_exp2f(-sigma.y);  // sigma = log2e * gsplat's
       f2 alpha = b4.y * vis;
       alpha.x = fminf(GOL_ALPHA_CAP_BWD, alpha.x); alpha.y = fminf(GOL_ALPHA_CAP_BWD, alpha.y);
       const bool v0 = (li <= bin_final.x) && !(sigma.x < 0.f || alpha.x < GOL_ALPHA_FLOOR);
       const bool v1 = (li <= bin_final.y) && !(sigma.y < 0.f || alpha.y < GOL_ALPHA_FLOOR);
-      if (!cw && __ballot(v0 || v1) == 0ull) continue;  // (with contribution words every visit has a taker)
+      if (__ballot(v0 || v1) == 0ull) continue;
       const f2 one_m = 1.f - alpha;
       f2 ra;
       ra.x = __builtin_amdgcn_rcpf(one_m.x); ra.y = __builtin_amdgcn_rcpf(one_m.y);
@@ -383,12 +353,11 @@ __global__ __launch_bounds__(128) void raster_bwd_kernel(
       }
     }
     __syncthreads();
-    // the conic sits in LDS scaled by log2e: v_xy = conic * (Sx, Sy) needs the true one back (one multiply by ln 2)
     if (PACKED) {
       // gradients live in 64-byte records [r g b | opacity | x y | conic a b c | extra | pad]: 16 consecutive
       // lanes own one Gaussian's record, so an atomic instruction touches 4 cache lines instead of 64
       float* rec = v_colors;
-      for (int idx = tid; idx < kBatchB * 16; idx += 128) {
+      for (int idx = tid; idx < batch_size * 16; idx += 128) {
         const int t = idx >> 4, c = idx & 15;
         const bool t0w = s_touched[0][t] != 0, t1w = s_touched[1][t] != 0;
         if (!(t0w || t1w) || c > (EXTRA ? 9 : 8)) continue;
@@ -402,7 +371,7 @@ __global__ __launch_bounds__(128) void raster_bwd_kernel(
         const float s2 = (t0w ? s_acc[0][t][k2] : 0.f) + (t1w ? s_acc[1][t][k2] : 0.f);
         atomicAdd(rec + (goff + (size_t)s_id[t]) * 16 + c, w1 * s1 + w2 * s2);
       }
-    } else if (tid < kBatchB) {
+    } else if (tid < batch_size) {
       float a[kAcc];
 #pragma unroll
       for (int k = 0; k < kAcc; ++k) a[k] = 0.f;
@@ -436,18 +405,12 @@ __global__ __launch_bounds__(128) void raster_bwd_kernel(
 
 }  // namespace
 
-extern "C" int64_t gol_raster_contrib_words(int64_t capacity, int img_h, int img_w) {
-  const int64_t T = (int64_t)((img_w + 15) / 16) * ((img_h + 15) / 16);
-  return capacity / 64 + T + 2;
-}
-
 extern "C" int gol_rasterize_fwd(int B, int N, int img_h, int img_w, int block, int planar, const int32_t* tile_bins,
                                  const int32_t* sorted_ids, int64_t capacity, const float* xys,
                                  const float* conics, const float* colors, const float* extra,
                                  const float* opacities, const float* background, float* out_img,
                                  float* out_extra, float* final_Ts, int32_t* final_idx, float* out_alpha,
-                                 float* out_extra_norm, float norm_lo, uint64_t* contrib, int64_t contrib_words,
-                                 void* stream) {
+                                 float* out_extra_norm, float norm_lo, void* stream) {
   GOL_REQUIRE(B >= 0 && N >= 0, "negative size");
   GOL_REQUIRE(block == 16, "only block_width == 16 is implemented (the reference's value, render_gsplat.py:28)");
   GOL_REQUIRE(img_h > 0 && img_w > 0, "empty image");
@@ -459,21 +422,17 @@ extern "C" int gol_rasterize_fwd(int B, int N, int img_h, int img_w, int block, 
   GOL_REQUIRE(N == 0 || ((extra == nullptr) == (out_extra == nullptr)), "extra and out_extra go together");
   GOL_REQUIRE(!out_extra_norm || out_extra, "out_extra_norm needs the extra channel");
   const int tiles_x = (img_w + 15) / 16, tiles_y = (img_h + 15) / 16, T = tiles_x * tiles_y;
-  GOL_REQUIRE(!contrib || contrib_words >= gol_raster_contrib_words(capacity, img_h, img_w),
-              "contrib_words < gol_raster_contrib_words(capacity, img_h, img_w)");
   dim3 grid(8 * ((tiles_y + 7) / 8) * tiles_x, B);
   const int2* bins = reinterpret_cast<const int2*>(tile_bins);
   hipStream_t s = (hipStream_t)stream;
-  unsigned long long* cb = reinterpret_cast<unsigned long long*>(contrib);
   if (out_extra)
     raster_fwd_kernel<true><<<grid, 128, 0, s>>>(N, img_h, img_w, planar, tiles_x, tiles_y, bins, sorted_ids, capacity, xys,
                                                   conics, colors, extra, opacities, background, out_img, out_extra,
-                                                  final_Ts, final_idx, out_alpha, out_extra_norm, norm_lo, cb, contrib_words);
+                                                  final_Ts, final_idx, out_alpha, out_extra_norm, norm_lo);
   else
     raster_fwd_kernel<false><<<grid, 128, 0, s>>>(N, img_h, img_w, planar, tiles_x, tiles_y, bins, sorted_ids, capacity, xys,
                                                    conics, colors, extra, opacities, background, out_img, out_extra,
-                                                   final_Ts, final_idx, out_alpha, nullptr, norm_lo, cb, contrib_words);
-  (void)T;
+                                                   final_Ts, final_idx, out_alpha, nullptr, norm_lo);
   GOL_CHECK_LAUNCH();
   return GOL_OK;
 }
@@ -484,8 +443,7 @@ extern "C" int gol_rasterize_bwd(int B, int N, int img_h, int img_w, int block, 
                                  const float* opacities, const float* background, const float* final_Ts,
                                  const int32_t* final_idx, const float* v_out_img, const float* v_out_extra,
                                  const float* v_out_alpha, float* v_xy, float* v_conic, float* v_colors,
-                                 float* v_extra, float* v_opacity, int grad_stride, const uint64_t* contrib,
-                                 int64_t contrib_words, void* stream) {
+                                 float* v_extra, float* v_opacity, int grad_stride, void* stream) {
   GOL_REQUIRE(B >= 0 && N >= 0, "negative size");
   GOL_REQUIRE(block == 16, "only block_width == 16 is implemented (the reference's value, render_gsplat.py:28)");
   GOL_REQUIRE(img_h > 0 && img_w > 0, "empty image");
@@ -502,19 +460,15 @@ extern "C" int gol_rasterize_bwd(int B, int N, int img_h, int img_w, int block, 
                     (!v_extra || v_extra == v_colors + 9),
                 "record layout is [rgb | opacity | xy | conic | extra | pad] (GOL_GRAD_RECORD floats)");
   const int tiles_x = (img_w + 15) / 16, tiles_y = (img_h + 15) / 16;
-  GOL_REQUIRE(!contrib || contrib_words >= gol_raster_contrib_words(capacity, img_h, img_w),
-              "contrib_words < gol_raster_contrib_words(capacity, img_h, img_w)");
   dim3 grid(8 * ((tiles_y + 7) / 8) * tiles_x, B);
   const int2* bins = reinterpret_cast<const int2*>(tile_bins);
   hipStream_t s = (hipStream_t)stream;
-  const unsigned long long* cb = reinterpret_cast<const unsigned long long*>(contrib);
   const bool ex = extra && (v_out_extra || v_extra);
 #define GOL_LAUNCH_BWD(EX, PK)                                                                                      \
   raster_bwd_kernel<EX, PK><<<grid, 128, 0, s>>>(N, img_h, img_w, planar, tiles_x, tiles_y, bins, sorted_ids, capacity, \
                                                  xys, conics, colors, EX ? extra : nullptr, opacities, background,    \
                                                  final_Ts, final_idx, v_out_img, EX ? v_out_extra : nullptr,          \
-                                                 v_out_alpha, v_xy, v_conic, v_colors, EX ? v_extra : nullptr, v_opacity, \
-                                                 cb, contrib_words)
+                                                 v_out_alpha, v_xy, v_conic, v_colors, EX ? v_extra : nullptr, v_opacity)
   if (ex && packed) GOL_LAUNCH_BWD(true, true);
   else if (ex) GOL_LAUNCH_BWD(true, false);
   else if (packed) GOL_LAUNCH_BWD(false, true);

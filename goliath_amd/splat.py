@@ -146,9 +146,6 @@ class _Workspace:
         self.sorted_ids = torch.empty(B, max(capacity, 1), dtype=torch.int32, device=device)
         self.n_isect = torch.empty(B, dtype=torch.int32, device=device)
         self.reach = torch.empty(B, max(N, 1), dtype=torch.int64, device=device)  # pass-1 -> pass-3 tile masks
-        # forward -> backward: one bit per (list entry, tile half) "composited by some pixel" (include/goliath_hip.h)
-        self.contrib_words = capacity // 64 + T + 2
-        self.contrib = torch.empty(B, 2, self.contrib_words, dtype=torch.int64, device=device)
 
 
 def _bin_sort(B, N, xys, depths, radii, img_h, img_w, ws, conics=None, opacities=None):
@@ -270,7 +267,7 @@ class _RasterizeGaussians(torch.autograd.Function):
                           c_int(BLOCK), c_int(0), iptr(ws.tile_bins), iptr(ws.sorted_ids), c_i64(ws.capacity), fptr(xys),
                           fptr(conics), fptr(colors), fptr(None), fptr(opacity), fptr(background),
                           fptr(out_img), fptr(None), fptr(final_Ts), iptr(final_idx), fptr(None), fptr(None),
-                          c_float(0.0), ptr(ws.contrib, torch.int64), c_i64(ws.contrib_words), stream_ptr())
+                          c_float(0.0), stream_ptr())
             ctx.ws = ws
             ctx.save_for_backward(xys, conics, colors, opacity, background, final_Ts, final_idx)
             out_img, final_Ts = out_img[0], final_Ts[0]
@@ -298,8 +295,7 @@ class _RasterizeGaussians(torch.autograd.Function):
                           iptr(ws.tile_bins), iptr(ws.sorted_ids), c_i64(ws.capacity), fptr(xys), fptr(conics),
                           fptr(colors), fptr(None), fptr(opacity), fptr(background), fptr(final_Ts),
                           iptr(final_idx), fptr(vo), fptr(None), fptr(va), fptr(v_xy),
-                          fptr(v_conic), fptr(v_colors), fptr(None), fptr(v_opacity), c_int(0),
-                          ptr(ws.contrib, torch.int64), c_i64(ws.contrib_words), stream_ptr())
+                          fptr(v_conic), fptr(v_colors), fptr(None), fptr(v_opacity), c_int(0), stream_ptr())
             ctx.ws = None
         return (v_xy, None, None, v_conic, None, v_colors, v_opacity[:, None]) + (None,) * 5
 
@@ -361,8 +357,7 @@ class _RenderViews(torch.autograd.Function):
                           iptr(ws.tile_bins), iptr(ws.sorted_ids), c_i64(ws.capacity), fptr(xys), fptr(conics),
                           fptr(colors), fptr(depths if with_depth else None), fptr(opac_eff), fptr(background),
                           fptr(out_img), fptr(out_depth), fptr(final_Ts), iptr(final_idx), fptr(alpha),
-                          fptr(depth_norm), c_float(depth_norm_lo), ptr(ws.contrib, torch.int64),
-                          c_i64(ws.contrib_words), stream_ptr())
+                          fptr(depth_norm), c_float(depth_norm_lo), stream_ptr())
                 return ws, pending
 
             ws, pending = bin_and_raster(capacity)
@@ -421,8 +416,7 @@ class _RenderViews(torch.autograd.Function):
                       fptr(colors), fptr(depths if use_depth else None), fptr(opac_eff), fptr(background),
                       fptr(final_Ts), iptr(final_idx), fptr(v_img_c), fptr(v_depth_c), fptr(v_alpha_c),
                       field(4), field(6), field(0),
-                      field(9) if use_depth else fptr(None), field(3), c_int(GRAD_RECORD),
-                      ptr(ws.contrib, torch.int64), c_i64(ws.contrib_words), stream_ptr())
+                      field(9) if use_depth else fptr(None), field(3), c_int(GRAD_RECORD), stream_ptr())
             _lib.call("gol_project_bwd", c_int(B), c_int(N), fptr(means), fptr(scales), c_float(glob_scale),
                       fptr(quats), fptr(viewmats), fptr(intrins), fptr(cov3d), iptr(radii), fptr(conics),
                       fptr(comp), field(4), field(9) if use_depth else fptr(None), field(6), fptr(None), fptr(opacity),

@@ -127,27 +127,21 @@ int gol_bin_sort(int B, int N, const float* xys, const float* depths, const int3
  *   [rgb 0-2 | opacity 3 | xy 4-5 | conic 6-8 | extra 9 | pad], i.e. v_colors = rec, v_opacity = rec+3, v_xy = rec+4,
  *   v_conic = rec+6, v_extra = rec+9 (checked): the float atomics of a Gaussian then hit one cache line and 16
  *   consecutive lanes issue them together -- the memory-side atomic units see 1/10 of the requests.
- * contrib (optional, NULL = off): [B, 2, contrib_words] 64-bit words, contrib_words >= gol_raster_contrib_words().  The
- *   forward WRITES one bit per (list entry, 16x8 half of its tile): "some pixel of the half composited the entry"; the
- *   backward, given the same buffer, visits only those entries (same result: a pixel replays exactly the entries it
- *   took).  No initialisation needed; the buffer belongs to one (bins, sorted_ids) pair.
  * ---------------------------------------------------------------------------------------- */
 #define GOL_GRAD_RECORD 16
-int64_t gol_raster_contrib_words(int64_t capacity, int img_h, int img_w);
 int gol_rasterize_fwd(int B, int N, int img_h, int img_w, int block, int planar, const int32_t* tile_bins,
                       const int32_t* sorted_ids, int64_t capacity, const float* xys,
                       const float* conics, const float* colors, const float* extra,
                       const float* opacities, const float* background, float* out_img,
                       float* out_extra, float* final_Ts, int32_t* final_idx, float* out_alpha,
-                      float* out_extra_norm, float norm_lo, uint64_t* contrib, int64_t contrib_words, void* stream);
+                      float* out_extra_norm, float norm_lo, void* stream);
 int gol_rasterize_bwd(int B, int N, int img_h, int img_w, int block, int planar, const int32_t* tile_bins,
                       const int32_t* sorted_ids, int64_t capacity, const float* xys,
                       const float* conics, const float* colors, const float* extra,
                       const float* opacities, const float* background, const float* final_Ts,
                       const int32_t* final_idx, const float* v_out_img, const float* v_out_extra,
                       const float* v_out_alpha, float* v_xy, float* v_conic, float* v_colors,
-                      float* v_extra, float* v_opacity, int grad_stride, const uint64_t* contrib,
-                      int64_t contrib_words, void* stream);
+                      float* v_extra, float* v_opacity, int grad_stride, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Fused RGCA shading tail.  Replaces the chain of ATen kernels in PrimDecoder.forward after the

@@ -53,4 +53,7 @@ def cpu_view(t, height, width, loss_scale=None, backward=True):
     (preds["primpos"][0] * v_mean).sum().add((preds["primscale"][0] * v_scale).sum()).add(
         (preds["primqvec"][0] * v_quat).sum()).add((preds["color"][0] * v_col[:, :3]).sum()).add(
         (preds["opacity"][0, :, 0] * v_op[:, 0] * comp).sum()).backward()
+    # the gradients at the raster / projection boundary (what the shading tail receives), for stage-wise reports
+    out["stage_grads"] = dict(color=v_col[:, :3], opacity=(v_op[:, 0] * comp)[:, None], primpos=v_mean,
+                              primscale=v_scale, primqvec=v_quat)
     return out

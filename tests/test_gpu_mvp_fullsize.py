@@ -70,7 +70,7 @@ def test_config5_ray_crops_match_oracle(y0, x0, h, w):
     go = torch.randn(1, h, w, 4, generator=torch.Generator().manual_seed(3))
     cref.set_threads(min(32, os.cpu_count() or 1))
     out, g = _hip(rp, rd, 1.0 / 64, tm, case, go, 8.0, 8.0)
-    assert float(out[..., 3].mean()) > 0.05  # the crop looks into the volume
+    assert float(out[..., 3].mean()) > 0.02  # the crop looks into the volume
     ref, rg = _oracle((8, 8, 512), rp.cpu(), rd.cpu(), 1.0 / 64, tm.cpu(), case, go, 8.0, 8.0)
     report = {"crop": [y0, x0, h, w], "out": rel_l2(out, ref), **{f"grad_{k}": rel_l2(g[k], rg[k]) for k in GRADS}}
     # the reference's own geometry (8x4 warps, cap 512) and the uncapped per-ray list give the same numbers here
