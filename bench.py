@@ -32,6 +32,12 @@ import torch
 import torch.nn.functional as F
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+# VALU issue ceiling, measured on the bench box class with tools/probe/valu_probe.hip (profiles/r02c_valu_probe.txt):
+# the cheapest instruction class (v_fma_f32 / v_mul_f32) sustains one wave-instruction per 2.94 nominal cycles per SIMD
+# at 8 waves per SIMD; 1024 SIMDs x 2.4 GHz / 2.94 = 836 G wave-instructions/s.  Packed fp32 (7.6 cycles), transcendentals
+# and permlane swaps (8.2) are dearer, so a kernel made of them cannot reach frac = 1.
+VALU_PEAK_GINST = 1024 * 2.4 / 2.94
+VALU_BOUND_CALLS = {"gol_rasterize_fwd": "raster_fwd_kernel", "gol_rasterize_bwd": "raster_bwd_kernel"}
 
 CFG = dict(workload="rgca_config2_envrelight", gaussians=250_000, slab=500, height=2048, width=1334,
            views_per_gpu=8, focal=3000.0, cam_radius_mm=700.0, n_mips=4, seed=1234)
@@ -141,7 +147,52 @@ def algorithmic_bytes(name, N, I, P, n_mips_bytes):
         "gol_bin_sort": 16 * N + 8 * I + 8 * I + 4 * I,
         "gol_rasterize_fwd": 4 * I + 44 * I + 24 * P,
         "gol_rasterize_bwd": 4 * I + 44 * I + 20 * P + 36 * N,
+        "gol_l1_fwd": 24 * P,           # rendered + target image
+        "gol_l1_bwd": 24 * P + 12 * P,  # ... and the image gradient
     }[name]
+
+
+def _stamped(name):
+    """profiles/<name> (PMC-derived, per 8-view launch) if it was measured on the kernel sources of this tree."""
+    from goliath_amd import build
+
+    path = os.path.join(ROOT, "profiles", name)
+    if not os.path.exists(path):
+        return None
+    data = json.load(open(path))
+    if data.get("_stamp", {}).get("csrc_sha16") != build.source_digest():
+        return None  # stale: the kernels changed since the counters were taken
+    return data
+
+
+def make_roofline(call, ms, views_per_launch, N, I, P, mip_bytes):
+    """Roofline of the dominant ABI call.  Time: HIP events around the call, measured live.  Algorithmic bytes: DESIGN.md
+    section 4.  HBM traffic and instruction counts: rocprofv3 PMC passes recorded under profiles/ (tools/gpu_profile.sh +
+    tools/make_profile_record.py), used only while their source digest matches this tree (else null)."""
+    alg = views_per_launch * algorithmic_bytes(call, N, I, P, mip_bytes)
+    gbs = alg / (ms * 1e-3) / 1e9
+    traffic = _stamped("traffic.json")
+    traffic = None if traffic is None or call not in traffic else traffic[call] * views_per_launch / 8.0
+    hbm = {"achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+           "algorithmic_bytes_per_launch": alg}
+    if call not in VALU_BOUND_CALLS:
+        return dict(hbm, bound="hbm", kernel=call, traffic=traffic)
+    # the rasterizer moves ~1/10 of what HBM could deliver in its run time and keeps the vector ALUs busy instead:
+    # report the instruction-issue roofline (and the HBM numbers beside it)
+    valu = _stamped("valu.json")
+    insts = busy = None
+    if valu is not None:
+        for k, v in valu.items():
+            if k.startswith(VALU_BOUND_CALLS[call]) and "SQ_INSTS_VALU" in v:
+                insts = v["SQ_INSTS_VALU"] * views_per_launch / 8.0
+                if "SQ_ACTIVE_INST_VALU" in v and "GRBM_GUI_ACTIVE" in v:  # quad-cycles over 1024 SIMDs / XCD-summed cycles
+                    busy = 4.0 * v["SQ_ACTIVE_INST_VALU"] / 1024.0 / (v["GRBM_GUI_ACTIVE"] / 8.0)
+    ach = None if insts is None else insts / (ms * 1e-3) / 1e9
+    return {"bound": "valu", "kernel": call, "achieved": ach, "peak": VALU_PEAK_GINST, "unit": "G wave-instructions/s",
+            "frac": None if ach is None else ach / VALU_PEAK_GINST, "valu_busy_frac_pmc": busy,
+            "valu_instructions_per_launch": insts, "traffic": traffic, "hbm": hbm,
+            "evidence": "profiles/valu.json, profiles/traffic.json (rocprofv3 --pmc, same source digest)" if valu else
+                        "no PMC record for this source digest under profiles/: instruction count unavailable"}
 
 
 def cpu_baseline(cfg):
@@ -429,20 +480,6 @@ def e2e_main(args):
 
     from goliath_amd import _lib
 
-    reruns = [0]
-    raw_step = step
-
-    def step():
-        # the documented recovery protocol of the sync-free path: an overflowed intersection capacity is reported
-        # (late) by an exception after the capacity has been raised -- run the step again
-        try:
-            return raw_step()
-        except _lib.GoliathHipError as e:
-            if "capacity" not in str(e):
-                raise
-            reruns[0] += 1
-            return raw_step()
-
     loss_first = None
     for _ in range(args.warmup):
         l = step()
@@ -460,10 +497,6 @@ def e2e_main(args):
     barrier()
     dt = time.perf_counter() - t0
     timing, _lib.TIMING = _lib.TIMING, None
-    try:
-        splat.PLANNER.poll(block=True)
-    except _lib.GoliathHipError:
-        reruns[0] += 1  # an overflow in the very last steps: reported, nothing left to re-run
     if world > 1:
         import torch.distributed as dist
 
@@ -486,7 +519,9 @@ def e2e_main(args):
                "kernels_ms_per_call": ms, "hot_path_ms_per_step": sum(sum(v) for v in per.values()) / args.steps,
                # sanity signal of the whole gradient chain: the training loss on the fixed batch, first vs last step
                "loss_first_step": float(loss_first) if loss_first is not None else None,
-               "loss_last_step": float(l.detach()), "capacity_overflow_reruns": reruns[0]}
+               "loss_last_step": float(l.detach()),
+               # forwards whose intersection capacity overflowed and were repaired inside render_views (never an exception)
+               "capacity_overflow_reruns": splat.PLANNER.reruns}
         if args.segments:
             res["segments_ms"] = {"decoder_fwd" if not args.fused_tail else "decoder_trunk_fwd": seg[0] / args.steps,
                                   "tail_render_loss_and_all_backward": seg[1] / args.steps,
@@ -630,13 +665,19 @@ def main():
         dom = max(kernels_ms, key=kernels_ms.get)
         mip_bytes = sum(m[0].numel() * 4 for m in t["micro"][0]["mips"])
         views_per_launch = B // args.micro  # every ABI call processes one micro-batch
-        ach = views_per_launch * algorithmic_bytes(dom, N, I, P, mip_bytes) / (kernels_ms[dom] * 1e-3) / 1e9
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath):
-            traffic = json.load(open(tpath)).get(dom)
-            if traffic is not None:
-                traffic = traffic * views_per_launch / 8.0  # profiles/traffic.json is per 8-view launch
+        roofline = make_roofline(dom, kernels_ms[dom], views_per_launch, N, I, P, mip_bytes)
+        # every streaming call beside it: algorithmic GB/s, fraction of the 8 TB/s spec, PMC traffic / algorithmic bytes
+        per_call = {}
+        tr = _stamped("traffic.json")
+        for k, ms in kernels_ms.items():
+            try:
+                alg = views_per_launch * algorithmic_bytes(k, N, I, P, mip_bytes)
+            except KeyError:
+                continue
+            gbs = alg / (ms * 1e-3) / 1e9
+            per_call[k] = {"GBs": round(gbs, 1), "hbm_frac": round(gbs / HBM_PEAK_GBS, 4),
+                           "traffic_over_algorithmic": None if tr is None or k not in tr else
+                           round(tr[k] * views_per_launch / 8.0 / alg, 3)}
         views = B * world * args.steps
         res = {
             "metric": "relit views/sec (fwd+bwd) at 2048x1334, 250k Gaussians",
@@ -649,8 +690,8 @@ def main():
                                                                 "instrumented pass after the timed replays)", "relight": "envmap_4mips", "intersections_per_view": I,
                        "mean_alpha": mean_alpha, "parallelism": f"view-parallel x{world}"},
             "kernels_ms_per_call": kernels_ms,
-            "roofline": {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": ach / HBM_PEAK_GBS, "traffic": traffic},
+            "roofline": roofline,
+            "hbm_per_call": per_call,
         }
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(cfg)

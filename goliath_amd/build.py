@@ -33,6 +33,18 @@ def _headers():
     return hs
 
 
+def source_digest():
+    """sha256 (first 16 hex digits) over the kernel sources + the ABI header: identifies the code a profile under
+    profiles/ was measured on (the .git directory does not travel to the GPU box, file contents do)."""
+    import hashlib
+
+    h = hashlib.sha256()
+    for path in sorted(_sources() + _headers()):
+        h.update(os.path.basename(path).encode())
+        h.update(open(path, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def _stale(target, deps):
     if not os.path.exists(target):
         return True

@@ -23,18 +23,20 @@ if ROOT not in sys.path:
 
 TOL_OUT = 1e-4       # north_star: outputs within 1e-4 L2 (rgb, alpha)
 TOL_DEPTH = 2e-4     # depth / clamp(alpha, 0.05, 1): the division by a clamped alpha amplifies threshold-flip pixels 20x
-TOL_STAGE = 5e-4     # gradients at the raster / projection boundary: sums of signed float atomics + threshold-flip pixels
-TOL_LEAF = 5e-4      # leaf gradients with the 1e-4 worst Gaussians excluded (see below)
-TOL_LEAF_ALL = 3e-3  # leaf gradients, every Gaussian
+TOL_ROBUST = 2e-4    # every gradient, with the 1e-4 fraction of Gaussians with the largest error left out (see below)
+TOL_ALL = 3e-3       # every gradient, every Gaussian: the ~4e-5 fraction of threshold-flip pixels (a Gaussian at
+                     # alpha ~ 1/255 or a pixel at T ~ 1e-4 is composited by one implementation and skipped by the
+                     # other -- fast exp vs expf) concentrates O(1) relative errors on the few Gaussians of those pixels
 LEAVES = ("f_vn", "f_vc", "postex", "tn", "albedo")
 STAGE = ("color", "opacity", "primpos", "primscale", "primqvec")
 
 
 def _robust_rel_l2(a, b, drop=1e-4):
     """rel-L2 over [B, C, N]-shaped per-Gaussian gradients with the `drop` fraction of Gaussians with the largest error
-    left out: the env-map specular term is piecewise linear in the reflection direction (bilinear texel lookups,
-    mipmap_sampler.py:13-69), so its DERIVATIVE jumps at texel borders and a Gaussian whose lookup lands within rounding
-    of a border legitimately gets a different gradient on the two implementations."""
+    left out.  Two legitimate sources put O(1) errors on isolated Gaussians: threshold-flip pixels (above), and the
+    env-map specular term, which is piecewise linear in the reflection direction (bilinear texel lookups,
+    mipmap_sampler.py:13-69) -- its DERIVATIVE jumps at texel borders, so a lookup within rounding of a border gets a
+    different gradient on the two implementations.  Everything systematic shows up in this number."""
     a, b = a.double().cpu(), b.double().cpu()
     err = (a - b).pow(2).sum(1)                     # [B, N]
     k = max(1, int(drop * err.numel()))
@@ -108,7 +110,12 @@ def test_bench_step_matches_oracle_chain_at_config2(B):
     report["flip_pixel_fraction"] = flips / (B * H * W)
     report["pixels_off_by_more_than_1e-3"] = big / (B * H * W)
     report["loss"] = {"hip": loss, "oracle": ref_loss}
-    report["stage_grads"] = {k: rel_l2(mb["_stage"][k], torch.stack(ref_stage[k])) for k in STAGE}
+    report["stage_grads"], report["stage_grads_without_worst_1e-4_gaussians"] = {}, {}
+    for k in STAGE:
+        ref = torch.stack(ref_stage[k])                                   # [B, N, C]
+        report["stage_grads"][k] = rel_l2(mb["_stage"][k], ref)
+        report["stage_grads_without_worst_1e-4_gaussians"][k] = _robust_rel_l2(
+            mb["_stage"][k].reshape(B, ref.shape[1], -1).transpose(1, 2), ref.transpose(1, 2))
     report["grads_without_worst_1e-4_gaussians"] = {}
     for k in LEAVES:
         ref = torch.stack(ref_grads[k]).sum(0) if k == "albedo" else torch.cat(ref_grads[k], 0)
@@ -126,9 +133,9 @@ def test_bench_step_matches_oracle_chain_at_config2(B):
     for k, v in worst.items():
         assert v < (TOL_DEPTH if k == "depth" else TOL_OUT), (k, v)
     assert report["flip_pixel_fraction"] < 1e-3, report["flip_pixel_fraction"]  # expected << 0.1 %
-    for k, v in report["stage_grads"].items():
-        assert v < TOL_STAGE, (k, v)
-    for k, v in report["grads_without_worst_1e-4_gaussians"].items():
-        assert v < TOL_LEAF, (k, v)
-    for k, v in report["grads"].items():
-        assert v < TOL_LEAF_ALL, (k, v)
+    for name in ("stage_grads_without_worst_1e-4_gaussians", "grads_without_worst_1e-4_gaussians"):
+        for k, v in report[name].items():
+            assert v < TOL_ROBUST, (name, k, v)
+    for name in ("stage_grads", "grads"):
+        for k, v in report[name].items():
+            assert v < TOL_ALL, (name, k, v)

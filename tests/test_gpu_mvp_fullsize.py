@@ -28,6 +28,16 @@ if ROOT not in sys.path:
 GRADS = ("primpos", "primrot", "primscale", "template")
 
 
+def _record(tag, report):
+    """Keep the measured parity numbers next to the profiles (gpurun_out/ is merged back from the GPU box)."""
+    out_dir = os.path.join(ROOT, "gpurun_out")
+    if os.path.isdir(out_dir):
+        path = os.path.join(out_dir, "mvp_parity.json")
+        data = json.load(open(path)) if os.path.exists(path) else {}
+        data[tag] = report
+        json.dump(data, open(path, "w"), indent=1)
+
+
 def _oracle(fp, rp, rd, step, tm, case, go, fs, fe):
     from oracle import cref
 
@@ -77,6 +87,7 @@ def test_config5_ray_crops_match_oracle(y0, x0, h, w):
     ref84, rg84 = _oracle((8, 4, 512), rp.cpu(), rd.cpu(), 1.0 / 64, tm.cpu(), case, go, 8.0, 8.0)
     report["oracle_8x8_vs_reference_8x4"] = max([rel_l2(ref, ref84)] + [rel_l2(rg[k], rg84[k]) for k in GRADS])
     print("\nMVP_CONFIG5_PARITY " + json.dumps(report))
+    _record(f"config5_crop_{y0}_{x0}", report)
     assert report["oracle_8x8_vs_reference_8x4"] < 1e-6
     assert report["out"] < 1e-4, report
     for k in GRADS:
@@ -112,6 +123,7 @@ def test_footprint_over_the_512_hit_cap():
     report = {"hip_vs_oracle_8x8_cap512": rel_l2(out, ref88), **{f"grad_{k}": rel_l2(gr[k], g88[k]) for k in GRADS},
               "cap_effect_vs_uncapped": rel_l2(ref88, full), "oracle_8x8_vs_reference_8x4": rel_l2(ref88, ref84)}
     print("\nMVP_OVER_CAP " + json.dumps(report))
+    _record("over_512_cap", report)
     assert report["cap_effect_vs_uncapped"] > 1e-3          # the cap really truncates in this scene
     assert report["hip_vs_oracle_8x8_cap512"] < 1e-4, report
     for k in GRADS:

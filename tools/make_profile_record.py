@@ -1,0 +1,65 @@
+#!/usr/bin/env python
+"""Turn one run of tools/gpu_profile.sh (gpurun_out/TAG/) into the tracked evidence under profiles/:
+    profiles/TAG_bench.json, TAG_bench_micro1.json, TAG_kernel_stats.csv, TAG_pmc_traffic.csv, TAG_pmc_sq.csv
+    profiles/traffic.json   HBM-side bytes per 8-view launch of every C-ABI call = 2 * FETCH_SIZE + WRITE_SIZE
+                            (FETCH_SIZE doubled on gfx950, MI355X_MICROARCH.md; separate --pmc passes)
+    profiles/valu.json      SQ_INSTS_VALU / SQ_ACTIVE_INST_VALU / SQ_BUSY_CYCLES ... per 8-view launch of every kernel
+both stamped with the digest of the kernel sources they were measured on (goliath_amd.build.source_digest());
+bench.py uses them only while that digest still matches the tree.
+Usage: python tools/make_profile_record.py TAG"""
+import csv
+import json
+import os
+import shutil
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CALLS = {  # kernel-name prefix -> ABI call
+    "shade_fwd_kernel": "gol_shade_fwd", "shade_bwd_kernel": "gol_shade_bwd", "project_fwd_kernel": "gol_project_fwd",
+    "project_bwd_kernel": "gol_project_bwd", "count_lds_kernel": "gol_bin_sort", "count_kernel": "gol_bin_sort",
+    "scan_kernel": "gol_bin_sort", "scatter_lds_kernel": "gol_bin_sort", "scatter_kernel": "gol_bin_sort",
+    "sort_kernel": "gol_bin_sort", "bin_": "gol_bin_sort", "raster_fwd_kernel": "gol_rasterize_fwd",
+    "raster_bwd_kernel": "gol_rasterize_bwd", "l1_kernel<false>": "gol_l1_fwd", "l1_kernel<true>": "gol_l1_bwd",
+}
+
+
+def call_of(kernel):
+    return next((c for p, c in CALLS.items() if kernel.startswith(p)), None)
+
+
+def main(tag):
+    src = os.path.join(ROOT, "gpurun_out", tag)
+    dst = os.path.join(ROOT, "profiles")
+    sha = open(os.path.join(src, "csrc_sha16.txt")).read().strip()
+    head = open(os.path.join(src, "head.txt")).read().strip() if os.path.exists(os.path.join(src, "head.txt")) else ""
+    for f in ("bench.json", "bench_micro1.json", "kernel_stats.csv", "pmc_traffic.csv", "pmc_sq.csv"):
+        if os.path.exists(os.path.join(src, f)):
+            shutil.copy(os.path.join(src, f), os.path.join(dst, f"{tag}_{f}"))
+    stamp = {"csrc_sha16": sha, "commit": head, "source": f"profiles/{tag}_pmc_*.csv",
+             "command": "rocprofv3 --pmc <counters> -- python bench.py --micro 1 --no-graph --no-cpu-baseline --steps 3 "
+                        "--warmup 1 (8 views per launch; one pass per counter group; mean over the dispatches)"}
+    tpath = os.path.join(src, "pmc_traffic.csv")
+    if os.path.exists(tpath):
+        traffic = {}
+        for r in csv.DictReader(open(tpath)):
+            c = call_of(r["kernel"])
+            if c and r["FETCH_SIZE"] and r["WRITE_SIZE"]:
+                traffic[c] = traffic.get(c, 0.0) + 1024.0 * (2.0 * float(r["FETCH_SIZE"]) + float(r["WRITE_SIZE"]))
+        traffic["_stamp"] = dict(stamp, note="bytes per 8-view launch = 2*FETCH_SIZE + WRITE_SIZE (KiB counters); counts "
+                                              "L2->fabric requests, i.e. includes Infinity-Cache hits and memory-side atomics")
+        json.dump(traffic, open(os.path.join(dst, "traffic.json"), "w"), indent=1)
+    spath = os.path.join(src, "pmc_sq.csv")
+    if os.path.exists(spath):
+        valu = {}
+        for r in csv.DictReader(open(spath)):
+            valu[r["kernel"]] = {k: float(v) for k, v in r.items()
+                                 if k.startswith(("SQ_", "GRBM_")) and v not in ("", None)}
+            valu[r["kernel"]]["abi_call"] = call_of(r["kernel"])
+        valu["_stamp"] = dict(stamp, note="per 8-view launch; SQ_ACTIVE_INST_* / SQ_WAVE_CYCLES / SQ_WAIT_* count "
+                                          "quad-cycles summed over all SIMDs, GRBM_GUI_ACTIVE is summed over the 8 XCDs")
+        json.dump(valu, open(os.path.join(dst, "valu.json"), "w"), indent=1)
+    print("recorded", tag, "csrc", sha)
+
+
+if __name__ == "__main__":
+    main(sys.argv[1])
