@@ -47,12 +47,28 @@ def l1_image(pred: torch.Tensor, target: torch.Tensor, mask: Optional[torch.Tens
     return _L1.apply(pred.to(torch.float32).contiguous(), c(target), c(mask))
 
 
+def erode_mask(mask: torch.Tensor, ks: int) -> torch.Tensor:
+    """ca_code/utils/image.py:393-422 erode(): a pixel survives iff every pixel of its ks x ks window (zero-padded
+    complement) is set.  Returns a float mask of 0 / 1.  (A ks x ks box filter of the complement on a tiny tensor:
+    plain torch, it has no gradient and is not on the per-pixel hot path.)"""
+    assert ks % 2 == 1
+    x = mask.to(torch.float32)
+    if x.dim() == 3:
+        x = x[:, None]
+    flip = 1.0 - x
+    w = torch.ones(1, 1, ks, ks, device=x.device)
+    hit = torch.nn.functional.conv2d(flip.reshape(-1, 1, *x.shape[-2:]), w, padding=ks // 2) > 0
+    return 1.0 - hit.reshape(x.shape).to(torch.float32)
+
+
 def rgb_l1(preds, targets, src_key: str = "rendered_rgb", tgt_key: str = "image", mask_key: str = "image_mask",
            ddisc_key: str = "depth_disc_mask", mask_erode: Optional[int] = None):
-    """Same semantics as the reference's rgb_l1 (mask erosion is not fused: pass an eroded mask)."""
-    if mask_erode is not None:
-        raise NotImplementedError("mask_erode: erode the mask first (ca_code/utils/image.py) and pass it in")
+    """Same semantics as the reference's rgb_l1 (ca_code/loss/__init__.py:391-411), incl. `mask_erode`."""
     mask = targets.get(mask_key, preds.get(mask_key, None))
+    if mask_erode is not None:
+        if mask is None:
+            mask = torch.ones_like(preds[src_key])
+        mask = (erode_mask(mask, mask_erode) > 0).to(torch.float32)  # .to(th.bool) in the reference
     if ddisc_key in preds:
         d = preds[ddisc_key]
         inv = (~d).float() if d.dtype == torch.bool else (1 - d)

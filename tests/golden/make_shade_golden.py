@@ -6,8 +6,9 @@ does not exist on the GPU box, which is why the vectors are committed.  Third-pa
 are missing here (cv2, torchvision, pytorch3d, gsplat) are stubbed -- none of them is executed by
 the shading tail.  The two conv decoders and the geometry module are replaced by fakes that return
 seeded tensors, so lines 505-620 run unmodified on known inputs.  The CUDA-only
-`sgutilslib.evaluate_gaussian_fwd/bwd` is served by the C oracle (oracle/sg_oracle.c); the
-environment-map branch (dir2uv + mipmap_grid_sample) is 100 % reference code.
+`sgutilslib.evaluate_gaussian_fwd/bwd` is served by the reference's OWN sg.cu kernels compiled for the
+host (oracle/_ref/libref.so, see oracle/Makefile); the environment-map branch (dir2uv +
+mipmap_grid_sample) is reference code as well -- every number in the fixture comes from reference code.
 """
 import os
 import sys
@@ -19,49 +20,37 @@ import torch
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, HERE)
 sys.path.insert(0, "/root/reference")
 
 from oracle import cref  # noqa: E402
 
 
-def _stub(name, **attrs):
-    m = types.ModuleType(name)
-    m.__dict__.update(attrs)
-    sys.modules[name] = m
-    return m
-
-
 def install_stubs():
-    class _Any(types.ModuleType):
-        def __getattr__(self, name):  # any cv2.CONSTANT used as a default argument
-            return 0
+    """Stand-ins for the third-party imports (tests/golden/ref_stubs.py).  The CUDA-only sgutilslib is served by the
+    reference's OWN kernels compiled for the host (oracle/_ref/libref.so) when built, else by the C restatement."""
+    import ref_stubs
+    from oracle import refso
 
-    sys.modules["cv2"] = _Any("cv2")
-    tv = _stub("torchvision")
-    tv.utils = _stub("torchvision.utils", make_grid=lambda *a, **k: None)
-    tv.transforms = _stub("torchvision.transforms")
-    tv.transforms.functional = _stub("torchvision.transforms.functional", gaussian_blur=lambda *a, **k: None)
-    _stub("pytorch3d")
-    _stub("pytorch3d.renderer")
-    _stub("pytorch3d.renderer.mesh")
-    _stub("pytorch3d.renderer.mesh.rasterize_meshes", rasterize_meshes=None)
-    _stub("pytorch3d.structures", Meshes=None)
-    _stub("gsplat", project_gaussians=None, rasterize_gaussians=None)
+    impl = refso if refso.available() else cref
 
-    def fwd(lobe_dirs, lobe_sigmas, light_values, light_pts, prim_pts, n_lights, integral, w_type):
-        integral.copy_(cref.evaluate_gaussian_fwd(lobe_dirs, lobe_sigmas, light_values, light_pts, prim_pts,
-                                                  n_lights, w_type))
-        return []
+    class _SgLib:
+        @staticmethod
+        def evaluate_gaussian_fwd(lobe_dirs, lobe_sigmas, light_values, light_pts, prim_pts, n_lights, integral, w_type):
+            integral.copy_(impl.evaluate_gaussian_fwd(lobe_dirs, lobe_sigmas, light_values, light_pts, prim_pts,
+                                                      n_lights, w_type))
+            return []
 
-    def bwd(lobe_dirs, lobe_sigmas, light_values, light_pts, prim_pts, n_lights, grad_integral, grad_dirs,
-            grad_sigmas, grad_light_values, w_type):
-        gd, gs, _ = cref.evaluate_gaussian_bwd(lobe_dirs, lobe_sigmas, light_values, light_pts, prim_pts, n_lights,
-                                               grad_integral, w_type)
-        grad_dirs.copy_(gd)
-        grad_sigmas.copy_(gs)
-        return []
+        @staticmethod
+        def evaluate_gaussian_bwd(lobe_dirs, lobe_sigmas, light_values, light_pts, prim_pts, n_lights, grad_integral,
+                                  grad_dirs, grad_sigmas, grad_light_values, w_type):
+            gd, gs, _ = impl.evaluate_gaussian_bwd(lobe_dirs, lobe_sigmas, light_values, light_pts, prim_pts, n_lights,
+                                                   grad_integral, w_type)
+            grad_dirs.copy_(gd)
+            grad_sigmas.copy_(gs)
+            return []
 
-    _stub("sgutilslib", evaluate_gaussian_fwd=fwd, evaluate_gaussian_bwd=bwd)
+    ref_stubs.install(sgutilslib=_SgLib)
 
 
 class FakeGeo:

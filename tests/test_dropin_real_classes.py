@@ -1,0 +1,123 @@
+"""CPU: the drop-in against the REAL reference classes (VERDICT r1 "next" #10).
+
+With stand-ins for the third-party imports this image lacks (tests/golden/ref_stubs.py), `ca_code.models.rgca`,
+`ca_code.utils.shadowmap` and `ca_code.loss` import unchanged from /root/reference.  Checked here:
+  * dropin.patch_rgca() / patch_urhand() / patch_losses() replace PrimDecoder.forward, AutoEncoder.render,
+    get_shadow_map, rgb_l1, rgb_ssim by callables with the SAME parameter lists (names, order, defaults, kinds) --
+    `filter_inputs` (ca_code/utils/train.py:99-116) selects batch entries by introspection, so names matter;
+  * a real `PrimDecoder` (reference architecture, 162.8 M parameters) qualifies for the fused decoder tail, its
+    state_dict loads strictly into goliath_amd.decoder.PrimDecoderConvs and back, and the light-contracted tail
+    (goliath_amd/tail.py) applied to the REFERENCE layer's parameters reproduces `layer(x)` contracted with the light
+    at the native 1024^2 slab;
+  * rgb_l1(mask_erode=...) == the reference's rgb_l1 on CPU-computable pieces (the erosion)."""
+import inspect
+import os
+import sys
+
+import pytest
+import torch
+
+REF = "/root/reference"
+pytestmark = pytest.mark.skipif(not os.path.isdir(REF), reason="reference tree only exists in the build container")
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+
+
+def _params(fn):
+    return [(p.name, p.kind, p.default) for p in inspect.signature(fn).parameters.values()]
+
+
+@pytest.fixture(scope="module")
+def ref():
+    import types
+
+    import ref_stubs
+
+    ref_stubs.install()
+    sys.modules.setdefault("sgutilslib", types.ModuleType("sgutilslib"))
+    import ca_code.loss as L
+    import ca_code.models.rgca as R
+    import ca_code.utils.shadowmap as SM
+
+    return types.SimpleNamespace(R=R, SM=SM, L=L)
+
+
+def test_patched_entry_points_keep_the_reference_signatures(ref):
+    from goliath_amd import dropin, losses, shadowmap
+
+    R = ref.R
+    orig_fwd, orig_render = R.PrimDecoder.forward, R.AutoEncoder.render
+    try:
+        assert dropin.patch_rgca(R) is R
+        assert R.PrimDecoder.forward is not orig_fwd and R.AutoEncoder.render is not orig_render
+        assert _params(R.PrimDecoder.forward) == _params(orig_fwd)
+        assert _params(R.AutoEncoder.render) == _params(orig_render)
+    finally:
+        R.PrimDecoder.forward, R.AutoEncoder.render = orig_fwd, orig_render
+    assert _params(shadowmap.get_shadow_map) == _params(ref.SM.get_shadow_map)
+    assert _params(losses.rgb_l1) == _params(ref.L.rgb_l1)
+    assert _params(losses.rgb_ssim) == _params(ref.L.rgb_ssim)
+    # AutoEncoder.forward is NOT replaced: its parameter list (what filter_inputs introspects) is the reference's own
+    assert "preconv_envmap" in inspect.signature(R.AutoEncoder.forward).parameters
+
+
+def test_loss_registry_patch_on_the_real_registry(ref):
+    from goliath_amd import dropin, losses
+
+    import ca_code.loss.registry as reg
+
+    saved = dict(reg.loss_registry)
+    try:
+        dropin.patch_losses(reg)
+        mod = reg.loss_registry["rgb_l1"](None, src_key="rgb", mask_erode=5)
+        assert isinstance(mod, reg.FnLoss) and mod.fn is losses.rgb_l1 and mod.extra_args["mask_erode"] == 5
+        assert reg.loss_registry["rgb_ssim"](None).fn is losses.rgb_ssim
+        assert set(reg.loss_registry) == set(saved)  # nothing else touched
+    finally:
+        reg.loss_registry.clear()
+        reg.loss_registry.update(saved)
+
+
+def test_mask_erode_matches_reference_erode(ref):
+    from goliath_amd import losses
+
+    from ca_code.utils.image import erode
+
+    g = torch.Generator().manual_seed(0)
+    mask = (torch.rand(2, 1, 40, 33, generator=g) > 0.15).float()
+    for ks in (3, 5, 9):
+        assert torch.equal(losses.erode_mask(mask, ks), erode(mask, ks))
+    assert torch.equal(losses.erode_mask(mask[:, 0] > 0, 3)[:, 0] > 0, erode(mask[:, 0] > 0, 3)[:, 0])
+
+
+def test_real_prim_decoder_takes_the_fused_tail_branch(ref):
+    from goliath_amd import decoder, rgca, tail
+
+    torch.manual_seed(0)
+    dec = ref.R.PrimDecoder(256, None, torch.rand(3, 1024, 1024) * 255.0)
+    with torch.no_grad():  # a "trained" state: non-trivial untied bias and magnitudes
+        for m in (dec.vnocond_mod[-1], dec.vcond_mod[-1]):
+            m.bias.normal_(0.0, 0.1)
+            m.weight_g.mul_(1.0 + 0.2 * torch.rand_like(m.weight_g))
+    assert rgca._can_fuse_tail(dec)
+    # state_dict: reference -> ours -> reference, strict both ways
+    sd = dec.state_dict()
+    mine = decoder.PrimDecoderConvs()
+    missing = mine.load_state_dict({k: v for k, v in sd.items() if k != "albedo"}, strict=True)
+    assert not missing.missing_keys and not missing.unexpected_keys
+    back = dict(mine.state_dict(), albedo=sd["albedo"])
+    dec.load_state_dict(back, strict=True)
+    # the light-contracted tail on the reference layer's own parameters == the reference layer, then the contraction
+    last = dec.vnocond_mod[-1]
+    ncol, nmono = dec.n_color_sh_coeffs, dec.n_mono_sh_coeffs
+    nd = 3 * ncol + nmono
+    x = torch.randn(1, 16, 512, 512)
+    L = torch.randn(1, 3, ncol + nmono)
+    with torch.no_grad():
+        f = last(x)                                                   # [1, 125, 1024, 1024], the reference's layer
+        assert torch.allclose(mine.vnocond_mod[-1](x), f, atol=1e-5)  # our module with the loaded state: same output
+        Lc = tail.light_matrix(L, ncol, nmono)                       # rgca.py:506-514 + :528-530 as one matrix
+        want = torch.cat([torch.einsum("bek,bkn->ben", Lc, f[:, :nd].reshape(1, nd, -1)), f[:, nd:].reshape(1, 12, -1)], 1)
+        got, E = tail.contracted_vnocond_torch(x, tail.wn_weight(last), last.bias, L, None, ncol, nmono)
+    assert E == 3
+    err = float((got.reshape(1, 15, -1) - want).norm() / want.norm())
+    assert err < 1e-5, err
