@@ -35,13 +35,15 @@ def install():
 
 
 def patch_rgca(rgca_module=None):
-    """Swap AutoEncoder.render (rgca.py:112-151) and PrimDecoder.forward (rgca.py:466-620) for the
-    batched / fused versions in goliath_amd.rgca.  Returns the patched module."""
+    """Swap AutoEncoder.render (rgca.py:112-151), AutoEncoder.forward (rgca.py:153-253: the image tail after the render
+    becomes one fused pass) and PrimDecoder.forward (rgca.py:466-620) for the batched / fused versions in
+    goliath_amd.rgca.  Returns the patched module."""
     from . import rgca as fused
 
     if rgca_module is None:
         import ca_code.models.rgca as rgca_module
     rgca_module.AutoEncoder.render = fused.autoencoder_render
+    rgca_module.AutoEncoder.forward = fused.autoencoder_forward
     rgca_module.PrimDecoder.forward = fused.prim_decoder_forward
     return rgca_module
 

@@ -346,6 +346,27 @@ int gol_shadow_pcf(int B, int L, int H, int W, int dh, int dw, const float* dept
                    float cx, float cy, const float* postex, const float* nml, float exp_scale, float* out,
                    void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Image tail of AutoEncoder.forward between the rasterizer and the losses, one pass each way over
+ * rgb[B,3,H,W]:  out = blur( cal(rgb) + (1 - alpha) * bg * bg_scale )
+ *   cal      CalV5.forward, ca_code/nn/color_cal.py:211-241, as cal_M[B,3,3] / cal_b[B,3] (both NULL = identity):
+ *            cal(rgb)[c] = sum_j cal_M[b,c,j] * rgb[j] + cal_b[b,c]  (grey cameras: three identical rows)
+ *   alpha[B,H,W], bg[B,3,H,W] (both NULL = no composite), bg_scale[B] or NULL: ca_code/models/rgca.py:226-230
+ *   blur_w[B,3] (NULL = no blur): LearnableBlur.forward, ca_code/nn/dof_cal.py:44-56, softmaxed weights of
+ *            (identity, gaussian_blur 3x3, gaussian_blur 7x7), torchvision semantics (reflect padding, H, W >= 4)
+ * bwd: g_rgb[B,3,H,W] is written; `partials` (gol_imgtail_partial_floats(B,H,W) floats, [B, tiles, 16]) receives
+ *   per-workgroup partial sums of the parameter gradients -- columns 0..2 blur_w, 3..5 cal_b, 6..14 cal_M (row-major)
+ *   -- to be summed over `tiles` by the caller (no float atomics).  No gradient to alpha / bg (alpha is detached in the
+ *   reference, rgca.py:137).
+ * ---------------------------------------------------------------------------------------- */
+int64_t gol_imgtail_partial_floats(int B, int H, int W);
+int gol_imgtail_fwd(int B, int H, int W, const float* rgb, const float* alpha, const float* bg,
+                    const float* bg_scale, const float* cal_M, const float* cal_b, const float* blur_w,
+                    float* out, void* stream);
+int gol_imgtail_bwd(int B, int H, int W, const float* rgb, const float* alpha, const float* bg,
+                    const float* bg_scale, const float* cal_M, const float* cal_b, const float* blur_w,
+                    const float* g_out, float* g_rgb, float* partials, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

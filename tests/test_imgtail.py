@@ -1,0 +1,138 @@
+"""Image tail (colour calibration + background composite + LearnableBlur) against goldens produced by the
+reference's own CalV5 / LearnableBlur modules (tests/golden/make_imgtail_golden.py).
+CPU: the host glue `cal_v5_matrix` (CalV5.forward as a per-view matrix, incl. the training gradient hook).
+GPU: the fused HIP pass, values and every gradient (rgb, calibration parameters, blur weights), rel-L2 <= 1e-5."""
+import os
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from scenes import rel_l2
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CASES = ("all", "blur_only", "cal_only", "tiny")
+
+
+def load():
+    z = np.load(os.path.join(HERE, "golden", "imgtail_golden.npz"))
+    return {k: (torch.from_numpy(z[k]) if z[k].dtype.kind in "fb" else z[k]) for k in z.files}
+
+
+class _Cal(torch.nn.Module):
+    """The attributes of a CalV5 that cal_v5_matrix reads (color_cal.py:103-139), on golden parameters."""
+
+    def __init__(self, G, tag, device):
+        super().__init__()
+        cams = sorted(str(c) for c in G["cameras"])                      # ParamHolder sorts its keys
+        self.cams = cams
+        self.params = torch.nn.Parameter(G[f"{tag}/cal_params"].to(device))
+        self.identity_idx = cams.index(str(G["identity"]))
+        self.grey_idxs = [i for i, c in enumerate(cams) if c.startswith("41")]
+        self.gs_lrscale, self.col_lrscale = 1.0, 0.1
+
+    def holder(self, idxs):
+        return self.params[idxs]
+
+    def name_to_idx(self, names):
+        return torch.tensor([self.cams.index(str(n)) for n in names], device=self.params.device)
+
+
+def _run(G, tag, device, tail_fn):
+    use_cal, use_bg, use_blur = (bool(v) for v in G[f"{tag}/flags"])
+    cams = [str(c) for c in G[f"{tag}/cams"]]
+    cal = _Cal(G, tag, device).train()
+    rgb = G[f"{tag}/rgb"].to(device).requires_grad_(True)
+    blur_raw = G[f"{tag}/blur_raw"].to(device).requires_grad_(True)
+    idx = cal.name_to_idx(cams)
+    M = b = bw = alpha = bg = lit = None
+    from goliath_amd import imgtail
+
+    if use_cal:
+        M, b = imgtail.cal_v5_matrix(cal, idx)
+    if use_bg:
+        alpha, bg, lit = G[f"{tag}/alpha"].to(device), G[f"{tag}/background"].to(device), G[f"{tag}/lit"].to(device).float()
+    if use_blur:
+        bw = torch.softmax(blur_raw[idx], dim=-1)
+    out = tail_fn(rgb, alpha, bg, lit, M, b, bw)
+    (out * G[f"{tag}/w"].to(device)).sum().backward()
+    return out, rgb.grad, cal.params.grad, blur_raw.grad
+
+
+def test_cal_v5_matrix_reproduces_calv5_forward_and_its_gradient_hook():
+    G = load()
+
+    def torch_tail(rgb, alpha, bg, lit, M, b, bw):  # plain torch: only the calibration is exercised here
+        return torch.einsum("bcj,bjhw->bchw", M, rgb) + b[:, :, None, None]
+
+    out, g_rgb, g_cal, _ = _run(G, "cal_only", "cpu", torch_tail)
+    assert rel_l2(out, G["cal_only/out"]) < 1e-6
+    assert rel_l2(g_rgb, G["cal_only/g_rgb"]) < 1e-6
+    assert rel_l2(g_cal, G["cal_only/g_cal"]) < 1e-5
+    # the identity camera's row gets no gradient, exactly like the reference (its image is passed through)
+    cal = _Cal(G, "cal_only", "cpu")
+    assert float(g_cal[cal.identity_idx].abs().max()) == 0.0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", CASES)
+def test_fused_image_tail_matches_reference_modules(tag):
+    from goliath_amd import imgtail
+
+    G = load()
+    out, g_rgb, g_cal, g_blur = _run(G, tag, "cuda", imgtail.image_tail)
+    assert rel_l2(out, G[f"{tag}/out"]) < 1e-5, rel_l2(out, G[f"{tag}/out"])
+    assert rel_l2(g_rgb, G[f"{tag}/g_rgb"]) < 1e-5, rel_l2(g_rgb, G[f"{tag}/g_rgb"])
+    use_cal, _, use_blur = (bool(v) for v in G[f"{tag}/flags"])
+    if use_cal:
+        assert rel_l2(g_cal, G[f"{tag}/g_cal"]) < 2e-5, rel_l2(g_cal, G[f"{tag}/g_cal"])
+    if use_blur:
+        assert rel_l2(g_blur, G[f"{tag}/g_blur"]) < 2e-5, rel_l2(g_blur, G[f"{tag}/g_blur"])
+
+
+@pytest.mark.gpu
+def test_autoencoder_image_tail_on_a_module_shaped_like_the_reference():
+    """rgca.py:223-231 + :249-251 driven through the module-level entry point (cal_enabled / learn_blur_enabled /
+    training flags, camera-name lookup)."""
+    from goliath_amd import imgtail
+
+    G = load()
+    tag = "all"
+    cams = [str(c) for c in G[f"{tag}/cams"]]
+    me = torch.nn.Module()
+    me.cal_enabled = me.learn_blur_enabled = True
+    me.cal = _Cal(G, tag, "cuda")
+    all_cams = sorted(str(c) for c in G["cameras"])                      # LearnableBlur keeps the given order
+    raw = torch.nn.Parameter(G[f"{tag}/blur_raw"].cuda())
+    order = [str(c) for c in G["cameras"]]
+    me.learn_blur = types.SimpleNamespace(reg=lambda names: raw[torch.tensor([order.index(n) for n in names]).cuda()])
+    me.train()
+    me.cal.train()
+    rgb = G[f"{tag}/rgb"].cuda().requires_grad_(True)
+    out, reg = imgtail.autoencoder_image_tail(me, rgb, G[f"{tag}/alpha"].cuda(), cams, G[f"{tag}/background"].cuda(),
+                                              G[f"{tag}/lit"].cuda())
+    assert rel_l2(out, G[f"{tag}/out"]) < 1e-5 and reg.shape == (len(cams), 3)
+    assert all_cams  # (silence linters)
+    me.eval()        # inference: no background composite, calibration and blur stay
+    out_eval, _ = imgtail.autoencoder_image_tail(me, rgb, G[f"{tag}/alpha"].cuda(), cams, G[f"{tag}/background"].cuda(),
+                                                 G[f"{tag}/lit"].cuda())
+    assert rel_l2(out_eval, out) > 1e-3
+
+
+@pytest.mark.gpu
+def test_image_tail_full_size_properties():
+    """2048x1334 x 8 views: identity configuration returns the input; blur weights (1, 0, 0) == no blur; the blur
+    preserves a constant image (kernels are normalised, reflect padding)."""
+    from goliath_amd import imgtail
+
+    g = torch.Generator(device="cuda").manual_seed(0)
+    rgb = torch.rand(8, 3, 2048, 1334, device="cuda", generator=g)
+    eye = torch.eye(3, device="cuda").expand(8, 3, 3).contiguous()
+    zero = torch.zeros(8, 3, device="cuda")
+    assert torch.equal(imgtail.image_tail(rgb, cal_M=eye, cal_b=zero), rgb)
+    w = torch.tensor([[1.0, 0.0, 0.0]], device="cuda").expand(8, 3).contiguous()
+    assert rel_l2(imgtail.image_tail(rgb, blur_weights=w), rgb) < 1e-7
+    const = torch.full_like(rgb, 0.37)
+    w = torch.tensor([[0.2, 0.3, 0.5]], device="cuda").expand(8, 3).contiguous()
+    assert float((imgtail.image_tail(const, blur_weights=w) - 0.37).abs().max()) < 1e-6
