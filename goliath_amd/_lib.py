@@ -21,7 +21,7 @@ _SYMBOLS = [
     "gol_mvp_march_bwd", "gol_envmap_pack", "gol_uvlight_phong_fwd", "gol_uvlight_phong_bwd",
     "gol_uvlight_ggx_fwd", "gol_uvlight_ggx_bwd", "gol_l1_blocks", "gol_l1_fwd", "gol_l1_bwd",
     "gol_tail_conv_fwd", "gol_tail_conv_bwd", "gol_tail_conv_bwd_scratch_floats", "gol_ssim_blocks", "gol_ssim_fwd", "gol_ssim_bwd",
-    "gol_shadow_pcf", "gol_imgtail_partial_floats", "gol_imgtail_fwd", "gol_imgtail_bwd",
+    "gol_shadow_pcf", "gol_imgtail_partial_floats", "gol_imgtail_fwd", "gol_imgtail_bwd", "gol_mvp_shadow_march", "gol_mesh_raster_workspace_bytes", "gol_mesh_raster",
 ]
 
 

@@ -262,6 +262,8 @@ struct MarchArgs {
   float stepsize, fadescale, fadeexp;
   const float* raypos; const float* raydir; const float* tminmax; const float* nodeaabb;
   const float* primpos; const float* primrot; const float* primscale; const float* tplate;
+  int group = 1;          // `group` consecutive ray images share one primitive set / template (light-batched shadow march)
+  int alpha_only = 0;     // template has ONE channel (alpha); colour channels read as 0
 };
 
 __device__ __forceinline__ bool load_ray(const MarchArgs& a, int n, Ray& ray, float& tmin, float& tmax, size_t& r,
@@ -305,12 +307,14 @@ __global__ __launch_bounds__(256) void march_fwd_kernel(MarchArgs a, float* __re
   Ray ray; float tmin, tmax; size_t r; int wave;
   load_ray(a, n, ray, tmin, tmax, r, wave);
   const size_t vox = (size_t)a.TD * a.TH * a.TW;
-  const float* primpos = a.primpos + (size_t)n * a.K * 3;
-  const float* primrot = a.primrot + (size_t)n * a.K * 9;
-  const float* primscale = a.primscale + (size_t)n * a.K * 3;
-  const float4* tplate = reinterpret_cast<const float4*>(a.tplate) + (size_t)n * a.K * vox;
+  const int pn = n / a.group;  // primitive set of this ray image
+  const float* primpos = a.primpos + (size_t)pn * a.K * 3;
+  const float* primrot = a.primrot + (size_t)pn * a.K * 9;
+  const float* primscale = a.primscale + (size_t)pn * a.K * 3;
+  const float4* tplate = reinterpret_cast<const float4*>(a.tplate) + (size_t)pn * a.K * vox;
+  const float* tplate_a = a.tplate + (size_t)pn * a.K * vox;  // alpha-only layout
   float* shadow_n = SHADOW ? shadow + (size_t)n * a.K * vox * 2 : nullptr;
-  const int num = build_hits(a.K, a.nodeaabb + (size_t)n * (2 * a.K - 1) * 6, primpos, primrot, primscale, a.stepsize,
+  const int num = build_hits(a.K, a.nodeaabb + (size_t)pn * (2 * a.K - 1) * 6, primpos, primrot, primscale, a.stepsize,
                              tmin, tmax, ray, s_list[wave], s_lo[wave], s_hi[wave]);
 
   float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f, sat0 = -1.f, sat1 = -1.f, sat2 = -1.f;
@@ -337,13 +341,20 @@ __global__ __launch_bounds__(256) void march_fwd_kernel(MarchArgs a, float* __re
                                                   fade_pow(fabsf(y0.z), a.fadeexp, e8)));
         Tri q;
         tri_setup(q, a.TD, a.TH, a.TW, y0);
-        const float4* tp = tplate + (size_t)k * vox;
         float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        if (a.alpha_only) {  // (kernel-uniform) shadow march: 4 bytes per voxel instead of 16
+          const float* tp = tplate_a + (size_t)k * vox;
 #pragma unroll
-        for (int c = 0; c < 8; ++c) {
-          if (q.idx[c] >= 0) {
-            const float4 v = tp[q.idx[c]];
-            s0 += v.x * q.w[c]; s1 += v.y * q.w[c]; s2 += v.z * q.w[c]; s3 += v.w * q.w[c];
+          for (int c = 0; c < 8; ++c)
+            if (q.idx[c] >= 0) s3 += tp[q.idx[c]] * q.w[c];
+        } else {
+          const float4* tp = tplate + (size_t)k * vox;
+#pragma unroll
+          for (int c = 0; c < 8; ++c) {
+            if (q.idx[c] >= 0) {
+              const float4 v = tp[q.idx[c]];
+              s0 += v.x * q.w[c]; s1 += v.y * q.w[c]; s2 += v.z * q.w[c]; s3 += v.w * q.w[c];
+            }
           }
         }
         s3 *= fade;
@@ -389,7 +400,7 @@ __global__ __launch_bounds__(256) void march_fwd_kernel(MarchArgs a, float* __re
     ray.pos = ray.pos + ray.dir * a.stepsize;
     ++iter;
   }
-  if (ray.live) {
+  if (ray.live && rayrgba) {
     *reinterpret_cast<float4*>(rayrgba + 4 * r) = make_float4(acc0, acc1, acc2, acc3);
     if (raysat) { raysat[3 * r] = sat0; raysat[3 * r + 1] = sat1; raysat[3 * r + 2] = sat2; }
   }
@@ -617,6 +628,25 @@ extern "C" int gol_mvp_march_fwd(int N, int H, int W, int K, const float* raypos
   dim3 grid(gol_cdiv(W, 16), gol_cdiv(H, 16), N);
   if (shadow) march_fwd_kernel<true><<<grid, 256, 0, (hipStream_t)stream>>>(a, rayrgba, raysat, shadow);
   else march_fwd_kernel<false><<<grid, 256, 0, (hipStream_t)stream>>>(a, rayrgba, raysat, shadow);
+  GOL_CHECK_LAUNCH();
+  return GOL_OK;
+}
+
+extern "C" int gol_mvp_shadow_march(int N, int group, int H, int W, int K, const float* raypos, const float* raydir,
+                                    float stepsize, const float* tminmax, const float* nodeaabb, const float* primpos,
+                                    const float* primrot, const float* primscale, const float* tplate, int alpha_only,
+                                    int TD, int TH, int TW, float fadescale, float fadeexp, float* rayrgba, float* shadow,
+                                    void* stream) {
+  int rc = check_march(N, H, W, K, TD, TH, TW, stepsize);
+  if (rc != GOL_OK) return rc;
+  GOL_REQUIRE(group >= 1 && N % group == 0, "N must be a multiple of group");
+  if (N == 0 || H == 0 || W == 0) return GOL_OK;
+  GOL_REQUIRE(raypos && raydir && tminmax && nodeaabb && primpos && primrot && primscale && tplate && shadow,
+              "null pointer");
+  MarchArgs a{N, H, W, K, TD, TH, TW, stepsize, fadescale, fadeexp, raypos, raydir, tminmax, nodeaabb,
+              primpos, primrot, primscale, tplate, group, alpha_only ? 1 : 0};
+  dim3 grid(gol_cdiv(W, 16), gol_cdiv(H, 16), N);
+  march_fwd_kernel<true><<<grid, 256, 0, (hipStream_t)stream>>>(a, rayrgba, nullptr, shadow);
   GOL_CHECK_LAUNCH();
   return GOL_OK;
 }

@@ -280,26 +280,9 @@ __device__ __forceinline__ void spec_forward(const gol_shade_in& in, int b, cons
 }
 
 template <int V, bool ENV, bool RAND>
-__global__ __launch_bounds__(256) void shade_fwd_kernel(const gol_shade_in in, const gol_shade_out out, int nx) {
-  // 1-D grid.  With an environment map every Gaussian gathers 8 texels of ITS view's mip pyramid (10 MB per view):
-  // band the workgroups so that die x (= blockIdx % 8, observed) works on its own view(s) and its 4 MB L2 holds texels
-  // of one pyramid instead of all of them.  Speed only -- any mapping is correct.
-  const int lin = blockIdx.x, B = in.B;
-  int b, chunk;
-  if (ENV && B % 8 == 0) {
-    const int j = lin >> 3;
-    b = (lin & 7) * (B >> 3) + j / nx;
-    chunk = j % nx;
-  } else if (ENV && 8 % B == 0) {
-    const int g = 8 / B, xcd = lin & 7;
-    b = xcd / g;
-    chunk = (lin >> 3) * g + xcd % g;
-    if (chunk >= nx) return;
-  } else {
-    b = lin / nx;
-    chunk = lin - b * nx;
-  }
-  const int i0 = (chunk * 256 + threadIdx.x) * V;
+__global__ __launch_bounds__(256) void shade_fwd_kernel(const gol_shade_in in, const gol_shade_out out) {
+  const int b = blockIdx.y;
+  const int i0 = (blockIdx.x * 256 + threadIdx.x) * V;
   const int N = in.N;
   if (i0 >= N) return;
   const int ncol = in.n_color_coef, nmono = in.n_mono_coef, ncoef = ncol + nmono, nd = 3 * ncol + nmono;
@@ -719,14 +702,11 @@ extern "C" int gol_envmap_pack(int B, int h, int w, const float* src, float* dst
 
 #define GOL_SHADE_FWD_V(V, ...)                                                                   \
   do {                                                                                           \
-    const int nx = gol_cdiv(in->N / V, 256), Bv = in->B;                                         \
-    long long nblk = (long long)nx * Bv;                                                         \
-    if (env && Bv % 8 != 0 && 8 % Bv == 0) nblk = 8ll * gol_cdiv(nx, 8 / Bv);                    \
-    dim3 grid((unsigned)nblk);                                                                   \
-    if (env && rnd) shade_fwd_kernel<V, true, true><<<grid, 256, 0, s>>>(__VA_ARGS__, nx);       \
-    else if (env) shade_fwd_kernel<V, true, false><<<grid, 256, 0, s>>>(__VA_ARGS__, nx);        \
-    else if (rnd) shade_fwd_kernel<V, false, true><<<grid, 256, 0, s>>>(__VA_ARGS__, nx);        \
-    else shade_fwd_kernel<V, false, false><<<grid, 256, 0, s>>>(__VA_ARGS__, nx);                \
+    dim3 grid(gol_cdiv(in->N / V, 256), in->B);                                                  \
+    if (env && rnd) shade_fwd_kernel<V, true, true><<<grid, 256, 0, s>>>(__VA_ARGS__);           \
+    else if (env) shade_fwd_kernel<V, true, false><<<grid, 256, 0, s>>>(__VA_ARGS__);            \
+    else if (rnd) shade_fwd_kernel<V, false, true><<<grid, 256, 0, s>>>(__VA_ARGS__);            \
+    else shade_fwd_kernel<V, false, false><<<grid, 256, 0, s>>>(__VA_ARGS__);                    \
   } while (0)
 
 // 4 Gaussians per lane (16-byte plane loads) when N allows, else 2 (8-byte), else 1

@@ -24,6 +24,11 @@ def _need_gpu(t, name):
         raise _lib.GoliathHipError(f"{name} must be a CUDA tensor (there is no CPU path)")  # CHECK_INPUT
 
 
+def _gpu_contig(t, name):
+    _need_gpu(t, name)
+    return t.detach().to(torch.float32).contiguous()
+
+
 def _dims(template):
     if template.dim() != 6 or template.size(-1) != 4:
         raise RuntimeError("template must be channels-last [N, K, TD, TH, TW, 4]")
@@ -171,6 +176,38 @@ def mvpraymarch(raypos, raydir, stepsize, tminmax, primtransf, template, warp, r
     if with_shadow:
         return out, shadow[..., 0:1] / (shadow[..., 1:] + 1e-5)
     return out
+
+
+def shadow_march(raypos, raydir, stepsize, tminmax, primtransf, alpha_template, lights_per_frame, fadescale=8.0,
+                 fadeexp=8.0, return_image=False):
+    """The teacher model's deep-shadow march, hand_teacher_mvp.py:271-358 (`with th.no_grad()`), for all L lights of a
+    frame in ONE launch WITHOUT the reference's L-fold copies of the primitive set:
+        raypos / raydir [B*L,H,W,3], tminmax [B*L,H,W,2]   light-camera rays, lights of a frame consecutive
+        primtransf = (primpos[B,K,3], primrot[B,K,3,3], primscale[B,K,3])   once per frame
+        alpha_template [B,K,TD,TH,TW] or [B,K,TD,TH,TW,1]                   opacity only (the reference pads it with a
+                                                                            constant colour it never reads back)
+    -> shadow[B*L,K,TD,TH,TW,1], normalised like mvpraymarch(with_shadow=True) (accumulated visibility / weight + 1e-5);
+    with return_image also the marched rayrgba[B*L,H,W,4] (colour channels 0)."""
+    primpos, primrot, primscale = (_gpu_contig(t, n) for t, n in zip(primtransf, ("primpos", "primrot", "primscale")))
+    raypos, raydir, tminmax = _gpu_contig(raypos, "raypos"), _gpu_contig(raydir, "raydir"), _gpu_contig(tminmax, "tminmax")
+    tpl = _gpu_contig(alpha_template.reshape(alpha_template.shape[:5]), "alpha_template")
+    B, K = primpos.shape[:2]
+    N, H, W = raypos.shape[:3]
+    L = int(lights_per_frame)
+    if N != B * L:
+        raise ValueError(f"{N} ray images for {B} frames x {L} lights")
+    with torch.no_grad():
+        _, _, nodeaabb = build_accel((primpos, primrot, primscale))
+        TD, TH, TW = tpl.shape[2:5]
+        shadow = torch.zeros(N, K, TD, TH, TW, 2, device=tpl.device)
+        img = torch.empty(N, H, W, 4, device=tpl.device) if return_image else None
+        with torch.cuda.device(tpl.device):
+            _lib.call("gol_mvp_shadow_march", c_int(N), c_int(L), c_int(H), c_int(W), c_int(K), fptr(raypos), fptr(raydir),
+                      c_float(float(stepsize)), fptr(tminmax), fptr(nodeaabb), fptr(primpos), fptr(primrot),
+                      fptr(primscale), fptr(tpl), c_int(1), c_int(TD), c_int(TH), c_int(TW), c_float(float(fadescale)),
+                      c_float(float(fadeexp)), fptr(img), fptr(shadow), stream_ptr())
+        out = shadow[..., 0:1] / (shadow[..., 1:] + 1e-5)
+    return (out, img) if return_image else out
 
 
 # ------------------------------------------------------------------------------------------- raydirs

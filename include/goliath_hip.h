@@ -255,6 +255,19 @@ int gol_mvp_march_bwd(int N, int H, int W, int K, const float* raypos, const flo
                       float* grad_primpos, float* grad_primrot, float* grad_primscale, float* grad_tplate,
                       void* stream);
 
+/* Light-batched shadow march of the teacher model (ca_code/models/hand_teacher_mvp.py:271-358, no_grad): N = B*L ray
+ * images (L = `group` lights per frame, consecutive), but the primitive transforms, the AABB tree and the template exist
+ * once per FRAME: primpos/primrot/primscale [B,K,.], nodeaabb [B,2K-1,2,3], tplate [B,K,TD,TH,TW,4] -- or, with
+ * alpha_only, [B,K,TD,TH,TW] (the reference fills the colour channels with the constant 255 and never looks at the
+ * marched colour).  The reference materialises L copies of all of them (expand().reshape(), :273-349).
+ * shadow [N,K,TD,TH,TW,2] is ACCUMULATED (caller zeroes), exactly like raymarch_forward's `shadow` argument;
+ * rayrgba [N,H,W,4] may be NULL. */
+int gol_mvp_shadow_march(int N, int group, int H, int W, int K, const float* raypos, const float* raydir,
+                         float stepsize, const float* tminmax, const float* nodeaabb, const float* primpos,
+                         const float* primrot, const float* primscale, const float* tplate, int alpha_only,
+                         int TD, int TH, int TW, float fadescale, float fadeexp, float* rayrgba, float* shadow,
+                         void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * URHand per-texel-per-light UV feature loops (BASELINE config 4).  Replace the broadcast PyTorch
  * expressions of ConvTeacherDecoder.forward: ca_code/models/urhand.py:419-445 (Lambert + Phong^p
@@ -366,6 +379,21 @@ int gol_imgtail_fwd(int B, int H, int W, const float* rgb, const float* alpha, c
 int gol_imgtail_bwd(int B, int H, int W, const float* rgb, const float* alpha, const float* bg,
                     const float* bg_scale, const float* cal_M, const float* cal_b, const float* blur_w,
                     const float* g_out, float* g_rgb, float* partials, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Triangle-mesh z-buffer rasterizer: the index / depth / barycentric images the reference obtains from the third-party
+ * drtk (drtk.rasterize + drtk.render, ca_code/utils/render_drtk.py:44-46); consumer on the hot path: the per-light depth
+ * render of the shadow map (ca_code/utils/shadowmap.py:39-50).  Forward only.
+ *   v_pix[B,V,3] = (pixel x, pixel y, camera z) per vertex, vi[F,3] int32 vertex indices (shared by the B meshes)
+ *   index_img[B,H,W] int32: nearest covering face, -1 = none;  depth_img[B,H,W]: its depth, 0 = none;
+ *   bary_img[B,3,H,W] (may be NULL): perspective-correct barycentrics of the sample.
+ * Conventions (drtk's source is not in the reference tree): sample at the pixel centre (j + 0.5, i + 0.5); coverage =
+ * all edge functions >= 0, either winding; faces with a vertex at z <= 0 are skipped; depth ties -> lower face index.
+ * workspace: gol_mesh_raster_workspace_bytes(B, F) bytes of device scratch.
+ * ---------------------------------------------------------------------------------------- */
+int64_t gol_mesh_raster_workspace_bytes(int B, int F);
+int gol_mesh_raster(int B, int V, int F, int H, int W, const float* v_pix, const int32_t* vi, int32_t* index_img,
+                    float* depth_img, float* bary_img, void* workspace, void* stream);
 
 #ifdef __cplusplus
 }

@@ -42,3 +42,30 @@ def head_scene(N, H, W, seed=1234, cam_angle=0.3, focal=None, radii=(90.0, 120.0
 def rel_l2(a, b):
     a, b = a.detach().double().cpu(), b.detach().double().cpu()
     return float((a - b).norm() / b.norm().clamp_min(1e-30))
+
+
+def icosphere(subdiv=2, radius=1.0):
+    """Closed genus-0 triangle mesh (20 * 4^subdiv faces): vertices [V,3] float32, faces [F,3] int64."""
+    t = (1.0 + 5 ** 0.5) / 2.0
+    v = [(-1, t, 0), (1, t, 0), (-1, -t, 0), (1, -t, 0), (0, -1, t), (0, 1, t), (0, -1, -t), (0, 1, -t), (t, 0, -1),
+         (t, 0, 1), (-t, 0, -1), (-t, 0, 1)]
+    f = [(0, 11, 5), (0, 5, 1), (0, 1, 7), (0, 7, 10), (0, 10, 11), (1, 5, 9), (5, 11, 4), (11, 10, 2), (10, 7, 6),
+         (7, 1, 8), (3, 9, 4), (3, 4, 2), (3, 2, 6), (3, 6, 8), (3, 8, 9), (4, 9, 5), (2, 4, 11), (6, 2, 10), (8, 6, 7),
+         (9, 8, 1)]
+    v = [torch.tensor(p, dtype=torch.float64) / torch.tensor(p, dtype=torch.float64).norm() for p in v]
+    for _ in range(subdiv):
+        cache, nf = {}, []
+
+        def mid(a, b):
+            key = (min(a, b), max(a, b))
+            if key not in cache:
+                m = v[a] + v[b]
+                v.append(m / m.norm())
+                cache[key] = len(v) - 1
+            return cache[key]
+
+        for a, b, c in f:
+            ab, bc, ca = mid(a, b), mid(b, c), mid(c, a)
+            nf += [(a, ab, ca), (b, bc, ab), (c, ca, bc), (ab, bc, ca)]
+        f = nf
+    return (torch.stack(v) * radius).float(), torch.tensor(f, dtype=torch.int64)

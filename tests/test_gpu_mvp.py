@@ -128,3 +128,36 @@ def test_raymarcher_wrapper_and_errors():
     with pytest.raises(RuntimeError):  # CPU tensors
         mvp.mvpraymarch(rp.cpu(), rd.cpu(), 0.05, tm.cpu(), (case["primpos"], case["primrot"], case["primscale"]),
                         case["template"], None)
+
+
+def test_light_batched_shadow_march_equals_per_light_copies():
+    """hand_teacher_mvp.py:271-358: L lights per frame.  The reference expands primitives and template L times and pads
+    the opacity template with a constant colour; shadow_march shares them (alpha-only template).  Same shadow grid."""
+    from goliath_amd import mvp
+
+    B, L, H, W, K, T = 2, 3, 40, 36, 27, (4, 6, 5)
+    case = _random_case(B, H, W, K, T, seed=9)
+    c = lambda t: t.cuda().contiguous()
+    g = torch.Generator().manual_seed(3)
+    # light cameras: per (frame, light) a viewpoint looking at the volume
+    viewpos = (torch.tensor([0.1, -0.2, -3.0]) + 0.6 * torch.randn(B * L, 3, generator=g)).contiguous()
+    viewrot = torch.eye(3)[None].repeat(B * L, 1, 1).contiguous()
+    focal, princpt = torch.full((B * L, 2), 1.6 * W), torch.tensor([[W * 0.5, H * 0.5]] * (B * L))
+    rp, rd, tm = mvp.compute_raydirs(c(viewpos), c(viewrot), c(focal), c(princpt), (W, H), 1.0)
+    alpha = case["template"][..., 3:4].contiguous()                                   # [B,K,TD,TH,TW,1]
+    prims = (c(case["primpos"]), c(case["primrot"]), c(case["primscale"]))
+    shadow, img = mvp.shadow_march(rp, rd, case["step"], tm, prims, c(alpha), L, fadescale=6.5, fadeexp=8.0,
+                                   return_image=True)
+    # the reference's formulation: everything repeated per light, rgb = 255, through the ordinary march
+    rep = lambda t: c(t[:, None].expand(-1, L, *t.shape[1:]).reshape(B * L, *t.shape[1:]))
+    tpl = torch.cat([torch.full_like(alpha.expand(-1, -1, -1, -1, -1, 3), 255.0), alpha], -1)
+    with torch.no_grad():
+        ref_img, ref_shadow = mvp.mvpraymarch(rp, rd, case["step"], tm, (rep(case["primpos"]), rep(case["primrot"]),
+                                                                         rep(case["primscale"])), rep(tpl), None,
+                                              fadescale=6.5, fadeexp=8.0, with_shadow=True)
+    assert shadow.shape == ref_shadow.shape == (B * L, K, *T, 1)
+    assert float(ref_shadow.max()) > 0.1
+    assert rel_l2(shadow, ref_shadow) < 1e-5, rel_l2(shadow, ref_shadow)
+    assert rel_l2(img[..., 3], ref_img[..., 3]) < 1e-6
+    with pytest.raises(ValueError):
+        mvp.shadow_march(rp, rd, case["step"], tm, prims, c(alpha), L + 1)
