@@ -53,8 +53,9 @@ def _run(G, tag, device, tail_fn):
         M, b = imgtail.cal_v5_matrix(cal, idx)
     if use_bg:
         alpha, bg, lit = G[f"{tag}/alpha"].to(device), G[f"{tag}/background"].to(device), G[f"{tag}/lit"].to(device).float()
-    if use_blur:
-        bw = torch.softmax(blur_raw[idx], dim=-1)
+    if use_blur:  # LearnableBlur keeps the camera order it was given (dof_cal.py:29-34); ParamHolder sorts (CalV5)
+        order = [str(c) for c in G["cameras"]]
+        bw = torch.softmax(blur_raw[torch.tensor([order.index(n) for n in cams], device=device)], dim=-1)
     out = tail_fn(rgb, alpha, bg, lit, M, b, bw)
     (out * G[f"{tag}/w"].to(device)).sum().backward()
     return out, rgb.grad, cal.params.grad, blur_raw.grad
