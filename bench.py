@@ -287,9 +287,10 @@ URHAND_CFG = dict(workload="urhand_config4_uvlight", uv=1024, lights=32, frames_
 
 def urhand_main(args):
     """Secondary workload (BASELINE config 4): URHand UV light loops, S=1024, L=32 point lights on a
-    1100 mm sphere, B=1: shadow-map PCF (shadowmap.py:30-96, depth renders given) + Phong features (urhand.py:419-445) + GGX shading
+    1100 mm sphere, B=1: per-light mesh depth render (the drtk call of shadowmap.py:39-50; synthetic closed mesh of 5120
+    faces, no dataset) + shadow-map PCF (shadowmap.py:30-96) + Phong features (urhand.py:419-445) + GGX shading
     (:508-567), fwd+bwd."""
-    from goliath_amd import shadowmap, uvlight
+    from goliath_amd import meshraster, shadowmap, uvlight
 
     cfg = URHAND_CFG
     dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
@@ -301,7 +302,6 @@ def urhand_main(args):
              cam=torch.tensor([[0.0, 0.0, -700.0]] * B),
              lpos=1100.0 * F.normalize(torch.randn(B, L, 3, generator=g), dim=-1),
              lint=torch.rand(B, L, 1, generator=g),
-             depth=650.0 + 150.0 * torch.rand(B * L, 1024, 1024, generator=g),  # light-camera depth renders (input)
              rough=0.3 + 0.5 * torch.rand(B, 1, S, S, generator=g), tex=torch.rand(B, 3, S, S, generator=g),
              u1=torch.randn(B, 1, S, S, generator=g), u2=torch.randn(B, 3, 1, S, S, generator=g),
              u3=torch.randn(B, 4, S, S, generator=g), u4=torch.randn(B, 3, S, S, generator=g))
@@ -309,14 +309,31 @@ def urhand_main(args):
     z = F.normalize(-t["lpos"].reshape(-1, 3), dim=-1)
     x = F.normalize(torch.linalg.cross(torch.tensor([0.0, 1.0, 0.0]).expand_as(z), z), dim=-1)
     t["lrt"] = torch.cat([torch.stack([x, torch.linalg.cross(z, x), z], 1), t["lpos"].reshape(-1, 3, 1)], 2)
+    # synthetic hand stand-in: a bumpy closed genus-0 mesh (icosphere, 2562 vertices / 5120 faces) of ~90 mm radius
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from scenes import icosphere
+
+    verts, faces = icosphere(4, radius=90.0)
+    verts = verts * (1.0 + 0.08 * torch.sin(0.05 * verts[:, :1] + 0.07 * verts[:, 1:2]))
+    t["verts"] = verts[None].repeat(B, 1, 1)
     t = {k: v.to(dev).contiguous() for k, v in t.items()}
+    faces = faces.to(dev)
+    Kl = torch.eye(3, device=dev)[None].repeat(B * L, 1, 1)            # shadowmap.py:21-26: focal 1000, 1024^2 light cameras
+    Kl[:, 0, 0] = Kl[:, 1, 1] = 1000.0
+    Kl[:, 0, 2] = Kl[:, 1, 2] = 512.0
+    # ordinary [R | -R c] extrinsics of a camera AT the light, for the mesh render and the texel projection alike (the
+    # reference hands [R | light_pos] to both, urhand.py:415; same arithmetic, but here the mesh is in view)
+    cam_rt = torch.cat([t["lrt"][:, :, :3], -(t["lrt"][:, :, :3] @ t["lpos"].reshape(-1, 3, 1))], 2)
     for k in ("p_uv", "nml", "rough", "tex"):
         t[k].requires_grad_(True)
 
     def step():
         for k in ("p_uv", "nml", "rough", "tex"):
             t[k].grad = None
-        shadow = shadowmap.shadow_pcf(t["depth"], t["lrt"], t["p_uv"], t["nml"], exp_scale=8.0).view(B, L, 1, S, S)
+        with torch.no_grad():  # urhand.py:404: the shadow map is evaluated without gradients
+            v_pix = meshraster.transform(t["verts"].repeat_interleave(L, 0), Kl, cam_rt)
+            depth = meshraster.rasterize(v_pix, faces, 1024, 1024, with_bary=False)[1]
+        shadow = shadowmap.shadow_pcf(depth, cam_rt, t["p_uv"], t["nml"], exp_scale=8.0).view(B, L, 1, S, S)
         diff, spec = uvlight.phong_features(t["p_uv"], t["nml"], t["cam"], t["lpos"], t["lint"], shadow)
         feat, rgb = uvlight.ggx_features(t["p_uv"], t["nml"], t["cam"], t["lpos"], t["lint"], t["rough"], t["tex"],
                                          shadow)
@@ -326,12 +343,14 @@ def urhand_main(args):
     _, dt, ms = _time_steps(step, args)
     T = B * S * S
     sh = 4 * L * T  # the shadow map is the dominant stream: one float per texel per light
-    alg = {"gol_shadow_pcf": 24 * T + sh + 9 * 4 * L * T,  # texels + shadow out + 9 nearest depth taps per light
+    alg = {"gol_mesh_raster": B * L * (8 * 1024 * 1024 + 64 * 5120),  # index + depth images out, face records
+           "gol_shadow_pcf": 24 * T + sh + 9 * 4 * L * T,  # texels + shadow out + 9 nearest depth taps per light
            "gol_uvlight_phong_fwd": sh + 24 * T + 16 * T, "gol_uvlight_phong_bwd": sh + 24 * T + 16 * T + 24 * T,
            "gol_uvlight_ggx_fwd": sh + 40 * T + 28 * T, "gol_uvlight_ggx_bwd": sh + 40 * T + 28 * T + 40 * T}
     _secondary_line("URHand UV light-loop frames/sec (Phong + GGX, fwd+bwd), 1024x1024 texels x 32 lights",
                     "frames/s", B, args, dt, ms, alg,
-                    {"workload": cfg["workload"], "uv": [S, S], "lights": L, "frames_per_gpu": B})
+                    {"workload": cfg["workload"], "uv": [S, S], "lights": L, "frames_per_gpu": B,
+                     "shadow_depth_render": "32 x 1024^2 mesh z-buffer renders of a 5120-face closed mesh per frame"})
 
 
 SG_CFG = dict(workload="sgutils_native", gaussians=1_048_576, views=8, lights=8, seed=7)
