@@ -9,9 +9,11 @@
 // not copied: pixel (i, j) is sampled at its centre (j + 0.5, i + 0.5) in v_pix units; a face covers a sample when all
 // three edge functions are >= 0 (either winding); among the covering faces the smallest positive depth wins, ties go to
 // the lower face index; depth and barycentrics are perspective-correct (linear in 1 / z).
-// Two kernels: per-face setup (edge equations + tile bounds, 64 B per face), then one 256-thread workgroup per 16x16
-// tile: faces whose bounds touch the tile are compacted into LDS 256 at a time (wave ballots), every lane then walks
-// that short list for its own pixel with wave-uniform (scalar) loads of the face records -- no atomics.
+// Two kernels: per-face setup (edge equations + tile bounds, 64 B per face, plus the tile bounding box of the whole
+// mesh per view), then one 256-thread workgroup per 16x16 tile: tiles outside the mesh's box only clear their pixels
+// (a hand seen from a light 1.1 m away covers a few percent of the 1024^2 light camera); the others compact the faces
+// whose bounds touch the tile into LDS 256 at a time and every lane walks that short list for its own pixel with
+// wave-uniform (scalar) loads of the face records.  No global atomics besides the four per workgroup of the box.
 #include "gol_common.h"
 
 namespace {
@@ -22,14 +24,21 @@ struct FaceRec {
   int32_t tx0, tx1, ty0, ty1;  // inclusive tile bounds, tx1 < tx0 = culled
 };
 
+// per-view tile box of the mesh: {min tx, min ty, -max tx, -max ty} (all reduced with atomicMin; initialised to INT_MAX)
+__global__ void box_init_kernel(int n, int32_t* __restrict__ box) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) box[i] = 2147483647;
+}
+
 __global__ __launch_bounds__(256) void face_setup_kernel(int V, int F, int H, int W, const float* __restrict__ v_pix,
-                                                         const int32_t* __restrict__ vi, FaceRec* __restrict__ rec) {
+                                                         const int32_t* __restrict__ vi, FaceRec* __restrict__ rec,
+                                                         int32_t* __restrict__ box) {
   const int f = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
-  if (f >= F) return;
   FaceRec r;
   r.tx0 = 1; r.tx1 = 0; r.ty0 = 1; r.ty1 = 0;
-  const int i0 = vi[3 * f], i1 = vi[3 * f + 1], i2 = vi[3 * f + 2];
-  const bool ok_idx = i0 >= 0 && i0 < V && i1 >= 0 && i1 < V && i2 >= 0 && i2 < V;
+  int i0 = -1, i1 = -1, i2 = -1;
+  if (f < F) { i0 = vi[3 * f]; i1 = vi[3 * f + 1]; i2 = vi[3 * f + 2]; }
+  const bool ok_idx = f < F && i0 >= 0 && i0 < V && i1 >= 0 && i1 < V && i2 >= 0 && i2 < V;
   if (ok_idx) {
     const float* p = v_pix + (size_t)b * V * 3;
     const float ax = p[3 * i0], ay = p[3 * i0 + 1], az = p[3 * i0 + 2];
@@ -54,10 +63,20 @@ __global__ __launch_bounds__(256) void face_setup_kernel(int V, int F, int H, in
       }
     }
   }
-  rec[(size_t)b * F + f] = r;
+  if (f < F) rec[(size_t)b * F + f] = r;
+  // workgroup box -> one atomicMin per component
+  __shared__ int32_t s_box[4];
+  if (threadIdx.x < 4) s_box[threadIdx.x] = 2147483647;
+  __syncthreads();
+  if (r.tx0 <= r.tx1) {
+    atomicMin(&s_box[0], r.tx0); atomicMin(&s_box[1], r.ty0); atomicMin(&s_box[2], -r.tx1); atomicMin(&s_box[3], -r.ty1);
+  }
+  __syncthreads();
+  if (threadIdx.x < 4 && s_box[threadIdx.x] != 2147483647) atomicMin(&box[4 * b + threadIdx.x], s_box[threadIdx.x]);
 }
 
 __global__ __launch_bounds__(256) void mesh_raster_kernel(int F, int H, int W, const FaceRec* __restrict__ rec,
+                                                          const int32_t* __restrict__ box,
                                                           int32_t* __restrict__ index_img, float* __restrict__ depth_img,
                                                           float* __restrict__ bary_img) {
   __shared__ int32_t s_face[256];
@@ -69,7 +88,8 @@ __global__ __launch_bounds__(256) void mesh_raster_kernel(int F, int H, int W, c
   float best_iz = 0.f;   // 1 / depth of the nearest covering face (larger = nearer)
   int best = -1;
   float bb0 = 0.f, bb1 = 0.f, bb2 = 0.f;
-  for (int base = 0; base < F; base += 256) {
+  const bool in_box = F > 0 && box[4 * b] <= tx && tx <= -box[4 * b + 2] && box[4 * b + 1] <= ty && ty <= -box[4 * b + 3];
+  for (int base = 0; in_box && base < F; base += 256) {
     if (tid == 0) s_count = 0;
     __syncthreads();
     const int f = base + tid;
@@ -78,18 +98,9 @@ __global__ __launch_bounds__(256) void mesh_raster_kernel(int F, int H, int W, c
       const FaceRec& r = R[f];
       hit = r.tx0 <= tx && tx <= r.tx1 && r.ty0 <= ty && ty <= r.ty1;
     }
-    // order-preserving compaction (faces stay in index order, so depth ties resolve to the lower index): the four
-    // waves append their ballots one after the other
-    const unsigned long long m = __ballot(hit);
-    const int wave = tid >> 6, lane = tid & 63;
-    for (int w = 0; w < 4; ++w) {
-      if (wave == w) {
-        const int start = s_count;
-        if (hit) s_face[start + __builtin_popcountll(m & ((1ull << lane) - 1ull))] = f;
-        if (lane == 0) s_count = start + __builtin_popcountll(m);
-      }
-      __syncthreads();
-    }
+    // compaction (any order: the z-test below breaks depth ties by face index)
+    if (hit) s_face[atomicAdd(&s_count, 1)] = f;
+    __syncthreads();
     const int n = s_count;
     for (int k = 0; k < n; ++k) {
       const int fi = __builtin_amdgcn_readfirstlane(s_face[k]);
@@ -100,7 +111,7 @@ __global__ __launch_bounds__(256) void mesh_raster_kernel(int F, int H, int W, c
       if (b0 >= 0.f && b1 >= 0.f && b2 >= 0.f) {
         const float w0 = b0 * r.iz[0], w1 = b1 * r.iz[1], w2 = b2 * r.iz[2];
         const float iz = w0 + w1 + w2;  // 1 / depth at the sample
-        if (iz > best_iz) {             // strictly nearer: ties keep the lower face index (faces come in order)
+        if (iz > best_iz || (iz == best_iz && fi < best)) {  // nearer; exact ties go to the lower face index
           best_iz = iz; best = fi;
           const float z = 1.f / iz;
           bb0 = w0 * z; bb1 = w1 * z; bb2 = w2 * z;
@@ -122,7 +133,9 @@ __global__ __launch_bounds__(256) void mesh_raster_kernel(int F, int H, int W, c
 
 }  // namespace
 
-extern "C" int64_t gol_mesh_raster_workspace_bytes(int B, int F) { return (int64_t)B * F * (int64_t)sizeof(FaceRec); }
+extern "C" int64_t gol_mesh_raster_workspace_bytes(int B, int F) {
+  return (int64_t)B * F * (int64_t)sizeof(FaceRec) + (int64_t)B * 4 * (int64_t)sizeof(int32_t);
+}
 
 extern "C" int gol_mesh_raster(int B, int V, int F, int H, int W, const float* v_pix, const int32_t* vi,
                                int32_t* index_img, float* depth_img, float* bary_img, void* workspace, void* stream) {
@@ -130,11 +143,14 @@ extern "C" int gol_mesh_raster(int B, int V, int F, int H, int W, const float* v
   GOL_REQUIRE(B <= 65535 && H <= 16 * 65535 && W <= 16 * 65535, "size out of range");
   if (B == 0) return GOL_OK;
   GOL_REQUIRE(index_img && depth_img, "null output");
-  GOL_REQUIRE(F == 0 || (v_pix && vi && workspace), "null input / workspace");
+  GOL_REQUIRE(workspace != nullptr, "null workspace");
+  GOL_REQUIRE(F == 0 || (v_pix && vi), "null input");
   hipStream_t s = (hipStream_t)stream;
   FaceRec* rec = reinterpret_cast<FaceRec*>(workspace);
-  if (F > 0) face_setup_kernel<<<dim3(gol_cdiv(F, 256), B), 256, 0, s>>>(V, F, H, W, v_pix, vi, rec);
-  mesh_raster_kernel<<<dim3(gol_cdiv(W, 16), gol_cdiv(H, 16), B), 256, 0, s>>>(F, H, W, rec, index_img, depth_img, bary_img);
+  int32_t* box = reinterpret_cast<int32_t*>(rec + (size_t)B * F);  // [B,4] behind the face records
+  box_init_kernel<<<gol_cdiv(4 * B, 256), 256, 0, s>>>(4 * B, box);
+  if (F > 0) face_setup_kernel<<<dim3(gol_cdiv(F, 256), B), 256, 0, s>>>(V, F, H, W, v_pix, vi, rec, box);
+  mesh_raster_kernel<<<dim3(gol_cdiv(W, 16), gol_cdiv(H, 16), B), 256, 0, s>>>(F, H, W, rec, box, index_img, depth_img, bary_img);
   GOL_CHECK_LAUNCH();
   return GOL_OK;
 }
