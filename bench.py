@@ -297,7 +297,13 @@ def urhand_main(args):
     torch.cuda.set_device(dev)
     g = torch.Generator().manual_seed(cfg["seed"])
     B, S, L = cfg["frames_per_gpu"], cfg["uv"], cfg["lights"]
-    d = F.normalize(torch.randn(B, 3, S, S, generator=g), dim=1)
+    # texel positions: a UV ATLAS of the closed surface (latitude / longitude chart of the sphere, like a hand's uv map:
+    # neighbouring texels are neighbouring surface points), slightly jittered
+    th_ = math.pi * (torch.arange(S) + 0.5) / S
+    ph_ = 2 * math.pi * (torch.arange(S) + 0.5) / S
+    d = torch.stack([torch.sin(th_)[:, None] * torch.cos(ph_)[None], torch.cos(th_)[:, None].expand(S, S),
+                     torch.sin(th_)[:, None] * torch.sin(ph_)[None]])[None].repeat(B, 1, 1, 1)
+    d = F.normalize(d + 0.002 * torch.randn(B, 3, S, S, generator=g), dim=1)
     t = dict(p_uv=d * 90.0, nml=F.normalize(d + 0.2 * torch.randn(B, 3, S, S, generator=g), dim=1),
              cam=torch.tensor([[0.0, 0.0, -700.0]] * B),
              lpos=1100.0 * F.normalize(torch.randn(B, L, 3, generator=g), dim=-1),
