@@ -116,6 +116,10 @@ def step(t, cfg, world):
     return loss
 
 
+def _split(n, parts):
+    return [n // parts + (1 if i < n % parts else 0) for i in range(parts)] if n > 0 else []
+
+
 def run_step(t, cfg, world, graph=None):
     """One timed step: the compute part (eager, or one replay of its captured HIP graph) + the gradient exchange."""
     if graph is None:
@@ -470,7 +474,10 @@ def e2e_main(args):
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
 
     def step():
-        opt.zero_grad(set_to_none=True)
+        if world > 1:
+            sync.zero_grad()   # gradients are views of the persistent communication buckets (parallel.GradSync)
+        else:
+            opt.zero_grad(set_to_none=True)
         ev[0].record()
         if args.fused_tail:
             from goliath_amd import tail
@@ -540,7 +547,8 @@ def e2e_main(args):
                "config": {"workload": cfg["workload"], "gaussians": N, "image": [H, W], "views_per_gpu": B,
                           "fused_tail": bool(args.fused_tail), "loss": "10*l1" if args.no_ssim else "10*l1 + 0.2*(1-ssim)",
                           "trainable_params": sum(p.numel() for p in params),
-                          "parallelism": f"view-parallel x{world}"},
+                          "parallelism": f"view-parallel x{world}", "rccl_world_size": world,
+                          "grad_sync": "bucketed reduce-scatter + all-gather, launched from backward hooks"},
                "kernels_ms_per_call": ms, "hot_path_ms_per_step": sum(sum(v) for v in per.values()) / args.steps,
                # sanity signal of the whole gradient chain: the training loss on the fixed batch, first vs last step
                "loss_first_step": float(loss_first) if loss_first is not None else None,
@@ -567,6 +575,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--views", type=int, default=CFG["views_per_gpu"])
     ap.add_argument("--micro", type=int, default=2, help="micro-batches (HIP streams) per step")
+    ap.add_argument("--grad-floats", type=int, default=-1,
+                    help="size of the gradient set exchanged per step besides the albedo map (default: 60 M fp32 = the "
+                         "config-3 decoder parameter set when N > 1, 0 when N = 1)")
     ap.add_argument("--no-graph", action="store_true",
                     help="time eager launches instead of replays of the step captured as one HIP graph.  The ~120 launches "
                          "of a step cost the host almost as long as the GPU needs to run them, so the eager number moves "
@@ -604,7 +615,15 @@ def main():
     t = make_step_inputs(cfg, dev, rank, args.micro)
     from goliath_amd import parallel
 
-    t["_sync"] = parallel.GradSync([t["albedo"]])
+    # Gradient exchange of the step.  Mode A has a single trainable tensor on the path (the albedo map, 3 MB); BASELINE
+    # config 3 specifies the exchange of the 512^2-slab RGCA decoder parameter set (~60 M fp32) every step, so
+    # for N > 1 a gradient set of that size travels with it (its values are irrelevant to the timing; in training it is
+    # produced by the decoder backward, which is not part of mode A) -- a SCALE line must pay the real message size.
+    grad_floats = args.grad_floats if args.grad_floats >= 0 else (60_000_000 if world > 1 else 0)
+    dec = [torch.nn.Parameter(torch.zeros(n, device=dev)) for n in _split(grad_floats, 4)]
+    for p in dec:
+        p.grad = torch.zeros_like(p)
+    t["_sync"] = parallel.GradSync([t["albedo"]] + dec)
     B, N = cfg["views_per_gpu"], cfg["gaussians"]
     P = cfg["height"] * cfg["width"]
 
@@ -713,7 +732,9 @@ def main():
                        "views_per_gpu": B, "micro_batches": args.micro,
                        "launch": "eager" if graph is None else "hip_graph_replay (kernels_ms_per_call / roofline: eager "
                                                                 "instrumented pass after the timed replays)", "relight": "envmap_4mips", "intersections_per_view": I,
-                       "mean_alpha": mean_alpha, "parallelism": f"view-parallel x{world}"},
+                       "mean_alpha": mean_alpha, "parallelism": f"view-parallel x{world}",
+                       "rccl_world_size": world,
+                       "grad_exchange_bytes_per_step": 4 * (grad_floats + t["albedo"].numel()) if world > 1 else 0},
             "kernels_ms_per_call": kernels_ms,
             "roofline": roofline,
             "hbm_per_call": per_call,

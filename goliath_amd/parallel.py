@@ -7,7 +7,7 @@ of the hot path, so the multi-GPU scheme is:
   * shard: view b of the global batch goes to rank b % world (`shard_views`);
   * no collective on the data path (shade / project / bin / raster never talk to another GPU);
   * one gradient exchange per step for the trainable parameters, as bucketed reduce-scatter +
-    all-gather (`GradSync`) -- on MI355X the 8 GPUs are fully connected by point-to-point xGMI links
+    all-gather overlapped with backward (`GradSync`) -- on MI355X the 8 GPUs are fully connected by point-to-point xGMI links
     (7 x ~153 GB/s), so a direct reduce-scatter/all-gather uses all 7 links while a single-ring
     all-reduce is bound by one link (740 MB of RGCA gradients = 8.5 ms on a ring
     vs 1.2 ms direct);
@@ -60,18 +60,32 @@ def sync_mean(x: torch.Tensor) -> torch.Tensor:
 
 
 class GradSync:
-    """Bucketed gradient averaging: reduce-scatter + all-gather per bucket.
+    """Bucketed gradient averaging, overlapped with backward: reduce-scatter + all-gather per bucket.
 
-    params: the trainable parameters (same order on every rank).  bucket_bytes: target bucket size;
-    large buckets (default 256 MiB) suit 288 GB HBM and amortise the per-collective latency.
+    params: the trainable parameters (same order on every rank).  bucket_bytes: target bucket size (default 256 MiB:
+    large buckets suit 288 GB of HBM and amortise the per-collective latency; xGMI is point-to-point, so the direct
+    reduce-scatter / all-gather pair keeps all 7 links busy where a ring all-reduce is bound by one).
+
+    Every bucket owns ONE persistent flat buffer; the `.grad` of its parameters are views into it, so autograd
+    accumulates straight into the communication buffer -- no flatten / copy-back passes over the gradients.  Buckets are
+    filled in reverse parameter order (the order backward produces gradients); a post-accumulate hook per parameter
+    counts arrivals and launches the bucket's collectives asynchronously as soon as its last gradient is in, while
+    backward keeps computing the earlier layers.  `finish()` (or `sync()`) after `backward()` launches what is left
+    (buckets holding parameters that received no gradient contribute zeros for them) and waits.
+
+    Use `sync.zero_grad()` instead of `optimizer.zero_grad()`: it zeroes the flat buffers and keeps the views.  If a
+    `.grad` is replaced behind its back (zero_grad(set_to_none=True), a fresh tensor from autograd), the hook copies it
+    into the bucket and re-points `.grad` -- correct, one extra copy for that parameter.
     """
 
-    def __init__(self, params: Iterable[torch.nn.Parameter], bucket_bytes: int = 256 << 20, average: bool = True):
+    def __init__(self, params: Iterable[torch.nn.Parameter], bucket_bytes: int = 256 << 20, average: bool = True,
+                 overlap: bool = True):
         self.params = [p for p in params if p.requires_grad]
         self.average = average
+        self.overlap = overlap
         self.buckets: List[List[torch.nn.Parameter]] = []
         cur, size = [], 0
-        for p in self.params:
+        for p in reversed(self.params):  # gradients arrive last-layer first
             nbytes = p.numel() * p.element_size()
             if cur and size + nbytes > bucket_bytes:
                 self.buckets.append(cur)
@@ -80,36 +94,114 @@ class GradSync:
             size += nbytes
         if cur:
             self.buckets.append(cur)
+        self._flat: List[torch.Tensor] = []     # per bucket: padded flat gradient buffer
+        self._shard: List[torch.Tensor] = []    # per bucket: this rank's 1/world slice (reduce-scatter output)
+        self._view = {}                          # id(param) -> (bucket index, view into the flat buffer)
+        self._arrived: List[int] = []
+        self._work: List[list] = []
+        self._launched: List[bool] = []
+        self._hooks = []
+        self._built_for = None
 
-    @staticmethod
-    def _flatten(ps: Sequence[torch.nn.Parameter], pad_to: int) -> torch.Tensor:
-        flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in ps])
-        rem = (-flat.numel()) % pad_to
-        if rem:
-            flat = torch.cat([flat, flat.new_zeros(rem)])
-        return flat
+    # ---------------------------------------------------------------------------------------------------------
+    def _build(self, w: int):
+        """Allocate the flat buffers (first use, or the world size changed) and point the .grad views into them."""
+        self._flat, self._shard, self._view = [], [], {}
+        for bi, ps in enumerate(self.buckets):
+            n = sum(p.numel() for p in ps)
+            n_pad = n + (-n) % w
+            flat = torch.zeros(n_pad, dtype=ps[0].dtype, device=ps[0].device)
+            self._flat.append(flat)
+            self._shard.append(torch.empty(n_pad // w, dtype=flat.dtype, device=flat.device))
+            off = 0
+            for p in ps:
+                v = flat[off:off + p.numel()].view_as(p)
+                if p.grad is not None:
+                    v.copy_(p.grad)
+                p.grad = v
+                self._view[id(p)] = (bi, v)
+                off += p.numel()
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []
+        if self.overlap and w > 1:
+            for p in self.params:
+                self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
+        self._built_for = w
+        self._reset()
 
-    def sync(self):
-        """Average (or sum) .grad over all ranks, in place.  Call after backward, before clipping."""
+    def _reset(self):
+        self._arrived = [0] * len(self.buckets)
+        self._launched = [False] * len(self.buckets)
+        self._work = [[] for _ in self.buckets]
+
+    def _adopt(self, p):
+        """Make sure p.grad IS the bucket view (copy a foreign gradient tensor in once)."""
+        bi, v = self._view[id(p)]
+        if p.grad is None:
+            v.zero_()
+        elif p.grad.data_ptr() != v.data_ptr():
+            v.copy_(p.grad)
+        p.grad = v
+        return bi
+
+    def _on_grad(self, p):
+        bi = self._adopt(p)
+        self._arrived[bi] += 1
+        if self._arrived[bi] == len(self.buckets[bi]) and not self._launched[bi]:
+            self._launch(bi)
+
+    def _launch(self, bi: int):
+        w = self._built_for
+        flat, shard = self._flat[bi], self._shard[bi]
+        avg_op = self.average and dist.get_backend() == "nccl"   # RCCL reduces with AVG natively; gloo cannot
+        if self.average and not avg_op:
+            flat.div_(w)
+        h1 = dist.reduce_scatter_tensor(shard, flat, op=dist.ReduceOp.AVG if avg_op else dist.ReduceOp.SUM,
+                                        async_op=True)   # every rank reduces 1/w of the bucket
+        if dist.get_backend() != "nccl":
+            h1.wait()   # RCCL orders the two collectives on its stream; gloo's worker threads do not
+        h2 = dist.all_gather_into_tensor(flat, shard, async_op=True)   # ... and shares it
+        self._work[bi] = [h1, h2]
+        self._launched[bi] = True
+
+    # ---------------------------------------------------------------------------------------------------------
+    def zero_grad(self):
+        """Zero the gradients in place (keeps the bucket views; replaces optimizer.zero_grad())."""
+        _, w = world()
+        if self._built_for != w:
+            self._build(w)
+        for flat in self._flat:
+            flat.zero_()
+        self._reset()
+
+    def finish(self):
+        """After backward: launch the buckets that are not in flight yet, wait for all of them."""
         _, w = world()
         if w == 1:
             return
-        for ps in self.buckets:
-            flat = self._flatten(ps, w)
-            shard = flat.new_empty(flat.numel() // w)
-            dist.reduce_scatter_tensor(shard, flat)          # every rank reduces 1/w of the bucket
-            if self.average:
-                shard /= w
-            dist.all_gather_into_tensor(flat, shard)         # ... and shares it with the others
-            off = 0
-            for p in ps:
-                n = p.numel()
-                g = flat[off:off + n].view_as(p)
-                if p.grad is None:
-                    p.grad = g.clone()
-                else:
-                    p.grad.copy_(g)
-                off += n
+        if self._built_for != w:
+            self._build(w)     # first use without zero_grad(): adopt the existing .grad tensors
+        for bi, ps in enumerate(self.buckets):
+            if not self._launched[bi]:
+                for p in ps:
+                    self._adopt(p)   # (a parameter that received no gradient contributes zeros)
+                self._launch(bi)
+        for hs in self._work:
+            for h in hs:
+                h.wait()
+        self._reset()
+
+    def sync(self):
+        """Average (or sum) .grad over all ranks, in place.  Call after backward, before clipping."""
+        self.finish()
+
+    def close(self):
+        """Remove the gradient hooks (the .grad tensors stay views of the buckets until they are replaced)."""
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []
+        self._built_for = None
 
 
 def global_grad_norm(params: Iterable[torch.nn.Parameter]) -> torch.Tensor:

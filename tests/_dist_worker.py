@@ -20,18 +20,53 @@ def main():
              "cfg": "shared"}
     mine = parallel.shard_batch(batch)
     assert mine["ids"] == list(range(rank, B, world)) and mine["cfg"] == "shared"
-    # per-view loss summed over this rank's views, scaled so that the rank-average equals the full-batch mean
-    loss = ((model(mine["x"]) - mine["y"]) ** 2).sum() * world / B
-    loss.backward()
-    sync = parallel.GradSync(model.parameters(), bucket_bytes=256)  # tiny buckets -> several collectives
-    assert len(sync.buckets) > 1
-    sync.sync()
     # reference: the whole batch on one process
     torch.manual_seed(0)
     ref = torch.nn.Sequential(torch.nn.Linear(7, 13), torch.nn.Tanh(), torch.nn.Linear(13, 3))
     ((ref(batch["x"]) - batch["y"]) ** 2).sum().div(B).backward()
-    for p, q in zip(model.parameters(), ref.parameters()):
-        assert torch.allclose(p.grad, q.grad, atol=1e-6), (p.grad - q.grad).abs().max()
+
+    def check(tag):
+        for p, q in zip(model.parameters(), ref.parameters()):
+            assert torch.allclose(p.grad, q.grad, atol=1e-6), (tag, (p.grad - q.grad).abs().max())
+
+    # (1) plain use: backward first, then sync() adopts the existing .grad tensors.  Tiny buckets -> several collectives
+    # per-view loss summed over this rank's views, scaled so that the rank-average equals the full-batch mean
+    loss = ((model(mine["x"]) - mine["y"]) ** 2).sum() * world / B
+    loss.backward()
+    sync = parallel.GradSync(model.parameters(), bucket_bytes=256)
+    assert len(sync.buckets) > 1
+    sync.sync()
+    check("adopt")
+    # (2) steady state: gradients are views of the persistent flat buckets, the hooks launch each bucket's collectives
+    # DURING backward (overlap), finish() only waits
+    for step in range(2):
+        sync.zero_grad()
+        ptrs = [p.grad.data_ptr() for p in model.parameters()]
+        loss = ((model(mine["x"]) - mine["y"]) ** 2).sum() * world / B
+        loss.backward()
+        assert all(sync._launched), "every bucket was launched by its hooks before finish()"
+        sync.finish()
+        assert ptrs == [p.grad.data_ptr() for p in model.parameters()], "grads stayed views of the flat buffers"
+        check(f"overlap{step}")
+    # (3) a parameter that gets no gradient (p.grad is None) + grads replaced behind our back (set_to_none)
+    sync.close()
+    extra = torch.nn.Parameter(torch.ones(5))
+    sync2 = parallel.GradSync(list(model.parameters()) + [extra], bucket_bytes=1 << 20)
+    for p in model.parameters():
+        p.grad = None
+    extra.grad = None
+    loss = ((model(mine["x"]) - mine["y"]) ** 2).sum() * world / B
+    loss.backward()
+    sync2.sync()
+    check("unused")
+    assert extra.grad is not None and float(extra.grad.abs().max()) == 0.0
+    sync2.zero_grad()
+    for p in model.parameters():
+        p.grad = None                      # what optimizer.zero_grad(set_to_none=True) does
+    loss = ((model(mine["x"]) - mine["y"]) ** 2).sum() * world / B
+    loss.backward()
+    sync2.finish()
+    check("set_to_none")
     gn = parallel.global_grad_norm(model.parameters())
     gathered = [torch.zeros(()) for _ in range(world)]
     dist.all_gather(gathered, gn)
