@@ -23,6 +23,16 @@ FLAGS = [
 ]
 
 
+# per-file extra flags.  raster.hip: no packed fp32.  Its pixel loops are written on 2-vectors (two pixels per lane); on
+# gfx950 a v_pk_fma_f32 costs 7.6 issue cycles against 2 x 2.95 for the two plain FMAs it replaces
+# (profiles/r02c_valu_probe.txt), and these kernels are VALU-issue bound.  (The host pass ignores the feature with a
+# warning.)  GOLIATH_RASTER_PK=1 builds the packed variant for A/B runs.
+EXTRA_FLAGS = {
+    "raster.hip": [] if os.environ.get("GOLIATH_RASTER_PK") == "1" else
+                  ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"],
+}
+
+
 def _sources():
     return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip"))
 
@@ -54,7 +64,7 @@ def _stale(target, deps):
 
 def _compile(src, verbose):
     obj = os.path.join(OBJ, os.path.basename(src)[:-4] + ".o")
-    cmd = [HIPCC, *FLAGS, "-c", src, "-o", obj]
+    cmd = [HIPCC, *FLAGS, *EXTRA_FLAGS.get(os.path.basename(src), []), "-c", src, "-o", obj]
     if verbose:
         print(" ".join(cmd), flush=True)
     r = subprocess.run(cmd, capture_output=True, text=True)

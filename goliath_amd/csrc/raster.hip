@@ -147,15 +147,15 @@ __global__ __launch_bounds__(128) void raster_fwd_kernel(
         alpha.y = fminf(GOL_ALPHA_CAP_FWD, b4.y * __builtin_amdgcn_exp2f(-sigma.y));
         const bool c0 = !done0 && !(sigma.x < 0.f || alpha.x < GOL_ALPHA_FLOOR);
         const bool c1 = !done1 && !(sigma.y < 0.f || alpha.y < GOL_ALPHA_FLOOR);
-        const f2 next_T = T_cur * (1.f - alpha);
+        f2 vis = alpha * T_cur;
+        const f2 next_T = T_cur - vis;  // = T (1 - alpha)
         const bool stop0 = c0 && (next_T.x <= GOL_T_STOP), stop1 = c1 && (next_T.y <= GOL_T_STOP);
         const bool take0 = c0 && !stop0, take1 = c1 && !stop1;
         done0 = done0 || stop0; done1 = done1 || stop1;
-        f2 vis = alpha * T_cur;
         vis.x = take0 ? vis.x : 0.f; vis.y = take1 ? vis.y : 0.f;
         acc0 += b4.z * vis; acc1 += b4.w * vis; acc2 += c2.x * vis;
         if (EXTRA) acc3 += c2.y * vis;
-        T_cur.x = take0 ? next_T.x : T_cur.x; T_cur.y = take1 ? next_T.y : T_cur.y;
+        T_cur -= vis;                   // unchanged where the entry is not taken
         cur_idx.x = take0 ? (batch_start + t) : cur_idx.x; cur_idx.y = take1 ? (batch_start + t) : cur_idx.y;
       }
     }
@@ -192,7 +192,7 @@ __global__ __launch_bounds__(128) void raster_fwd_kernel(
 }
 
 constexpr int kBatchB = 64;   // backward batch (smaller: per-wave gradient slots live in LDS)
-constexpr int kAcc = 12;      // r g b v_opacity | Sx Sy Sxx Sxy | Syy extra - -
+constexpr int kAcc = 12;      // r g b v_opacity | Mx My Mxx Mxy | Myy extra - -   (M = moments of gop, see the loop)
 
 // ---- backward, two pixels per lane -------------------------------------------------------------
 // 128-thread workgroup per tile: wave w owns the 16x8 half (rows 8w..8w+7), lane = (x = lane&15, row pair
@@ -256,7 +256,7 @@ __global__ __launch_bounds__(128) void raster_bwd_kernel(
     }
   }
   const f2 tail = T_final * (voa - (background[0] * vo0 + background[1] * vo1 + background[2] * vo2));
-  f2 buf0 = {0.f, 0.f}, buf1 = buf0, buf2 = buf0, buf3 = buf0;
+  f2 q = {0.f, 0.f};  // running sum over the Gaussians behind of fac * <colour, v_out>
 
   int wmax = max(bin_final.x, bin_final.y);
 #pragma unroll
@@ -320,30 +320,34 @@ __global__ __launch_bounds__(128) void raster_bwd_kernel(
       f2 fac = alpha * T_new;
       fac.x = v0 ? fac.x : 0.f; fac.y = v1 ? fac.y : 0.f;
       T_cur.x = v0 ? T_new.x : T_cur.x; T_cur.y = v1 ? T_new.y : T_cur.y;
-      f2 v_alpha = (b4.z * T_new - buf0 * ra) * vo0 + (b4.w * T_new - buf1 * ra) * vo1 +
-                   (c2.x * T_new - buf2 * ra) * vo2 + tail * ra;
+      // gsplat: v_alpha = sum_c (rgb_c T - buffer_c ra) v_out_c + T_final ra (v_out_alpha - <bg, v_out>) with
+      // buffer_c = sum over the Gaussians behind of rgb_c alpha T.  All channels enter through ONE dot product with the
+      // upstream gradient, w = <colour, v_out>, so the three running colour buffers collapse into the running scalar
+      // q = sum_behind fac w:  v_alpha = T w + ra (tail - q)
+      f2 w = b4.z * vo0 + b4.w * vo1 + c2.x * vo2;
+      if (EXTRA) w += c2.y * vo3;
+      const f2 v_alpha = T_new * w + ra * (tail - q);
+      q += fac * w;
       const f2 g0v = fac * vo0, g1v = fac * vo1, g2v = fac * vo2;
       float g3 = 0.f;
       if (EXTRA) {
         const f2 g3v = fac * vo3;
         g3 = g3v.x + g3v.y;
-        v_alpha += (c2.y * T_new - buf3 * ra) * vo3;
-        buf3 += c2.y * fac;
       }
-      buf0 += b4.z * fac; buf1 += b4.w * fac; buf2 += c2.x * fac;
-      f2 gopv = vis * v_alpha;
-      gopv.x = v0 ? gopv.x : 0.f; gopv.y = v1 ? gopv.y : 0.f;
-      const f2 vs = -b4.y * gopv;           // d loss / d sigma per pixel
-      const f2 vsy = vs * dy;
-      const float s0 = vs.x + vs.y;         // sum_pix v_sigma
-      const float sy = vsy.x + vsy.y;       // sum v_sigma dy
-      const f2 vsyy = vsy * dy;
-      const float syy = vsyy.x + vsyy.y;
-      const float sx = s0 * dx, sxx = sx * dx, sxy = sy * dx;
-      const float r0 = gol_wave_sum4(g0v.x + g0v.y, g1v.x + g1v.y, g2v.x + g2v.y, gopv.x + gopv.y);
-      const float r1 = gol_wave_sum4(sx, sy, sxx, sxy);
+      // d loss / d sigma per pixel is -opacity * gop; the (wave-uniform) factor -opacity is applied once per Gaussian in
+      // the merge step: the lanes reduce the moments of gop itself, whose zeroth moment IS v_opacity
+      f2 gop = vis * v_alpha;
+      gop.x = v0 ? gop.x : 0.f; gop.y = v1 ? gop.y : 0.f;
+      const f2 gy = gop * dy;
+      const float m0 = gop.x + gop.y;       // sum_pix gop
+      const float my = gy.x + gy.y;         // sum gop dy
+      const f2 gyy = gy * dy;
+      const float myy = gyy.x + gyy.y;
+      const float mx = m0 * dx, mxx = mx * dx, mxy = my * dx;
+      const float r0 = gol_wave_sum4(g0v.x + g0v.y, g1v.x + g1v.y, g2v.x + g2v.y, m0);
+      const float r1 = gol_wave_sum4(mx, my, mxx, mxy);
       // the 9th (and 10th) sum: a 6-instruction DPP ladder each (total in lane 63) instead of a third 4-way reduction
-      const float r2 = gol_wave_sum_to_lane63(syy);
+      const float r2 = gol_wave_sum_to_lane63(myy);
       const float r3 = EXTRA ? gol_wave_sum_to_lane63(g3) : 0.f;
       if ((lane & 15) == 15) {
         float* a = &s_acc[wave][t][lane >> 4];
@@ -361,12 +365,15 @@ __global__ __launch_bounds__(128) void raster_bwd_kernel(
         const int t = idx >> 4, c = idx & 15;
         const bool t0w = s_touched[0][t] != 0, t1w = s_touched[1][t] != 0;
         if (!(t0w || t1w) || c > (EXTRA ? 9 : 8)) continue;
-        // component c = w1 * S[k1] + w2 * S[k2] of the wave-summed slots S
+        // component c = w1 * S[k1] + w2 * S[k2] of the wave-summed slots S; slots 4..8 hold moments of gop:
+        // v_sigma-sums = -opacity * moment (conic back from its log2e scaling with ln 2)
         const float4 a4 = s_a[t];
-        const float cc = s_b[t].x;
+        const float4 b4 = s_b[t];
+        const float nop = -b4.y, cc = b4.x;
         const int k1 = (c == 5) ? 4 : c, k2 = 5;
-        const float w1 = (c == 4) ? a4.z * kLn2 : (c == 5) ? a4.w * kLn2 : (c == 6 || c == 8) ? 0.5f : 1.f;
-        const float w2 = (c == 4) ? a4.w * kLn2 : (c == 5) ? cc * kLn2 : 0.f;
+        const float w1 = (c == 4) ? nop * a4.z * kLn2 : (c == 5) ? nop * a4.w * kLn2 : (c == 6 || c == 8) ? 0.5f * nop
+                       : (c == 7) ? nop : 1.f;
+        const float w2 = (c == 4) ? nop * a4.w * kLn2 : (c == 5) ? nop * cc * kLn2 : 0.f;
         const float s1 = (t0w ? s_acc[0][t][k1] : 0.f) + (t1w ? s_acc[1][t][k1] : 0.f);
         const float s2 = (t0w ? s_acc[0][t][k2] : 0.f) + (t1w ? s_acc[1][t][k2] : 0.f);
         atomicAdd(rec + (goff + (size_t)s_id[t]) * 16 + c, w1 * s1 + w2 * s2);
@@ -390,13 +397,15 @@ __global__ __launch_bounds__(128) void raster_bwd_kernel(
       if (any) {
         const size_t g = goff + (size_t)s_id[tid];
         const float4 a4 = s_a[tid];
-        const float ca = a4.z * kLn2, cb = a4.w * kLn2, cc = s_b[tid].x * kLn2;
+        const float4 b4 = s_b[tid];
+        const float nop = -b4.y;  // slots 4..8 are moments of gop: v_sigma-sums = -opacity * moment
+        const float ca = a4.z * kLn2, cb = a4.w * kLn2, cc = b4.x * kLn2;
         atomicAdd(v_colors + 3 * g, a[0]); atomicAdd(v_colors + 3 * g + 1, a[1]); atomicAdd(v_colors + 3 * g + 2, a[2]);
         atomicAdd(v_opacity + g, a[3]);
-        atomicAdd(v_xy + 2 * g, ca * a[4] + cb * a[5]);
-        atomicAdd(v_xy + 2 * g + 1, cb * a[4] + cc * a[5]);
-        atomicAdd(v_conic + 3 * g, 0.5f * a[6]); atomicAdd(v_conic + 3 * g + 1, a[7]);
-        atomicAdd(v_conic + 3 * g + 2, 0.5f * a[8]);
+        atomicAdd(v_xy + 2 * g, nop * (ca * a[4] + cb * a[5]));
+        atomicAdd(v_xy + 2 * g + 1, nop * (cb * a[4] + cc * a[5]));
+        atomicAdd(v_conic + 3 * g, 0.5f * nop * a[6]); atomicAdd(v_conic + 3 * g + 1, nop * a[7]);
+        atomicAdd(v_conic + 3 * g + 2, 0.5f * nop * a[8]);
         if (EXTRA && v_extra) atomicAdd(v_extra + g, a[9]);
       }
     }
