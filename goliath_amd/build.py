@@ -23,14 +23,11 @@ FLAGS = [
 ]
 
 
-# per-file extra flags.  raster.hip: no packed fp32.  Its pixel loops are written on 2-vectors (two pixels per lane); on
-# gfx950 a v_pk_fma_f32 costs 7.6 issue cycles against 2 x 2.95 for the two plain FMAs it replaces
-# (profiles/r02c_valu_probe.txt), and these kernels are VALU-issue bound.  (The host pass ignores the feature with a
-# warning.)  GOLIATH_RASTER_PK=1 builds the packed variant for A/B runs.
-EXTRA_FLAGS = {
-    "raster.hip": [] if os.environ.get("GOLIATH_RASTER_PK") == "1" else
-                  ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"],
-}
+# per-file extra flags (none at present).  Measured and rejected: compiling raster.hip without packed fp32 ops
+# ("-Xclang -target-feature -Xclang -packed-fp32-ops") -- the isolated probe prices v_pk_fma_f32 at 2.6x a plain FMA
+# (profiles/r02c_valu_probe.txt), but inside the raster loops both builds take the same time (0.741 / 1.303 ms vs
+# 0.739 / 1.302 ms per 8 views): in situ a packed op costs two plain ones, so only the operation COUNT matters.
+EXTRA_FLAGS = {}
 
 
 def _sources():
