@@ -389,32 +389,20 @@ __device__ __forceinline__ void sort_tile_regs(const uint64_t* __restrict__ keys
   }
 }
 
-// Two size classes, two launches over all tiles (a tile exits at once in the launch that is not its class): lists of
-// up to 1024 keys -- all of them at the BASELINE config -- need 8 KiB of LDS for the three cross-wave steps, so 8
-// workgroups fit a CU where the 32 KiB of the general kernel allowed 5; the sort is a chain of dependent cross-lane
-// exchanges, i.e. latency bound, and speeds up with the number of lists in flight.
-template <bool LARGE>
 __global__ __launch_bounds__(256) void sort_kernel(int T, int64_t capacity, int32_t* __restrict__ tile_bins,
                                                    uint64_t* __restrict__ isect_keys,
                                                    int32_t* __restrict__ sorted_ids) {
-  __shared__ uint64_t lds_keys[LARGE ? kSortLds : 1024];
+  __shared__ uint64_t lds_keys[kSortLds];
   const int b = blockIdx.y, t = blockIdx.x, tid = threadIdx.x;
   int2* binp = reinterpret_cast<int2*>(tile_bins) + (size_t)b * T + t;
   int2 bin = *binp;
-  // clamp to capacity (overflow is reported through n_isect; keep the bins self-consistent).  The small-class launch
-  // runs first and rewrites the bin; the large-class launch sees the clamped values.
+  __syncthreads();  // everyone has read the bin before thread 0 may clamp it
+  // clamp to capacity (overflow is reported through n_isect; keep the bins self-consistent)
   int start = bin.x, end = bin.y;
   if (start > capacity) start = (int)capacity;
   if (end > capacity) end = (int)capacity;
+  if (tid == 0 && (start != bin.x || end != bin.y)) *binp = make_int2(start, end);
   const int n = end - start;
-  if (LARGE ? (n <= 1024) : (n > 1024)) {
-    if (!LARGE && tid == 0 && (start != bin.x || end != bin.y)) *binp = make_int2(start, end);
-    return;
-  }
-  if (!LARGE) {
-    __syncthreads();  // everyone has read the bin before thread 0 may clamp it
-    if (tid == 0 && (start != bin.x || end != bin.y)) *binp = make_int2(start, end);
-  }
   if (n <= 0) return;
   uint64_t* keys = isect_keys + (size_t)b * capacity + start;
   int32_t* out = sorted_ids + (size_t)b * capacity + start;
@@ -422,22 +410,27 @@ __global__ __launch_bounds__(256) void sort_kernel(int T, int64_t capacity, int3
     if (tid == 0) out[0] = (int32_t)(uint32_t)keys[0];
     return;
   }
-  if constexpr (!LARGE) {
-    if (n <= 256) sort_tile_regs<1>(keys, out, n, lds_keys, tid);
-    else if (n <= 512) sort_tile_regs<2>(keys, out, n, lds_keys, tid);
-    else sort_tile_regs<4>(keys, out, n, lds_keys, tid);
+  if (n <= 256) {
+    sort_tile_regs<1>(keys, out, n, lds_keys, tid);
+  } else if (n <= 512) {
+    sort_tile_regs<2>(keys, out, n, lds_keys, tid);
+  } else if (n <= 1024) {
+    sort_tile_regs<4>(keys, out, n, lds_keys, tid);
+  } else if (n <= 2048) {
+    sort_tile_regs<8>(keys, out, n, lds_keys, tid);
+  } else if (n <= 4096) {
+    sort_tile_regs<16>(keys, out, n, lds_keys, tid);
+  } else if (n <= kSortLds) {
+    for (int i = tid; i < n; i += 256) lds_keys[i] = keys[i];
+    __syncthreads();
+    bitonic_sort(lds_keys, n, tid, 256);
+    for (int i = tid; i < n; i += 256) out[i] = (int32_t)(uint32_t)lds_keys[i];
   } else {
-    if (n <= 2048) {
-      sort_tile_regs<8>(keys, out, n, lds_keys, tid);
-    } else if (n <= 4096) {
-      sort_tile_regs<16>(keys, out, n, lds_keys, tid);
-    } else {
-      // rare: a tile covered by > 4096 Gaussians; the plain network straight on global memory
-      // (one workgroup = one CU, so __syncthreads() orders its own global stores and loads)
-      __syncthreads();
-      bitonic_sort(keys, n, tid, 256);
-      for (int i = tid; i < n; i += 256) out[i] = (int32_t)(uint32_t)keys[i];
-    }
+    // rare: a tile covered by > 4096 Gaussians; same network straight on global memory
+    // (one workgroup = one CU, so __syncthreads() orders its own global stores and loads)
+    __syncthreads();
+    bitonic_sort(keys, n, tid, 256);
+    for (int i = tid; i < n; i += 256) out[i] = (int32_t)(uint32_t)keys[i];
   }
 }
 
@@ -514,8 +507,7 @@ extern "C" int gol_bin_sort(int B, int N, const float* xys, const float* depths,
     } else {
       scatter_kernel<<<dim3(gol_cdiv(N, 256), B), 256, 0, s>>>(a, capacity, tile_bins, isect_keys);
     }
-    sort_kernel<false><<<dim3(T, B), 256, 0, s>>>(T, capacity, tile_bins, isect_keys, sorted_ids);
-    sort_kernel<true><<<dim3(T, B), 256, 0, s>>>(T, capacity, tile_bins, isect_keys, sorted_ids);
+    sort_kernel<<<dim3(T, B), 256, 0, s>>>(T, capacity, tile_bins, isect_keys, sorted_ids);
   }
   GOL_CHECK_LAUNCH();
   return GOL_OK;
