@@ -31,7 +31,7 @@ LEAVES = ("f_vn", "f_vc", "postex", "tn", "albedo")
 STAGE = ("color", "opacity", "primpos", "primscale", "primqvec")
 
 
-def _robust_rel_l2(a, b, drop=1e-4):
+def _robust_rel_l2(a, b, drop=1e-4):  # noqa: C901
     """rel-L2 over [B, C, N]-shaped per-Gaussian gradients with the `drop` fraction of Gaussians with the largest error
     left out.  Two legitimate sources put O(1) errors on isolated Gaussians: threshold-flip pixels (above), and the
     env-map specular term, which is piecewise linear in the reflection direction (bilinear texel lookups,
@@ -67,12 +67,21 @@ def _gpu_step(mb, cfg):
     return rgb.detach(), alpha, depth.detach(), float(loss), last, d
 
 
-@pytest.mark.parametrize("B", [4])
-def test_bench_step_matches_oracle_chain_at_config2(B):
+CONFIGS = {
+    # BASELINE config 2: the benchmarked size, B = 4 views per launch (one micro-batch of bench.py)
+    "config2": dict(views_per_gpu=4),
+    # BASELINE config 1 (plumbing size): 10k Gaussians, one camera, 512x512
+    "config1": dict(views_per_gpu=1, slab=100, gaussians=10_000, height=512, width=512, focal=1150.0),
+}
+
+
+@pytest.mark.parametrize("name", ["config2", "config1"])
+def test_bench_step_matches_oracle_chain(name):
     import bench
     from oracle import chain, cref
 
-    cfg = dict(bench.CFG, views_per_gpu=B)
+    cfg = dict(bench.CFG, **CONFIGS[name])
+    B = cfg["views_per_gpu"]
     H, W = cfg["height"], cfg["width"]
     cpu = bench.make_inputs(cfg, "cpu", rank=0)
     mb = {k: (v.detach().cuda().requires_grad_(v.requires_grad) if torch.is_tensor(v) else [m.cuda() for m in v])
@@ -93,7 +102,8 @@ def test_bench_step_matches_oracle_chain_at_config2(B):
         one["mips"] = [m[b:b + 1] for m in cpu["mips"]]
         o = chain.cpu_view(one, H, W, loss_scale=1.0 / (B * 3 * H * W))
         ref_loss += o["loss"]
-        assert o["n_isect"] > 1_000_000  # config-2 density (the pruned HIP lists are ~2 M, the 3-sigma lists ~3.6 M)
+        if name == "config2":
+            assert o["n_isect"] > 1_000_000  # config-2 density (the pruned HIP lists are ~2 M, the 3-sigma lists ~3.6 M)
         worst["rgb"] = max(worst["rgb"], rel_l2(rgb[b], o["rgb"]))
         worst["alpha"] = max(worst["alpha"], rel_l2(alpha[b, 0], o["alpha"]))
         worst["depth"] = max(worst["depth"], rel_l2(depth[b, 0], o["depth_norm"]))
@@ -124,15 +134,20 @@ def test_bench_step_matches_oracle_chain_at_config2(B):
             S2 = ref.shape[-1] * ref.shape[-2]
             report["grads_without_worst_1e-4_gaussians"][k] = _robust_rel_l2(
                 mb[k].grad.reshape(B, -1, S2), ref.reshape(B, -1, S2))
-    print("\nFULLSIZE_PARITY " + json.dumps(report))
+    print(f"\nCHAIN_PARITY {name} " + json.dumps(report))
     out_dir = os.path.join(ROOT, "gpurun_out")
     if os.path.isdir(out_dir):
-        with open(os.path.join(out_dir, "fullsize_parity.json"), "w") as f:
+        with open(os.path.join(out_dir, "fullsize_parity.json" if name == "config2" else f"chain_parity_{name}.json"), "w") as f:
             json.dump(report, f, indent=1)
     assert abs(loss - ref_loss) < 1e-5 * abs(ref_loss)
     for k, v in worst.items():
         assert v < (TOL_DEPTH if k == "depth" else TOL_OUT), (k, v)
     assert report["flip_pixel_fraction"] < 1e-3, report["flip_pixel_fraction"]  # expected << 0.1 %
+    if name == "config1":  # 10k Gaussians: too few for a 1e-4 quantile to mean anything; the plain metric must hold
+        for k in ("stage_grads", "grads"):
+            for kk, v in report[k].items():
+                assert v < 2e-3, (k, kk, v)
+        return
     for name in ("stage_grads_without_worst_1e-4_gaussians", "grads_without_worst_1e-4_gaussians"):
         for k, v in report[name].items():
             assert v < TOL_ROBUST, (name, k, v)
