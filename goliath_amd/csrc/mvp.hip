@@ -327,13 +327,16 @@ __global__ __launch_bounds__(256) void march_fwd_kernel(MarchArgs a, float* __re
   int iter = 0;
   // !__all(t > rt1 + 1e-5 || done)   (subset_kernel.h:81)
   while (__ballot(ray.live && !(ray.t > ray.rt1 + 1e-5f || sat)) != 0ull) {
-    for (int s = 0; s < num; ++s) {
-      // wave-uniform LDS reads -> SGPRs, so the skip is a scalar branch and the box transform below
-      // comes through scalar loads
-      const int w_lo = __builtin_amdgcn_readfirstlane(s_lo[wave][s]);
-      const int w_hi = __builtin_amdgcn_readfirstlane(s_hi[wave][s]);
-      if (iter < w_lo || iter > w_hi) continue;  // no lane of the wave can be inside this box now
-      const int k = __builtin_amdgcn_readfirstlane(s_list[wave][s]);
+    // the boxes whose window contains this iteration, 64 list entries per ballot (lane j tests entry base + j), then a
+    // scalar walk over the set bits in list order: the per-step cost follows the 2-3 boxes the wave is inside, not the
+    // length of the hit list
+    for (int base = 0; base < num; base += 64) {
+    const int s_me = base + lane;
+    unsigned long long active = __ballot(s_me < num && s_lo[wave][s_me] <= iter && iter <= s_hi[wave][s_me]);
+    while (active) {
+      const int s = base + __builtin_ctzll(active);
+      active &= active - 1;
+      const int k = __builtin_amdgcn_readfirstlane(s_list[wave][s]);  // wave-uniform: the box transform comes through scalar loads
       Xform xf;
       const V3 y0 = xform_fwd(xf, primpos, primrot, primscale, k, ray.pos);
       const bool ev = ray.live && valid_pos(y0) && !sat && ray.t < ray.rt1 + 1e-5f;
@@ -401,6 +404,7 @@ __global__ __launch_bounds__(256) void march_fwd_kernel(MarchArgs a, float* __re
         }
       }
     }
+    }
     ray.t += a.stepsize;
     ray.pos = ray.pos + ray.dir * a.stepsize;
     ++iter;
@@ -450,10 +454,12 @@ __global__ __launch_bounds__(256) void march_bwd_kernel(MarchArgs a, const float
   int iter = 0;
   const float fe = a.fadeexp, fs = a.fadescale;
   while (__ballot(ray.live && ray.t < ray.rt1 + 1e-5f && !sat) != 0ull) {
-    for (int s = 0; s < num; ++s) {
-      const int w_lo = __builtin_amdgcn_readfirstlane(s_lo[wave][s]);
-      const int w_hi = __builtin_amdgcn_readfirstlane(s_hi[wave][s]);
-      if (iter < w_lo || iter > w_hi) continue;
+    for (int base = 0; base < num; base += 64) {  // (see the forward kernel)
+    const int s_me = base + lane;
+    unsigned long long active = __ballot(s_me < num && s_lo[wave][s_me] <= iter && iter <= s_hi[wave][s_me]);
+    while (active) {
+      const int s = base + __builtin_ctzll(active);
+      active &= active - 1;
       const int k = __builtin_amdgcn_readfirstlane(s_list[wave][s]);
       Xform xf;
       const V3 y0 = xform_fwd(xf, primpos, primrot, primscale, k, ray.pos);
@@ -564,6 +570,7 @@ __global__ __launch_bounds__(256) void march_bwd_kernel(MarchArgs a, const float
           if (j < 3) atomicAdd(g_rot + 9 * k + 6 + j, r3);
         }
       }
+    }
     }
     ray.t += a.stepsize;
     ray.pos = ray.pos + ray.dir * a.stepsize;
