@@ -112,7 +112,8 @@ def step(t, cfg, world):
     for stream in t["streams"]:
         main.wait_stream(stream)
     # the path's only parameter (albedo, rgca.py:462-464) is shared by all views: sum the micro-batch grads
-    t["albedo"].grad = torch.stack([mb["albedo"].grad for mb in t["micro"]]).sum(0)
+    t["_albedo_grad"] = torch.stack([mb["albedo"].grad for mb in t["micro"]]).sum(0)
+    t["albedo"].grad = t["_albedo_grad"]
     return loss
 
 
@@ -126,6 +127,7 @@ def run_step(t, cfg, world, graph=None):
         step(t, cfg, world)
     else:
         graph.replay()
+        t["albedo"].grad = t["_albedo_grad"]  # the tensor the captured step writes (GradSync re-points .grad to its bucket)
     if world > 1:
         t["_sync"].sync()  # reduce-scatter + all-gather over RCCL
 

@@ -102,6 +102,7 @@ class GradSync:
         self._launched: List[bool] = []
         self._hooks = []
         self._built_for = None
+        self._avg_op = False
 
     # ---------------------------------------------------------------------------------------------------------
     def _build(self, w: int):
@@ -128,7 +129,21 @@ class GradSync:
             for p in self.params:
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
         self._built_for = w
+        self._avg_op = self._probe_avg(w)
         self._reset()
+
+    def _probe_avg(self, w: int) -> bool:
+        """Can the backend average inside the collective (RCCL: ReduceOp.AVG)?  Probed once with a tiny synchronous
+        reduce-scatter; any refusal falls back to dividing the bucket before the sum (gloo always does)."""
+        if not self.average or w == 1 or dist.get_backend() != "nccl" or not self._flat:
+            return False
+        try:
+            src = torch.ones(w, dtype=self._flat[0].dtype, device=self._flat[0].device)
+            dst = torch.empty(1, dtype=src.dtype, device=src.device)
+            dist.reduce_scatter_tensor(dst, src, op=dist.ReduceOp.AVG)
+            return bool(abs(float(dst) - 1.0) < 1e-6)
+        except Exception:  # noqa: BLE001 -- an unsupported op must not take the job down
+            return False
 
     def _reset(self):
         self._arrived = [0] * len(self.buckets)
@@ -154,7 +169,7 @@ class GradSync:
     def _launch(self, bi: int):
         w = self._built_for
         flat, shard = self._flat[bi], self._shard[bi]
-        avg_op = self.average and dist.get_backend() == "nccl"   # RCCL reduces with AVG natively; gloo cannot
+        avg_op = self._avg_op   # RCCL reduces with AVG natively (probed); otherwise divide first, sum in the collective
         if self.average and not avg_op:
             flat.div_(w)
         h1 = dist.reduce_scatter_tensor(shard, flat, op=dist.ReduceOp.AVG if avg_op else dist.ReduceOp.SUM,
