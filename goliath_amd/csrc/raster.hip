@@ -102,11 +102,15 @@ __global__ __launch_bounds__(128) void raster_fwd_kernel(
   f2 T_cur = {1.f, 1.f};
   i2 cur_idx = {0, 0};
   f2 acc0 = {0.f, 0.f}, acc1 = acc0, acc2 = acc0, acc3 = acc0;
-  bool done0 = !in0, done1 = !in1;
+  // 1 while the pixel still composites, 0 once it stopped (or lies outside the image).  Carried as a FLOAT in a VGPR
+  // and multiplied into alpha: a dead pixel then fails the alpha >= 1/255 test by itself.  As loop-carried booleans the
+  // same state lived in SGPR lane masks and cost ~30 scalar instructions per visit to maintain (PMC: the scalar pipes
+  // of this kernel were as busy as the vector pipes, 76 % / 78 %).
+  f2 live = {in0 ? 1.f : 0.f, in1 ? 1.f : 0.f};
 
   const int n_batches = (range.y - range.x + kBatch - 1) / kBatch;
   for (int bb = 0; bb < n_batches; ++bb) {
-    if (__syncthreads_and(done0 && done1)) break;  // also protects the LDS batch from being overwritten early
+    if (__syncthreads_and((__float_as_uint(live.x) | __float_as_uint(live.y)) == 0u)) break;  // also protects the LDS batch from being overwritten early
     const int batch_start = range.x + bb * kBatch;
     for (int k = tid; k < kBatch; k += 128) {
       const int idx = batch_start + k;
@@ -132,7 +136,7 @@ __global__ __launch_bounds__(128) void raster_fwd_kernel(
     for (int chunk = 0; chunk < batch_size; chunk += 64) {
       unsigned long long bits = __ballot((s_mask[chunk + lane] >> wave) & 1);
       while (bits) {
-        if (__ballot(!(done0 && done1)) == 0ull) { chunk = batch_size; break; }  // this wave's half is finished
+        if (__ballot((__float_as_uint(live.x) | __float_as_uint(live.y)) != 0u) == 0ull) { chunk = batch_size; break; }  // this wave's half is finished
         const int t = chunk + __builtin_ctzll(bits);
         bits &= bits - 1;
         const float4 a4 = s_a[t];
@@ -141,17 +145,18 @@ __global__ __launch_bounds__(128) void raster_fwd_kernel(
         // branch-free pixel update: selects instead of exec-mask regions (the loop is issue-bound)
         const float dx = a4.x - px;
         const f2 dy = a4.y - py;
-        const f2 sigma = 0.5f * (a4.z * dx * dx + b4.x * dy * dy) + (a4.w * dx) * dy;
+        const f2 sigma = 0.5f * (a4.z * dx * dx + b4.x * dy * dy) + (a4.w * dx) * dy;  // log2e * gsplat's sigma
         f2 alpha;
-        alpha.x = fminf(GOL_ALPHA_CAP_FWD, b4.y * __builtin_amdgcn_exp2f(-sigma.x));  // sigma = log2e * gsplat's
+        alpha.x = fminf(GOL_ALPHA_CAP_FWD, b4.y * __builtin_amdgcn_exp2f(-sigma.x));
         alpha.y = fminf(GOL_ALPHA_CAP_FWD, b4.y * __builtin_amdgcn_exp2f(-sigma.y));
-        const bool c0 = !done0 && !(sigma.x < 0.f || alpha.x < GOL_ALPHA_FLOOR);
-        const bool c1 = !done1 && !(sigma.y < 0.f || alpha.y < GOL_ALPHA_FLOOR);
+        alpha *= live;
+        const bool c0 = !(sigma.x < 0.f || alpha.x < GOL_ALPHA_FLOOR);
+        const bool c1 = !(sigma.y < 0.f || alpha.y < GOL_ALPHA_FLOOR);
         f2 vis = alpha * T_cur;
         const f2 next_T = T_cur - vis;  // = T (1 - alpha)
         const bool stop0 = c0 && (next_T.x <= GOL_T_STOP), stop1 = c1 && (next_T.y <= GOL_T_STOP);
         const bool take0 = c0 && !stop0, take1 = c1 && !stop1;
-        done0 = done0 || stop0; done1 = done1 || stop1;
+        live.x = stop0 ? 0.f : live.x; live.y = stop1 ? 0.f : live.y;
         vis.x = take0 ? vis.x : 0.f; vis.y = take1 ? vis.y : 0.f;
         acc0 += b4.z * vis; acc1 += b4.w * vis; acc2 += c2.x * vis;
         if (EXTRA) acc3 += c2.y * vis;
