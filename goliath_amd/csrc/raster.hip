@@ -25,9 +25,11 @@
 namespace {
 
 constexpr int kBatch = 256;
-// conics are staged in LDS pre-multiplied by log2(e): alpha = opacity * 2^(-sigma') is one v_exp_f32 with a negated
-// operand instead of a multiply + exp per pixel; ln(2) brings the true conic back where the backward needs it
+// conics are staged in LDS pre-multiplied by log2(e) -- alpha = opacity * 2^(-sigma') is one v_exp_f32 with a negated
+// operand instead of a multiply + exp per pixel -- and the diagonal terms by the 1/2 of sigma = (a dx^2 + c dy^2) / 2 +
+// b dx dy as well; kUnA / kUnB bring the true conic back where the backward needs it
 constexpr float kLog2e = 1.4426950408889634f, kLn2 = 0.6931471805599453f;
+constexpr float kScA = 0.5f * kLog2e, kScB = kLog2e, kUnA = 2.f * kLn2, kUnB = kLn2;
 
 struct TileCoord { int tile, tx, ty; bool ok; };
 
@@ -121,8 +123,8 @@ __global__ __launch_bounds__(128) void raster_fwd_kernel(
         const float op = opacities[g];
         const float r = colors[3 * g], gg = colors[3 * g + 1], bl = colors[3 * g + 2];
         const float ex = EXTRA ? extra[g] : 0.f;
-        s_a[k] = make_float4(xy.x, xy.y, ca * kLog2e, cb * kLog2e);
-        s_b[k] = make_float4(cc * kLog2e, op, r, gg);
+        s_a[k] = make_float4(xy.x, xy.y, ca * kScA, cb * kScB);
+        s_b[k] = make_float4(cc * kScA, op, r, gg);
         s_c[k] = make_float2(bl, ex);
         s_mask[k] = half_mask(xy.x, xy.y, ca, cb, cc, op, (float)(tc.tx * 16), (float)(tc.ty * 16));
       } else {
@@ -145,7 +147,7 @@ __global__ __launch_bounds__(128) void raster_fwd_kernel(
         // branch-free pixel update: selects instead of exec-mask regions (the loop is issue-bound)
         const float dx = a4.x - px;
         const f2 dy = a4.y - py;
-        const f2 sigma = 0.5f * (a4.z * dx * dx + b4.x * dy * dy) + (a4.w * dx) * dy;  // log2e * gsplat's sigma
+        const f2 sigma = (a4.z * dx * dx + b4.x * dy * dy) + (a4.w * dx) * dy;  // log2e * gsplat's sigma
         f2 alpha;
         alpha.x = fminf(GOL_ALPHA_CAP_FWD, b4.y * __builtin_amdgcn_exp2f(-sigma.x));
         alpha.y = fminf(GOL_ALPHA_CAP_FWD, b4.y * __builtin_amdgcn_exp2f(-sigma.y));
@@ -286,8 +288,8 @@ __global__ __launch_bounds__(128) void raster_bwd_kernel(
         const float op = opacities[g];
         const float r = colors[3 * g], gg = colors[3 * g + 1], bl = colors[3 * g + 2];
         const float ex = EXTRA ? extra[g] : 0.f;
-        s_a[tid] = make_float4(xy.x, xy.y, ca * kLog2e, cb * kLog2e);
-        s_b[tid] = make_float4(cc * kLog2e, op, r, gg);
+        s_a[tid] = make_float4(xy.x, xy.y, ca * kScA, cb * kScB);
+        s_b[tid] = make_float4(cc * kScA, op, r, gg);
         s_c[tid] = make_float2(bl, ex);
         s_mask[tid] = half_mask(xy.x, xy.y, ca, cb, cc, op, (float)(tc.tx * 16), (float)(tc.ty * 16));
         s_id[tid] = gid;
@@ -310,7 +312,7 @@ __global__ __launch_bounds__(128) void raster_bwd_kernel(
       const int li = batch_end - t;
       const float dx = a4.x - px;
       const f2 dy = a4.y - py;
-      const f2 sigma = 0.5f * (a4.z * dx * dx + b4.x * dy * dy) + (a4.w * dx) * dy;
+      const f2 sigma = (a4.z * dx * dx + b4.x * dy * dy) + (a4.w * dx) * dy;
       f2 vis;
       vis.x = __builtin_amdgcn_exp2f(-sigma.x); vis.y = __builtin_amdgcn_exp2f(-sigma.y);  // sigma = log2e * gsplat's
       f2 alpha = b4.y * vis;
@@ -318,13 +320,15 @@ __global__ __launch_bounds__(128) void raster_bwd_kernel(
       const bool v0 = (li <= bin_final.x) && !(sigma.x < 0.f || alpha.x < GOL_ALPHA_FLOOR);
       const bool v1 = (li <= bin_final.y) && !(sigma.y < 0.f || alpha.y < GOL_ALPHA_FLOOR);
       if (__ballot(v0 || v1) == 0ull) continue;
+      // an entry the pixel did not take enters with alpha = 0: 1 / (1 - 0) = 1 exactly, so T and the running sums pass
+      // through unchanged without further selects
+      alpha.x = v0 ? alpha.x : 0.f; alpha.y = v1 ? alpha.y : 0.f;
       const f2 one_m = 1.f - alpha;
       f2 ra;
       ra.x = __builtin_amdgcn_rcpf(one_m.x); ra.y = __builtin_amdgcn_rcpf(one_m.y);
       const f2 T_new = T_cur * ra;
-      f2 fac = alpha * T_new;
-      fac.x = v0 ? fac.x : 0.f; fac.y = v1 ? fac.y : 0.f;
-      T_cur.x = v0 ? T_new.x : T_cur.x; T_cur.y = v1 ? T_new.y : T_cur.y;
+      const f2 fac = alpha * T_new;
+      T_cur = T_new;
       // gsplat: v_alpha = sum_c (rgb_c T - buffer_c ra) v_out_c + T_final ra (v_out_alpha - <bg, v_out>) with
       // buffer_c = sum over the Gaussians behind of rgb_c alpha T.  All channels enter through ONE dot product with the
       // upstream gradient, w = <colour, v_out>, so the three running colour buffers collapse into the running scalar
@@ -376,9 +380,9 @@ __global__ __launch_bounds__(128) void raster_bwd_kernel(
         const float4 b4 = s_b[t];
         const float nop = -b4.y, cc = b4.x;
         const int k1 = (c == 5) ? 4 : c, k2 = 5;
-        const float w1 = (c == 4) ? nop * a4.z * kLn2 : (c == 5) ? nop * a4.w * kLn2 : (c == 6 || c == 8) ? 0.5f * nop
+        const float w1 = (c == 4) ? nop * a4.z * kUnA : (c == 5) ? nop * a4.w * kUnB : (c == 6 || c == 8) ? 0.5f * nop
                        : (c == 7) ? nop : 1.f;
-        const float w2 = (c == 4) ? nop * a4.w * kLn2 : (c == 5) ? nop * cc * kLn2 : 0.f;
+        const float w2 = (c == 4) ? nop * a4.w * kUnB : (c == 5) ? nop * cc * kUnA : 0.f;
         const float s1 = (t0w ? s_acc[0][t][k1] : 0.f) + (t1w ? s_acc[1][t][k1] : 0.f);
         const float s2 = (t0w ? s_acc[0][t][k2] : 0.f) + (t1w ? s_acc[1][t][k2] : 0.f);
         atomicAdd(rec + (goff + (size_t)s_id[t]) * 16 + c, w1 * s1 + w2 * s2);
@@ -404,7 +408,7 @@ __global__ __launch_bounds__(128) void raster_bwd_kernel(
         const float4 a4 = s_a[tid];
         const float4 b4 = s_b[tid];
         const float nop = -b4.y;  // slots 4..8 are moments of gop: v_sigma-sums = -opacity * moment
-        const float ca = a4.z * kLn2, cb = a4.w * kLn2, cc = b4.x * kLn2;
+        const float ca = a4.z * kUnA, cb = a4.w * kUnB, cc = b4.x * kUnA;
         atomicAdd(v_colors + 3 * g, a[0]); atomicAdd(v_colors + 3 * g + 1, a[1]); atomicAdd(v_colors + 3 * g + 2, a[2]);
         atomicAdd(v_opacity + g, a[3]);
         atomicAdd(v_xy + 2 * g, nop * (ca * a[4] + cb * a[5]));
