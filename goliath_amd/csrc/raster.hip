@@ -319,8 +319,7 @@ __global__ __launch_bounds__(128) void raster_bwd_kernel(
       alpha.x = fminf(GOL_ALPHA_CAP_BWD, alpha.x); alpha.y = fminf(GOL_ALPHA_CAP_BWD, alpha.y);
       const bool v0 = (li <= bin_final.x) && !(sigma.x < 0.f || alpha.x < GOL_ALPHA_FLOOR);
       const bool v1 = (li <= bin_final.y) && !(sigma.y < 0.f || alpha.y < GOL_ALPHA_FLOOR);
-      // (no early-out for visits without a taker: the forward's early termination leaves almost none -- measured with
-      // per-(entry, half) contribution bits --, and an empty visit only adds zeros)
+      if (__ballot(v0 || v1) == 0ull) continue;
       // an entry the pixel did not take enters with alpha = 0: 1 / (1 - 0) = 1 exactly, so T and the running sums pass
       // through unchanged without further selects
       alpha.x = v0 ? alpha.x : 0.f; alpha.y = v1 ? alpha.y : 0.f;
