@@ -60,12 +60,12 @@ __device__ __forceinline__ TileBox tile_box(float gx, float gy, float radius, in
 }
 
 // exact per-tile test used inside the tile loops (only when the conic is well formed)
-struct Reach { float gx, gy, a, b, c, tau; bool exact; };
+struct Reach { float gx, gy, a, b, c, ia, ic, tau; bool exact; };
 
 __device__ __forceinline__ bool tile_reached(const Reach& r, int x, int y, float block) {
   if (!r.exact) return true;
   const float x0 = (float)x * block + 0.5f, y0 = (float)y * block + 0.5f;
-  return gol_min_sigma_rect(r.gx, r.gy, r.a, r.b, r.c, x0, x0 + block - 1.f, y0, y0 + block - 1.f) <= r.tau;
+  return gol_min_sigma_rect(r.gx, r.gy, r.a, r.b, r.c, r.ia, r.ic, x0, x0 + block - 1.f, y0, y0 + block - 1.f) <= r.tau;
 }
 
 struct BinArgs {
@@ -94,6 +94,7 @@ __device__ __forceinline__ TileBox box_of(const BinArgs& a, size_t e, Reach& rc)
     ca = a.conics[3 * e]; cb = a.conics[3 * e + 1]; cc = a.conics[3 * e + 2]; op = a.opacities[e];
     rc.gx = c.x; rc.gy = c.y; rc.a = ca; rc.b = cb; rc.c = cc; rc.tau = gol_alpha_tau(op);
     rc.exact = (ca * cc - cb * cb > 0.f) && ca > 0.f && cc > 0.f;
+    rc.ia = 1.f / ca; rc.ic = 1.f / cc;  // once per Gaussian, not once per tile test
   }
   return tile_box(c.x, c.y, (float)r, a.tiles_x, a.tiles_y, a.inv_block, a.block, tight, ca, cb, cc, op);
 }
@@ -135,11 +136,14 @@ __global__ __launch_bounds__(1024) void count_lds_kernel(BinArgs a, int32_t* __r
 __global__ __launch_bounds__(1024) void scatter_lds_kernel(BinArgs a, int64_t capacity,
                                                            int32_t* __restrict__ tile_bins,
                                                            uint64_t* __restrict__ isect_keys) {
+  // LDS: per-tile counters packed two to a word (a workgroup sees at most `chunk` <= 32768 Gaussians, so 16 bits
+  // hold any count) + per-tile 32-bit base offsets: 6 bytes per tile instead of 8, i.e. 64.5 KB at 2048x1334 -- two
+  // workgroups per CU instead of one.  The kernel is latency bound (returning global atomics, barriers).
   extern __shared__ int32_t s_mem[];
-  const int b = blockIdx.y, T = a.tiles_x * a.tiles_y;
-  int32_t* s_cnt = s_mem;
-  int32_t* s_base = s_mem + T;
-  for (int t = threadIdx.x; t < T; t += 1024) s_cnt[t] = 0;
+  const int b = blockIdx.y, T = a.tiles_x * a.tiles_y, Tw = (T + 1) >> 1;
+  uint32_t* s_cnt = reinterpret_cast<uint32_t*>(s_mem);
+  int32_t* s_base = s_mem + Tw;
+  for (int t = threadIdx.x; t < Tw; t += 1024) s_cnt[t] = 0u;
   __syncthreads();
   const int i_begin = blockIdx.x * a.chunk + threadIdx.x, i_end = min(a.N, (int)(blockIdx.x + 1) * a.chunk);
   for (int i = i_begin; i < i_end; i += 1024) {
@@ -149,15 +153,19 @@ __global__ __launch_bounds__(1024) void scatter_lds_kernel(BinArgs a, int64_t ca
     const uint64_t mask = hm ? a.reach[(size_t)b * a.N + i] : 0;
     for (int y = tb.y0; y < tb.y1; ++y)
       for (int x = tb.x0; x < tb.x1; ++x)
-        if (reached_cached(rc, tb, hm, mask, x, y, a.block)) atomicAdd(&s_cnt[y * a.tiles_x + x], 1);
+        if (reached_cached(rc, tb, hm, mask, x, y, a.block)) {
+          const int t = y * a.tiles_x + x;
+          atomicAdd(&s_cnt[t >> 1], 1u << ((t & 1) << 4));
+        }
   }
   __syncthreads();
   int32_t* bins = tile_bins + (size_t)b * T * 2;
   for (int t = threadIdx.x; t < T; t += 1024) {
-    const int c = s_cnt[t];
+    const int c = (int)((s_cnt[t >> 1] >> ((t & 1) << 4)) & 0xffffu);
     if (c) s_base[t] = atomicAdd(bins + 2 * t + 1, c);
-    s_cnt[t] = 0;
   }
+  __syncthreads();
+  for (int t = threadIdx.x; t < Tw; t += 1024) s_cnt[t] = 0u;
   __syncthreads();
   uint64_t* keys = isect_keys + (size_t)b * capacity;
   for (int i = i_begin; i < i_end; i += 1024) {
@@ -171,8 +179,8 @@ __global__ __launch_bounds__(1024) void scatter_lds_kernel(BinArgs a, int64_t ca
     for (int y = tb.y0; y < tb.y1; ++y)
       for (int x = tb.x0; x < tb.x1; ++x) {
         if (!reached_cached(rc, tb, hm, mask, x, y, a.block)) continue;
-        const int t = y * a.tiles_x + x;
-        const int slot = s_base[t] + atomicAdd(&s_cnt[t], 1);
+        const int t = y * a.tiles_x + x, sh = (t & 1) << 4;
+        const int slot = s_base[t] + (int)((atomicAdd(&s_cnt[t >> 1], 1u << sh) >> sh) & 0xffffu);
         if (slot < capacity) keys[slot] = key;
       }
   }
@@ -478,6 +486,7 @@ extern "C" int gol_bin_sort(int B, int N, const float* xys, const float* depths,
   int per_view = gol_cdiv(512, B);
   a.chunk = N > 0 ? gol_cdiv(N, per_view) : 1;
   if (a.chunk < 1024) a.chunk = 1024;
+  if (a.chunk > 32768) a.chunk = 32768;  // scatter_lds_kernel keeps per-workgroup tile counts in 16 bits
   const int nblk = N > 0 ? gol_cdiv(N, a.chunk) : 1;
   const bool lds_path = (size_t)T * 8 <= 128 * 1024;
   a.reach = (lds_path && conics) ? reach_scratch : nullptr;
@@ -500,7 +509,7 @@ extern "C" int gol_bin_sort(int B, int N, const float* xys, const float* depths,
   scan_kernel<<<B, 1024, 0, s>>>(T, tile_count, tile_bins, n_isect);
   if (N > 0 && capacity > 0) {
     if (lds_path) {
-      const size_t lds = sizeof(int32_t) * (size_t)T * 2;
+      const size_t lds = sizeof(int32_t) * ((size_t)((T + 1) >> 1) + (size_t)T);
       if (lds_limit_needs_raise(1, lds))
         hipFuncSetAttribute((const void*)scatter_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       scatter_lds_kernel<<<dim3(nblk, B), 1024, lds, s>>>(a, capacity, tile_bins, isect_keys);

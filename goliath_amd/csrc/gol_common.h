@@ -107,10 +107,10 @@ __device__ __forceinline__ float gol_alpha_tau(float op) {
 }
 // minimum of sigma over the axis-aligned rectangle [x0,x1] x [y0,y1] (exact: the quadratic is convex,
 // so the minimum is 0 inside or lies on one of the four edges)
-__device__ __forceinline__ float gol_min_sigma_rect(float gx, float gy, float a, float b, float c, float x0,
-                                                    float x1, float y0, float y1) {
+// (ia = 1 / a and ic = 1 / c are per-Gaussian: callers testing many rectangles pass them in)
+__device__ __forceinline__ float gol_min_sigma_rect(float gx, float gy, float a, float b, float c, float ia, float ic,
+                                                    float x0, float x1, float y0, float y1) {
   if (gx >= x0 && gx <= x1 && gy >= y0 && gy <= y1) return 0.f;
-  const float ia = 1.f / a, ic = 1.f / c;
   float m = 3.0e38f;
 #pragma unroll
   for (int e = 0; e < 2; ++e) {

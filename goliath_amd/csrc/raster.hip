@@ -63,10 +63,11 @@ __device__ __forceinline__ int half_mask(float gx, float gy, float ca, float cb,
   const float det = ca * cc - cb * cb;
   if (!(det > 0.f) || !(ca > 0.f) || !(cc > 0.f)) return 0x3;
   int m = 0;
+  const float ia = 1.f / ca, ic = 1.f / cc;
 #pragma unroll
   for (int q = 0; q < 2; ++q) {
     const float x0 = tile_x0 + 0.5f, y0 = tile_y0 + (float)(q * 8) + 0.5f;
-    const float ms = gol_min_sigma_rect(gx, gy, ca, cb, cc, x0, x0 + 15.f, y0, y0 + 7.f);
+    const float ms = gol_min_sigma_rect(gx, gy, ca, cb, cc, ia, ic, x0, x0 + 15.f, y0, y0 + 7.f);
     m |= (ms <= tau) ? (1 << q) : 0;
   }
   return m;
