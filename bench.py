@@ -9,8 +9,7 @@ HIP streams, --micro) through the whole hot path with the decoder outputs alread
     fused shading tail (SH diffuse + activations + env-map specular)      gol_shade_fwd
     EWA projection (+ tile counts)                                        gol_project_fwd
     tile binning + per-tile depth sort                                    gol_bin_sort
-    colour + depth tile raster                                            gol_rasterize_fwd
-    L1 loss vs a fixed random target image                                gol_l1_fwd / gol_l1_bwd
+    colour + depth tile raster, L1 loss vs a fixed random target image    gol_rasterize_fwd (loss fused into its epilogue)
     raster / projection / shading backward                                gol_*_bwd
 Multi-GPU: views are independent units -> each rank renders its own 8 views (weak scaling); the only
 parameter on this path, the albedo map, has its gradient all-reduced over RCCL every step.
@@ -106,8 +105,10 @@ def step(t, cfg, world):
                 mb[k].grad = None
             preds = shade.shading_tail(mb["f_vn"], mb["f_vc"], mb["postex"], mb["tn"], mb["albedo"], mb["light_sh"],
                                        mb["campos"], preconv_envmap=mb["mips"], lightrot=mb["lightrot"])
-            rgb, alpha, depth = render_gs.render_batch(mb["K"], mb["Rt"], preds, cfg["height"], cfg["width"])
-            loss = losses.l1_image(rgb, mb["target"])  # == (rgb - target).abs().mean(), loss/__init__.py:411
+            # loss == (rgb - target).abs().mean() (loss/__init__.py:411), evaluated in the raster epilogue and
+            # back-propagated by the raster backward itself (losses.l1_image is the stand-alone form of the same op)
+            rgb, alpha, depth, loss = render_gs.render_batch(mb["K"], mb["Rt"], preds, cfg["height"], cfg["width"],
+                                                             l1_target=mb["target"])
             loss.backward()
     for stream in t["streams"]:
         main.wait_stream(stream)
@@ -151,7 +152,8 @@ def algorithmic_bytes(name, N, I, P, n_mips_bytes):
         "gol_project_fwd": 44 * N + 92 * N,
         "gol_project_bwd": (44 + 24 + 16 + 4 + 4) * N + 36 * N + 44 * N,
         "gol_bin_sort": 16 * N + 8 * I + 8 * I + 4 * I,
-        "gol_rasterize_fwd": 4 * I + 44 * I + 24 * P,
+        # rgb 12 + depth 4 + T 4 + idx 4 + alpha 4 + depth_norm 4 out; fused L1: target 12 in, sign image 12 out
+        "gol_rasterize_fwd": 4 * I + 44 * I + 32 * P + 24 * P,
         "gol_rasterize_bwd": 4 * I + 44 * I + 20 * P + 36 * N,
         "gol_l1_fwd": 24 * P,           # rendered + target image
         "gol_l1_bwd": 24 * P + 12 * P,  # ... and the image gradient
@@ -493,8 +495,8 @@ def e2e_main(args):
             ev[1].record()
             preds = shade.shading_tail(f_vn, f_vc, t["postex"], t["tn"], albedo, t["light_sh"], t["campos"],
                                        preconv_envmap=t["mips"], lightrot=t["lightrot"])
-        rgb, alpha, depth = render_gs.render_batch(t["K"], t["Rt"], preds, H, W)
-        loss = 10.0 * losses.l1_image(rgb, t["target"])          # rgca_example.yml:43-47  rgb_l1 weight 1e1
+        rgb, alpha, depth, l1 = render_gs.render_batch(t["K"], t["Rt"], preds, H, W, l1_target=t["target"])
+        loss = 10.0 * l1                                         # rgca_example.yml:43-47  rgb_l1 weight 1e1
         if not args.no_ssim:
             loss = loss + 0.2 * (1.0 - losses.ssim_image(rgb, t["target"]))  # :48-52  rgb_ssim weight 2e-1
         loss.backward()

@@ -83,7 +83,10 @@ __global__ __launch_bounds__(128) void raster_fwd_kernel(
     const float* __restrict__ conics, const float* __restrict__ colors, const float* __restrict__ extra,
     const float* __restrict__ opacities, const float* __restrict__ background, float* __restrict__ out_img,
     float* __restrict__ out_extra, float* __restrict__ final_Ts, int32_t* __restrict__ final_idx,
-    float* __restrict__ out_alpha, float* __restrict__ out_extra_norm, float norm_lo) {
+    float* __restrict__ out_alpha, float* __restrict__ out_extra_norm, float norm_lo,
+    const float* __restrict__ l1_target, const float* __restrict__ l1_mask, int l1_mask_c,
+    float* __restrict__ l1_sign, float* __restrict__ l1_partial) {
+  __shared__ float s_l1[2];
   __shared__ float4 s_a[kBatch];  // x, y, conic.a, conic.b
   __shared__ float4 s_b[kBatch];  // conic.c, opacity, r, g
   __shared__ float2 s_c[kBatch];  // b, extra
@@ -172,30 +175,44 @@ __global__ __launch_bounds__(128) void raster_fwd_kernel(
   // planar: [B,3,H,W] (what the model consumes, rgca.py:139); else gsplat's [B,H,W,3]
   const size_t hw = (size_t)img_h * img_w;
   const size_t os = planar ? hw : 1;
-  if (in0) {
-    const size_t p = ((size_t)view * img_h + i0) * img_w + j;
-    final_Ts[p] = T_cur.x;
-    final_idx[p] = cur_idx.x;
-    const size_t o0 = planar ? (size_t)view * 3 * hw + (size_t)i0 * img_w + j : 3 * p;
-    out_img[o0] = acc0.x + T_cur.x * background[0];
-    out_img[o0 + os] = acc1.x + T_cur.x * background[1];
-    out_img[o0 + 2 * os] = acc2.x + T_cur.x * background[2];
-    if (EXTRA) out_extra[p] = acc3.x;
+  float l1_acc = 0.f;
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const bool in = q ? in1 : in0;
+    if (!in) continue;
+    const int i = i0 + q;
+    const float Tq = q ? T_cur.y : T_cur.x;
+    const float c0 = (q ? acc0.y : acc0.x) + Tq * background[0], c1 = (q ? acc1.y : acc1.x) + Tq * background[1],
+                c2 = (q ? acc2.y : acc2.x) + Tq * background[2], ex = q ? acc3.y : acc3.x;
+    const size_t p = ((size_t)view * img_h + i) * img_w + j;
+    final_Ts[p] = Tq;
+    final_idx[p] = q ? cur_idx.y : cur_idx.x;
+    const size_t o0 = planar ? (size_t)view * 3 * hw + (size_t)i * img_w + j : 3 * p;
+    out_img[o0] = c0; out_img[o0 + os] = c1; out_img[o0 + 2 * os] = c2;
+    if (EXTRA) out_extra[p] = ex;
     // optional fused epilogue of AutoEncoder.render (rgca.py:137,144-145): alpha = 1 - T, depth / clamp(alpha, lo, 1)
-    if (out_alpha) out_alpha[p] = 1.f - T_cur.x;
-    if (EXTRA && out_extra_norm) out_extra_norm[p] = acc3.x / fminf(fmaxf(1.f - T_cur.x, norm_lo), 1.f);
+    if (out_alpha) out_alpha[p] = 1.f - Tq;
+    if (EXTRA && out_extra_norm) out_extra_norm[p] = ex / fminf(fmaxf(1.f - Tq, norm_lo), 1.f);
+    // optional fused masked L1 against a target image (rgb_l1, ca_code/loss/__init__.py:391-411; planar layout): the
+    // |difference| goes into a per-tile partial sum, sign * mask -- the loss gradient up to its scalar factor -- into
+    // l1_sign, which the backward reads as v_out_img: the two separate passes over the image of the loss disappear
+    if (l1_target) {
+      const float m0 = l1_mask ? l1_mask[((size_t)view * l1_mask_c) * hw + (size_t)i * img_w + j] : 1.f;
+      const float cs[3] = {c0, c1, c2};
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const float m = (l1_mask && l1_mask_c == 3) ? l1_mask[((size_t)view * 3 + c) * hw + (size_t)i * img_w + j] : m0;
+        const float d = (cs[c] - l1_target[o0 + c * os]) * m;
+        l1_acc += fabsf(d);
+        l1_sign[o0 + c * os] = (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f)) * m;
+      }
+    }
   }
-  if (in1) {
-    const size_t p = ((size_t)view * img_h + i0 + 1) * img_w + j;
-    final_Ts[p] = T_cur.y;
-    final_idx[p] = cur_idx.y;
-    const size_t o0 = planar ? (size_t)view * 3 * hw + (size_t)(i0 + 1) * img_w + j : 3 * p;
-    out_img[o0] = acc0.y + T_cur.y * background[0];
-    out_img[o0 + os] = acc1.y + T_cur.y * background[1];
-    out_img[o0 + 2 * os] = acc2.y + T_cur.y * background[2];
-    if (EXTRA) out_extra[p] = acc3.y;
-    if (out_alpha) out_alpha[p] = 1.f - T_cur.y;
-    if (EXTRA && out_extra_norm) out_extra_norm[p] = acc3.y / fminf(fmaxf(1.f - T_cur.y, norm_lo), 1.f);
+  if (l1_target) {  // (kernel-uniform) per-tile sum of |difference|: the caller adds the tiles up (deterministic)
+    const float ws = gol_wave_sum_to_lane63(l1_acc);
+    if (lane == 63) s_l1[wave] = ws;
+    __syncthreads();
+    if (tid == 0) l1_partial[(size_t)view * T + tc.tile] = s_l1[0] + s_l1[1];
   }
 }
 
@@ -219,7 +236,8 @@ __global__ __launch_bounds__(128) void raster_bwd_kernel(
     const float* __restrict__ final_Ts, const int32_t* __restrict__ final_idx,
     const float* __restrict__ v_out_img, const float* __restrict__ v_out_extra,
     const float* __restrict__ v_out_alpha, float* __restrict__ v_xy, float* __restrict__ v_conic,
-    float* __restrict__ v_colors, float* __restrict__ v_extra, float* __restrict__ v_opacity) {
+    float* __restrict__ v_colors, float* __restrict__ v_extra, float* __restrict__ v_opacity,
+    const float* __restrict__ v_img_scale) {
   __shared__ float4 s_a[kBatchB];
   __shared__ float4 s_b[kBatchB];
   __shared__ float2 s_c[kBatchB];
@@ -249,16 +267,17 @@ __global__ __launch_bounds__(128) void raster_bwd_kernel(
   const i2 bin_final = {in0 ? final_idx[p0] : (range.x - 1), in1 ? final_idx[p1] : (range.x - 1)};
   f2 vo0 = {0.f, 0.f}, vo1 = vo0, vo2 = vo0, vo3 = vo0, voa = vo0;
   {
+    const float vsc = v_img_scale ? v_img_scale[0] : 1.f;  // device scalar on v_out_img (fused L1: sign image x g / n)
     const size_t os = planar ? hw : 1;
     if (in0) {
       const size_t o = planar ? (size_t)view * 3 * hw + (size_t)i0 * img_w + j : 3 * p0;
-      vo0.x = v_out_img[o]; vo1.x = v_out_img[o + os]; vo2.x = v_out_img[o + 2 * os];
+      vo0.x = vsc * v_out_img[o]; vo1.x = vsc * v_out_img[o + os]; vo2.x = vsc * v_out_img[o + 2 * os];
       if (EXTRA && v_out_extra) vo3.x = v_out_extra[p0];
       if (v_out_alpha) voa.x = v_out_alpha[p0];
     }
     if (in1) {
       const size_t o = planar ? (size_t)view * 3 * hw + (size_t)(i0 + 1) * img_w + j : 3 * p1;
-      vo0.y = v_out_img[o]; vo1.y = v_out_img[o + os]; vo2.y = v_out_img[o + 2 * os];
+      vo0.y = vsc * v_out_img[o]; vo1.y = vsc * v_out_img[o + os]; vo2.y = vsc * v_out_img[o + 2 * os];
       if (EXTRA && v_out_extra) vo3.y = v_out_extra[p1];
       if (v_out_alpha) voa.y = v_out_alpha[p1];
     }
@@ -429,7 +448,8 @@ extern "C" int gol_rasterize_fwd(int B, int N, int img_h, int img_w, int block, 
                                  const float* conics, const float* colors, const float* extra,
                                  const float* opacities, const float* background, float* out_img,
                                  float* out_extra, float* final_Ts, int32_t* final_idx, float* out_alpha,
-                                 float* out_extra_norm, float norm_lo, void* stream) {
+                                 float* out_extra_norm, float norm_lo, const float* l1_target, const float* l1_mask,
+                                 int l1_mask_c, float* l1_sign, float* l1_partial, void* stream) {
   GOL_REQUIRE(B >= 0 && N >= 0, "negative size");
   GOL_REQUIRE(block == 16, "only block_width == 16 is implemented (the reference's value, render_gsplat.py:28)");
   GOL_REQUIRE(img_h > 0 && img_w > 0, "empty image");
@@ -440,6 +460,8 @@ extern "C" int gol_rasterize_fwd(int B, int N, int img_h, int img_w, int block, 
   GOL_REQUIRE(N == 0 || (xys && conics && colors && opacities), "null Gaussian attribute");
   GOL_REQUIRE(N == 0 || ((extra == nullptr) == (out_extra == nullptr)), "extra and out_extra go together");
   GOL_REQUIRE(!out_extra_norm || out_extra, "out_extra_norm needs the extra channel");
+  GOL_REQUIRE(!l1_target || (planar && l1_sign && l1_partial), "the fused L1 needs planar images, l1_sign and l1_partial");
+  GOL_REQUIRE(!l1_mask || (l1_target && (l1_mask_c == 1 || l1_mask_c == 3)), "l1_mask: 1 or 3 channels, with l1_target");
   const int tiles_x = (img_w + 15) / 16, tiles_y = (img_h + 15) / 16, T = tiles_x * tiles_y;
   dim3 grid(8 * ((tiles_y + 7) / 8) * tiles_x, B);
   const int2* bins = reinterpret_cast<const int2*>(tile_bins);
@@ -447,11 +469,13 @@ extern "C" int gol_rasterize_fwd(int B, int N, int img_h, int img_w, int block, 
   if (out_extra)
     raster_fwd_kernel<true><<<grid, 128, 0, s>>>(N, img_h, img_w, planar, tiles_x, tiles_y, bins, sorted_ids, capacity, xys,
                                                   conics, colors, extra, opacities, background, out_img, out_extra,
-                                                  final_Ts, final_idx, out_alpha, out_extra_norm, norm_lo);
+                                                  final_Ts, final_idx, out_alpha, out_extra_norm, norm_lo, l1_target,
+                                                  l1_mask, l1_mask_c, l1_sign, l1_partial);
   else
     raster_fwd_kernel<false><<<grid, 128, 0, s>>>(N, img_h, img_w, planar, tiles_x, tiles_y, bins, sorted_ids, capacity, xys,
                                                    conics, colors, extra, opacities, background, out_img, out_extra,
-                                                   final_Ts, final_idx, out_alpha, nullptr, norm_lo);
+                                                   final_Ts, final_idx, out_alpha, nullptr, norm_lo, l1_target,
+                                                   l1_mask, l1_mask_c, l1_sign, l1_partial);
   GOL_CHECK_LAUNCH();
   return GOL_OK;
 }
@@ -462,7 +486,8 @@ extern "C" int gol_rasterize_bwd(int B, int N, int img_h, int img_w, int block, 
                                  const float* opacities, const float* background, const float* final_Ts,
                                  const int32_t* final_idx, const float* v_out_img, const float* v_out_extra,
                                  const float* v_out_alpha, float* v_xy, float* v_conic, float* v_colors,
-                                 float* v_extra, float* v_opacity, int grad_stride, void* stream) {
+                                 float* v_extra, float* v_opacity, int grad_stride, const float* v_img_scale,
+                                 void* stream) {
   GOL_REQUIRE(B >= 0 && N >= 0, "negative size");
   GOL_REQUIRE(block == 16, "only block_width == 16 is implemented (the reference's value, render_gsplat.py:28)");
   GOL_REQUIRE(img_h > 0 && img_w > 0, "empty image");
@@ -487,7 +512,8 @@ extern "C" int gol_rasterize_bwd(int B, int N, int img_h, int img_w, int block, 
   raster_bwd_kernel<EX, PK><<<grid, 128, 0, s>>>(N, img_h, img_w, planar, tiles_x, tiles_y, bins, sorted_ids, capacity, \
                                                  xys, conics, colors, EX ? extra : nullptr, opacities, background,    \
                                                  final_Ts, final_idx, v_out_img, EX ? v_out_extra : nullptr,          \
-                                                 v_out_alpha, v_xy, v_conic, v_colors, EX ? v_extra : nullptr, v_opacity)
+                                                 v_out_alpha, v_xy, v_conic, v_colors, EX ? v_extra : nullptr, v_opacity, \
+                                                 v_img_scale)
   if (ex && packed) GOL_LAUNCH_BWD(true, true);
   else if (ex) GOL_LAUNCH_BWD(true, false);
   else if (packed) GOL_LAUNCH_BWD(false, true);

@@ -32,11 +32,16 @@ def render(cam_img_w: int, cam_img_h: int, fx: float, fy: float, cx: float, cy: 
     return res
 
 
-def render_batch(K: th.Tensor, Rt: th.Tensor, preds: Dict[str, Any], height: int, width: int):
+def render_batch(K: th.Tensor, Rt: th.Tensor, preds: Dict[str, Any], height: int, width: int,
+                 l1_target: Optional[th.Tensor] = None, l1_mask: Optional[th.Tensor] = None):
     """AutoEncoder.render semantics (rgca.py:112-151): rgb[B,3,H,W], alpha = 1 - T.detach(),
-    depth / alpha.clamp(0.05, 1).  K[B,3,3] and Rt[B,3,4] stay on the device."""
+    depth / alpha.clamp(0.05, 1).  K[B,3,3] and Rt[B,3,4] stay on the device.
+    With l1_target (and optionally l1_mask) a fourth value is returned: the masked L1 loss of rgb against it
+    (rgb_l1, ca_code/loss/__init__.py:391-411), fused into the raster passes."""
     intr = th.stack([K[:, 0, 0], K[:, 1, 1], K[:, 0, 2], K[:, 1, 2]], dim=-1)
     out = render_views(preds["primpos"], preds["primscale"], preds["primqvec"], preds["opacity"],
-                       preds["color"], Rt, intr, height, width, with_depth=True)
+                       preds["color"], Rt, intr, height, width, with_depth=True, l1_target=l1_target, l1_mask=l1_mask)
     # alpha = 1 - T.detach() and depth / alpha.clamp(0.05, 1) are written by the raster kernel's epilogue
+    if l1_target is not None:
+        return out["render"], out["alpha"].detach(), out["depth_norm"], out["l1_loss"]
     return out["render"], out["alpha"].detach(), out["depth_norm"]

@@ -267,7 +267,7 @@ class _RasterizeGaussians(torch.autograd.Function):
                           c_int(BLOCK), c_int(0), iptr(ws.tile_bins), iptr(ws.sorted_ids), c_i64(ws.capacity), fptr(xys),
                           fptr(conics), fptr(colors), fptr(None), fptr(opacity), fptr(background),
                           fptr(out_img), fptr(None), fptr(final_Ts), iptr(final_idx), fptr(None), fptr(None),
-                          c_float(0.0), stream_ptr())
+                          c_float(0.0), fptr(None), fptr(None), c_int(0), fptr(None), fptr(None), stream_ptr())
             ctx.ws = ws
             ctx.save_for_backward(xys, conics, colors, opacity, background, final_Ts, final_idx)
             out_img, final_Ts = out_img[0], final_Ts[0]
@@ -295,7 +295,8 @@ class _RasterizeGaussians(torch.autograd.Function):
                           iptr(ws.tile_bins), iptr(ws.sorted_ids), c_i64(ws.capacity), fptr(xys), fptr(conics),
                           fptr(colors), fptr(None), fptr(opacity), fptr(background), fptr(final_Ts),
                           iptr(final_idx), fptr(vo), fptr(None), fptr(va), fptr(v_xy),
-                          fptr(v_conic), fptr(v_colors), fptr(None), fptr(v_opacity), c_int(0), stream_ptr())
+                          fptr(v_conic), fptr(v_colors), fptr(None), fptr(v_opacity), c_int(0), fptr(None),
+                          stream_ptr())
             ctx.ws = None
         return (v_xy, None, None, v_conic, None, v_colors, v_opacity[:, None]) + (None,) * 5
 
@@ -333,7 +334,7 @@ def rasterize_gaussians(xys, depths, radii, conics, num_tiles_hit, colors, opaci
 class _RenderViews(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means, scales, quats, opacity, colors, viewmats, intrins, background, img_h, img_w,
-                glob_scale, clip_thresh, with_depth, capacity, depth_norm_lo, plan_key):
+                glob_scale, clip_thresh, with_depth, capacity, depth_norm_lo, plan_key, l1_target, l1_mask):
         B, N = means.shape[:2]
         dev = means.device
         T = _tiles(img_h, img_w)
@@ -348,6 +349,10 @@ class _RenderViews(torch.autograd.Function):
             # alpha = 1 - T and depth / clamp(alpha, lo, 1) come out of the raster epilogue (rgca.py:137,144-145)
             alpha = torch.empty(B, img_h, img_w, device=dev)
             depth_norm = torch.empty(B, img_h, img_w, device=dev) if with_depth else None
+            # optional fused L1 against a target image: sign image (the loss gradient up to a scalar) + per-tile sums
+            l1_sign = torch.empty(B, 3, img_h, img_w, device=dev) if l1_target is not None else None
+            l1_partial = torch.empty(B, T, device=dev) if l1_target is not None else None
+            l1_mask_c = 0 if l1_mask is None else l1_mask.shape[1]
 
             def bin_and_raster(cap):
                 ws = _Workspace(B, N, T, cap, dev)
@@ -357,7 +362,8 @@ class _RenderViews(torch.autograd.Function):
                           iptr(ws.tile_bins), iptr(ws.sorted_ids), c_i64(ws.capacity), fptr(xys), fptr(conics),
                           fptr(colors), fptr(depths if with_depth else None), fptr(opac_eff), fptr(background),
                           fptr(out_img), fptr(out_depth), fptr(final_Ts), iptr(final_idx), fptr(alpha),
-                          fptr(depth_norm), c_float(depth_norm_lo), stream_ptr())
+                          fptr(depth_norm), c_float(depth_norm_lo), fptr(l1_target), fptr(l1_mask), c_int(l1_mask_c),
+                          fptr(l1_sign), fptr(l1_partial), stream_ptr())
                 return ws, pending
 
             ws, pending = bin_and_raster(capacity)
@@ -375,16 +381,19 @@ class _RenderViews(torch.autograd.Function):
                     PLANNER.observe(plan_key, worst, capacity)
         ctx.ws = ws
         ctx.cfg = (img_h, img_w, glob_scale, with_depth, depth_norm_lo)
+        ctx.l1_inv_n = 1.0 / max(B * 3 * img_h * img_w, 1)
+        l1 = l1_partial.sum() * ctx.l1_inv_n if l1_target is not None else None  # == mean(|(rgb - target) * mask|)
         ctx.save_for_backward(means, scales, quats, opacity, colors, viewmats, intrins, background, cov3d, xys,
-                              depths, radii, conics, comp, opac_eff, final_Ts, final_idx)
+                              depths, radii, conics, comp, opac_eff, final_Ts, final_idx, l1_sign)
         ctx.mark_non_differentiable(radii, ws.n_isect, final_Ts, final_idx, ws.sorted_ids, ws.tile_bins)
         ctx.set_materialize_grads(False)
-        return out_img, alpha, out_depth, depth_norm, radii, ws.n_isect, final_Ts, final_idx, ws.sorted_ids, ws.tile_bins
+        return (out_img, alpha, out_depth, depth_norm, l1, radii, ws.n_isect, final_Ts, final_idx, ws.sorted_ids,
+                ws.tile_bins)
 
     @staticmethod
-    def backward(ctx, v_img, v_alpha, v_depth, v_depth_norm, *_non_differentiable):
+    def backward(ctx, v_img, v_alpha, v_depth, v_depth_norm, v_l1, *_non_differentiable):
         (means, scales, quats, opacity, colors, viewmats, intrins, background, cov3d, xys, depths, radii,
-         conics, comp, opac_eff, final_Ts, final_idx) = ctx.saved_tensors
+         conics, comp, opac_eff, final_Ts, final_idx, l1_sign) = ctx.saved_tensors
         img_h, img_w, glob_scale, with_depth, depth_norm_lo = ctx.cfg
         B, N = means.shape[:2]
         dev = means.device
@@ -392,9 +401,20 @@ class _RenderViews(torch.autograd.Function):
         if v_depth_norm is not None:  # depth_norm = depth / clamp(alpha.detach(), lo, 1), alpha = 1 - final_T
             g = v_depth_norm / (1.0 - final_Ts).clamp(depth_norm_lo, 1.0)
             v_depth = g if v_depth is None else v_depth + g
-        if v_img is None and v_alpha is None and v_depth is None:
+        if l1_sign is None:
+            v_l1 = None
+        if v_img is None and v_alpha is None and v_depth is None and v_l1 is None:
             ctx.ws = None
-            return (None,) * 16
+            return (None,) * 18
+        # fused L1: d loss / d rgb = l1_sign * (v_l1 / n).  When the image has no other consumer the sign image goes to
+        # the raster backward as it is, with the scalar as v_img_scale (a device scalar: no sync, no pass over the image)
+        v_scale = None
+        if v_l1 is not None:
+            v_scale = (v_l1.to(torch.float32) * ctx.l1_inv_n).reshape(1).contiguous()
+            if v_img is None:
+                v_img = l1_sign
+            else:
+                v_img, v_scale = torch.addcmul(_f32c(v_img), l1_sign, v_scale), None
         if v_img is None:
             v_img = torch.zeros(B, 3, img_h, img_w, device=dev)
         use_depth = with_depth and v_depth is not None
@@ -407,7 +427,7 @@ class _RenderViews(torch.autograd.Function):
         rec = torch.zeros(B, N, GRAD_RECORD, device=dev)
         field = lambda k: ctypes.c_void_p(rec.data_ptr() + 4 * k)
         v_mean = torch.empty_like(means)
-        v_scale = torch.empty_like(scales)
+        v_scale_g = torch.empty_like(scales)
         v_quat = torch.empty_like(quats)
         v_opacity = torch.empty_like(opacity)
         with torch.cuda.device(dev):
@@ -416,18 +436,19 @@ class _RenderViews(torch.autograd.Function):
                       fptr(colors), fptr(depths if use_depth else None), fptr(opac_eff), fptr(background),
                       fptr(final_Ts), iptr(final_idx), fptr(v_img_c), fptr(v_depth_c), fptr(v_alpha_c),
                       field(4), field(6), field(0),
-                      field(9) if use_depth else fptr(None), field(3), c_int(GRAD_RECORD), stream_ptr())
+                      field(9) if use_depth else fptr(None), field(3), c_int(GRAD_RECORD), fptr(v_scale), stream_ptr())
             _lib.call("gol_project_bwd", c_int(B), c_int(N), fptr(means), fptr(scales), c_float(glob_scale),
                       fptr(quats), fptr(viewmats), fptr(intrins), fptr(cov3d), iptr(radii), fptr(conics),
                       fptr(comp), field(4), field(9) if use_depth else fptr(None), field(6), fptr(None), fptr(opacity),
-                      field(3), c_int(GRAD_RECORD), fptr(v_mean), fptr(v_scale), fptr(v_quat), fptr(v_opacity),
+                      field(3), c_int(GRAD_RECORD), fptr(v_mean), fptr(v_scale_g), fptr(v_quat), fptr(v_opacity),
                       stream_ptr())
         ctx.ws = None  # the tile lists (the largest buffers of a step) go back to the allocator now
-        return (v_mean, v_scale, v_quat, v_opacity, rec[..., :3]) + (None,) * 11
+        return (v_mean, v_scale_g, v_quat, v_opacity, rec[..., :3]) + (None,) * 13
 
 
 def render_views(means, scales, quats, opacity, colors, viewmats, intrins, img_h, img_w,
-                 background=None, glob_scale=1.0, clip_thresh=0.1, with_depth=True, capacity=None, depth_norm_lo=0.05):
+                 background=None, glob_scale=1.0, clip_thresh=0.1, with_depth=True, capacity=None, depth_norm_lo=0.05,
+                 l1_target=None, l1_mask=None):
     """Render B views in one launch sequence.
 
     means[B,N,3] scales[B,N,3] quats[B,N,4] opacity[B,N] or [B,N,1] colors[B,N,3]  (fp32, GPU)
@@ -437,6 +458,9 @@ def render_views(means, scales, quats, opacity, colors, viewmats, intrins, img_h
     rgca.py:144-145), final_T, radii[B,N] int32, n_isect[B] int32, final_idx[B,H,W], sorted_ids[B,cap], tile_bins[B,T,2]).
     `capacity` given: the caller sized the intersection buffers and checks `n_isect` itself; omitted: planned
     (CapacityPlanner) -- an overflow is repaired inside this call and never surfaces.
+    l1_target[B,3,H,W] (+ l1_mask[B,1|3,H,W]): also returns "l1_loss" = mean(|(render - target) * mask|), the masked
+    L1 of rgb_l1 (ca_code/loss/__init__.py:391-411), computed in the raster epilogue and back-propagated by the raster
+    backward itself (no separate passes over the image; no gradient to target / mask).
     """
     B, N = means.shape[:2]
     dev = means.device
@@ -465,10 +489,20 @@ def render_views(means, scales, quats, opacity, colors, viewmats, intrins, img_h
             planned = PLANNER.get(key)
             deferred = True
         capacity = planned if planned is not None else PLANNER.initial(N, T)
+    if l1_target is not None:
+        l1_target = _f32c(l1_target.detach())
+        if tuple(l1_target.shape) != (B, 3, img_h, img_w):
+            raise ValueError("l1_target must be [B,3,H,W]")
+        if l1_mask is not None:
+            l1_mask = _f32c(l1_mask.detach())
+            if l1_mask.dim() != 4 or l1_mask.shape[0] != B or l1_mask.shape[1] not in (1, 3):
+                raise ValueError("l1_mask must be [B,1,H,W] or [B,3,H,W]")
+    else:
+        l1_mask = None
     out = _RenderViews.apply(means, scales, quats, opacity, colors, viewmats, intrins, background, img_h,
                              img_w, float(glob_scale), float(clip_thresh), bool(with_depth), int(capacity),
-                             float(depth_norm_lo), plan_key)
-    img, alpha, depth, depth_norm, radii, n_isect, final_T, final_idx, sorted_ids, tile_bins = out
+                             float(depth_norm_lo), plan_key, l1_target, l1_mask)
+    img, alpha, depth, depth_norm, l1, radii, n_isect, final_T, final_idx, sorted_ids, tile_bins = out
     if PLANNER.frozen:
         PLANNER.frozen_log.append((n_isect, capacity))
     elif deferred and B > 0:
@@ -479,4 +513,6 @@ def render_views(means, scales, quats, opacity, colors, viewmats, intrins, img_h
     if with_depth:
         res["depth"] = depth[:, None]
         res["depth_norm"] = depth_norm[:, None]  # depth / clamp(alpha.detach(), depth_norm_lo, 1)
+    if l1 is not None:
+        res["l1_loss"] = l1
     return res

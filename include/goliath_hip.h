@@ -127,6 +127,12 @@ int gol_bin_sort(int B, int N, const float* xys, const float* depths, const int3
  *   [rgb 0-2 | opacity 3 | xy 4-5 | conic 6-8 | extra 9 | pad], i.e. v_colors = rec, v_opacity = rec+3, v_xy = rec+4,
  *   v_conic = rec+6, v_extra = rec+9 (checked): the float atomics of a Gaussian then hit one cache line and 16
  *   consecutive lanes issue them together -- the memory-side atomic units see 1/10 of the requests.
+ * Optional fused masked L1 loss (rgb_l1, ca_code/loss/__init__.py:391-411), planar layout only: with l1_target[B,3,H,W]
+ *   (l1_mask[B,l1_mask_c,H,W], l1_mask_c = 1 or 3, or NULL) the forward also writes l1_sign[B,3,H,W] = sign((rgb - target)
+ *   * mask) * mask and l1_partial[B, tiles] = per-tile sums of |(rgb - target) * mask| (tiles = ceil(W/16) * ceil(H/16);
+ *   loss = sum(l1_partial) / (B*3*H*W)).  The backward takes v_img_scale (device scalar, NULL = 1) as a factor on
+ *   v_out_img, so passing v_out_img = l1_sign, v_img_scale = d loss_total / d l1 / (B*3*H*W) back-propagates the loss
+ *   without the two extra passes over the image a separate loss kernel needs.
  * ---------------------------------------------------------------------------------------- */
 #define GOL_GRAD_RECORD 16
 int gol_rasterize_fwd(int B, int N, int img_h, int img_w, int block, int planar, const int32_t* tile_bins,
@@ -134,14 +140,15 @@ int gol_rasterize_fwd(int B, int N, int img_h, int img_w, int block, int planar,
                       const float* conics, const float* colors, const float* extra,
                       const float* opacities, const float* background, float* out_img,
                       float* out_extra, float* final_Ts, int32_t* final_idx, float* out_alpha,
-                      float* out_extra_norm, float norm_lo, void* stream);
+                      float* out_extra_norm, float norm_lo, const float* l1_target, const float* l1_mask, int l1_mask_c,
+                      float* l1_sign, float* l1_partial, void* stream);
 int gol_rasterize_bwd(int B, int N, int img_h, int img_w, int block, int planar, const int32_t* tile_bins,
                       const int32_t* sorted_ids, int64_t capacity, const float* xys,
                       const float* conics, const float* colors, const float* extra,
                       const float* opacities, const float* background, const float* final_Ts,
                       const int32_t* final_idx, const float* v_out_img, const float* v_out_extra,
                       const float* v_out_alpha, float* v_xy, float* v_conic, float* v_colors,
-                      float* v_extra, float* v_opacity, int grad_stride, void* stream);
+                      float* v_extra, float* v_opacity, int grad_stride, const float* v_img_scale, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Fused RGCA shading tail.  Replaces the chain of ATen kernels in PrimDecoder.forward after the

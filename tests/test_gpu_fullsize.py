@@ -50,10 +50,10 @@ def _gpu_step(mb, cfg):
 
     preds = shade.shading_tail(mb["f_vn"], mb["f_vc"], mb["postex"], mb["tn"], mb["albedo"], mb["light_sh"],
                                mb["campos"], preconv_envmap=mb["mips"], lightrot=mb["lightrot"])
-    rgb, alpha, depth = render_gs.render_batch(mb["K"], mb["Rt"], preds, cfg["height"], cfg["width"])
+    rgb, alpha, depth, loss = render_gs.render_batch(mb["K"], mb["Rt"], preds, cfg["height"], cfg["width"],
+                                                     l1_target=mb["target"])  # the fused L1 of bench.step
     for k in STAGE:
         preds[k].retain_grad()
-    loss = losses.l1_image(rgb, mb["target"])
     loss.backward()
     mb["_stage"] = {k: preds[k].grad for k in STAGE}
     # the lists of the same views (diagnostics only: last contributor per pixel)
