@@ -298,42 +298,8 @@ __device__ __forceinline__ void bitonic_sort(KeyPtr keys, int n, int tid, int nt
 // plain LDS network pays on every step.  The first step of every merge is the "flip" (partner = i ^ (k-1)), which
 // keeps all later steps of the merge ascending (no direction flags); in lane/register terms the flip partner is
 // lane ^ (k/KPT - 1), register KPT-1-r.
-// Cross-lane exchange v[lane ^ mask] without the LDS crossbar.  __shfl_xor compiles to ds_bpermute_b32: ~100 cycles of
-// latency per dependent step, and a tile sort is a chain of ~35 of them (PMC: the kernel sat in LDS-issue stalls, VALU 39 %
-// busy).  Every mask the network uses is a DPP pattern or a v_permlane*_swap: a handful of cycles on the vector pipe.
-template <int CTRL, int BANK_MASK = 0xf>
-__device__ __forceinline__ unsigned dpp_mov(unsigned old, unsigned v) {
-  return (unsigned)__builtin_amdgcn_update_dpp((int)old, (int)v, CTRL, 0xf, BANK_MASK, false);
-}
-__device__ __forceinline__ unsigned xor16_32(unsigned v, bool is32, int lane) {
-  if (is32) {
-    const auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false);  // r0 = [lo | lo], r1 = [hi | hi]
-    const unsigned r0 = r[0], r1 = r[1];
-    return lane < 32 ? r1 : r0;
-  }
-  const auto r = __builtin_amdgcn_permlane16_swap(v, v, false, false);    // r0 = rows [0 0 2 2], r1 = rows [1 1 3 3]
-  const unsigned r0 = r[0], r1 = r[1];
-  return (lane & 16) ? r0 : r1;
-}
-__device__ __forceinline__ unsigned xchg32(unsigned v, int mask, int lane) {
-  switch (mask) {  // (the mask is a compile-time constant at every call site: the network loops are fully unrolled)
-    case 1: return dpp_mov<0xB1>(v, v);   // quad_perm [1,0,3,2]
-    case 2: return dpp_mov<0x4E>(v, v);   // quad_perm [2,3,0,1]
-    case 3: return dpp_mov<0x1B>(v, v);   // quad_perm [3,2,1,0]
-    case 4: return dpp_mov<0x114, 0xa>(dpp_mov<0x104, 0x5>(v, v), v);  // banks 0,2 <- lane+4 (row_shl:4); banks 1,3 <- lane-4
-    case 7: return dpp_mov<0x141>(v, v);  // row_half_mirror
-    case 8: return dpp_mov<0x128>(v, v);  // row_ror:8
-    case 15: return dpp_mov<0x140>(v, v);  // row_mirror
-    case 16: return xor16_32(v, false, lane);
-    case 31: return dpp_mov<0x140>(0u, xor16_32(v, false, lane));  // ^16 then ^15
-    case 32: return xor16_32(v, true, lane);
-    case 63: return dpp_mov<0x140>(0u, xor16_32(xor16_32(v, true, lane), false, lane));  // ^32, ^16, ^15
-    default: return __shfl_xor(v, mask, 64);
-  }
-}
 __device__ __forceinline__ uint64_t shfl_xor64(uint64_t v, int mask) {
-  const int lane = threadIdx.x & 63;
-  const unsigned lo = xchg32((unsigned)v, mask, lane), hi = xchg32((unsigned)(v >> 32), mask, lane);
+  const unsigned lo = __shfl_xor((unsigned)v, mask, 64), hi = __shfl_xor((unsigned)(v >> 32), mask, 64);
   return ((uint64_t)hi << 32) | lo;
 }
 __device__ __forceinline__ void cex(uint64_t& a, uint64_t& b) {  // a <= b afterwards
