@@ -6,34 +6,38 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 
-template <int DISTINCT, int STRIDE>
+template <int DISTINCT, int STRIDE, typename T, bool RTN>
 __global__ __launch_bounds__(256) void probe(float* out, int iters) {
-  __shared__ float s[4][1024];
+  __shared__ T s[4][1024];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  for (int i = lane; i < 1024; i += 64) s[wave][i] = 0.f;
+  for (int i = lane; i < 1024; i += 64) s[wave][i] = (T)0;
   __syncthreads();
   // lane -> one of DISTINCT addresses (STRIDE floats apart); 8 independent address sets, one per unrolled instruction
-  float* base = &s[wave][(lane % DISTINCT) * STRIDE];
-  const float v = 1.f + lane;
+  T* base = &s[wave][(lane % DISTINCT) * STRIDE];
+  const T v = (T)(1 + lane);
+  T got = (T)0;
   for (int i = 0; i < iters; ++i) {
 #pragma unroll
-    for (int u = 0; u < 8; ++u) atomicAdd(base + ((u * 37) & 63), v);
+    for (int u = 0; u < 8; ++u) {
+      if (RTN) got += atomicAdd(base + ((u * 37) & 63), v);
+      else atomicAdd(base + ((u * 37) & 63), v);
+    }
   }
   __syncthreads();
-  float acc = 0.f;
+  float acc = (float)got;
   for (int i = lane; i < 1024; i += 64) acc += s[wave][i];
   out[blockIdx.x * 256 + threadIdx.x] = acc;
 }
 
-template <int DISTINCT, int STRIDE>
+template <int DISTINCT, int STRIDE, typename T = float, bool RTN = false>
 static void run(const char* name, float* out) {
   const int iters = 2000, blocks = 256 * 4;  // 4 workgroups of 4 waves per CU -> 4 waves per SIMD
   hipEvent_t e0, e1;
   hipEventCreate(&e0); hipEventCreate(&e1);
-  probe<DISTINCT, STRIDE><<<blocks, 256>>>(out, 10);
+  probe<DISTINCT, STRIDE, T, RTN><<<blocks, 256>>>(out, 10);
   hipDeviceSynchronize();
   hipEventRecord(e0);
-  probe<DISTINCT, STRIDE><<<blocks, 256>>>(out, iters);
+  probe<DISTINCT, STRIDE, T, RTN><<<blocks, 256>>>(out, iters);
   hipEventRecord(e1);
   hipEventSynchronize(e1);
   float ms = 0.f;
@@ -54,6 +58,13 @@ int main() {
   run<16, 4>("ds_add_f32  16 distinct, stride 4 floats", out);
   run<4, 4>("ds_add_f32   4 distinct, stride 4 floats", out);
   run<16, 32>("ds_add_f32  16 distinct, same bank", out);
+  run<64, 1, int>("ds_add_u32  64 distinct", out);
+  run<16, 1, int>("ds_add_u32  16 distinct (4 lanes each)", out);
+  run<1, 1, int>("ds_add_u32   1 address", out);
+  run<64, 1, int, true>("ds_add_rtn_u32  64 distinct", out);
+  run<16, 1, int, true>("ds_add_rtn_u32  16 distinct (4 lanes each)", out);
+  run<1, 1, int, true>("ds_add_rtn_u32   1 address", out);
+  run<16, 1, float, true>("ds_add_rtn_f32  16 distinct (4 lanes each)", out);
   hipFree(out);
   return 0;
 }
