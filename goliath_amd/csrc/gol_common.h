@@ -82,6 +82,9 @@ __device__ __forceinline__ float gol_wave_sum4(float a, float b, float c, float 
   return gol_row_sum_to_lane15(q);
 }
 
+// lane mask of a predicate as a scalar (s_and with exec); HIP's __ballot(int) goes through an int (v_cndmask + v_cmp_ne)
+__device__ __forceinline__ unsigned long long gol_ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+
 // returns the wave-wide sum in lane 63 (other lanes hold partial sums)
 __device__ __forceinline__ float gol_wave_sum_to_lane63(float v) {
   v += gol_dpp_mov0<0x111>(v);              // row_shr:1

@@ -214,14 +214,14 @@ __device__ __forceinline__ int build_hits(int K, const float* __restrict__ nodea
       float a, b;
       const bool hit = ray.live && box_hit(primpos, primrot, primscale, k, ray.pos, ray.dir, a, b);
       if (hit) { rt0 = fminf(rt0, a); rt1 = fmaxf(rt1, b); }
-      if (__ballot(hit) != 0ull && num < kMaxHits) {
+      if (gol_ballot(hit) != 0ull && num < kMaxHits) {
         if ((threadIdx.x & 63) == 0) s_list[num] = k;
         ++num;
       }
       node = heap_next(node);
     } else {
       const bool hit = ray.live && aabb_hit(nodeaabb + (size_t)node * 6, ray.pos, ird);
-      node = (__ballot(hit) != 0ull) ? 2 * node + 1 : heap_next(node);
+      node = (gol_ballot(hit) != 0ull) ? 2 * node + 1 : heap_next(node);
     }
   }
   __builtin_amdgcn_wave_barrier();  // list written by lane 0, read by the whole wave below
@@ -326,13 +326,13 @@ __global__ __launch_bounds__(256) void march_fwd_kernel(MarchArgs a, float* __re
   bool sat = false;
   int iter = 0;
   // !__all(t > rt1 + 1e-5 || done)   (subset_kernel.h:81)
-  while (__ballot(ray.live && !(ray.t > ray.rt1 + 1e-5f || sat)) != 0ull) {
+  while (gol_ballot(ray.live && !(ray.t > ray.rt1 + 1e-5f || sat)) != 0ull) {
     // the boxes whose window contains this iteration, 64 list entries per ballot (lane j tests entry base + j), then a
     // scalar walk over the set bits in list order: the per-step cost follows the 2-3 boxes the wave is inside, not the
     // length of the hit list
     for (int base = 0; base < num; base += 64) {
     const int s_me = base + lane;
-    unsigned long long active = __ballot(s_me < num && s_lo[wave][s_me] <= iter && iter <= s_hi[wave][s_me]);
+    unsigned long long active = gol_ballot(s_me < num && s_lo[wave][s_me] <= iter && iter <= s_hi[wave][s_me]);
     while (active) {
       const int s = base + __builtin_ctzll(active);
       active &= active - 1;
@@ -386,12 +386,12 @@ __global__ __launch_bounds__(256) void march_fwd_kernel(MarchArgs a, float* __re
         // the backward: group the wave's lanes by voxel cell, reduce each group, and let lanes 15|31 (corner c) and 47|63
         // (corner c+1) issue ONE pair of atomics per (cell, corner) -- memory-side float atomics per lane are the cost.
         float* sp = shadow_n + (size_t)k * vox * 2;
-        unsigned long long todo = __ballot(ev);
+        unsigned long long todo = gol_ballot(ev);
         while (todo) {
           const int leader = __builtin_ctzll(todo);
           const int key = __builtin_amdgcn_readlane(sh_key, leader);
           const bool mine = ev && (sh_key == key);
-          todo &= ~__ballot(mine);
+          todo &= ~gol_ballot(mine);
 #pragma unroll
           for (int c = 0; c < 8; c += 2) {
             const int i0 = __builtin_amdgcn_readlane(sh_idx[c], leader), i1 = __builtin_amdgcn_readlane(sh_idx[c + 1], leader);
@@ -453,10 +453,10 @@ __global__ __launch_bounds__(256) void march_bwd_kernel(MarchArgs a, const float
   bool sat = false;
   int iter = 0;
   const float fe = a.fadeexp, fs = a.fadescale;
-  while (__ballot(ray.live && ray.t < ray.rt1 + 1e-5f && !sat) != 0ull) {
+  while (gol_ballot(ray.live && ray.t < ray.rt1 + 1e-5f && !sat) != 0ull) {
     for (int base = 0; base < num; base += 64) {  // (see the forward kernel)
     const int s_me = base + lane;
-    unsigned long long active = __ballot(s_me < num && s_lo[wave][s_me] <= iter && iter <= s_hi[wave][s_me]);
+    unsigned long long active = gol_ballot(s_me < num && s_lo[wave][s_me] <= iter && iter <= s_hi[wave][s_me]);
     while (active) {
       const int s = base + __builtin_ctzll(active);
       active &= active - 1;
@@ -464,7 +464,7 @@ __global__ __launch_bounds__(256) void march_bwd_kernel(MarchArgs a, const float
       Xform xf;
       const V3 y0 = xform_fwd(xf, primpos, primrot, primscale, k, ray.pos);
       const bool ev = ray.live && valid_pos(y0) && !sat && ray.t < ray.rt1 + 1e-5f;
-      if (__ballot(ev) == 0ull) continue;
+      if (gol_ballot(ev) == 0ull) continue;
       V3 dLy = v3(0.f, 0.f, 0.f);
       float sd0 = 0.f, sd1 = 0.f, sd2 = 0.f, sd3 = 0.f, cw[8];
       int cidx[8], cellkey = -1;
@@ -524,12 +524,12 @@ __global__ __launch_bounds__(256) void march_bwd_kernel(MarchArgs a, const float
       // instead of one per lane (mvpraymarch utils.h:83-113 issues one per lane).
       {
         float* gt = g_tplate + (size_t)k * vox * 4;
-        unsigned long long todo = __ballot(ev);
+        unsigned long long todo = gol_ballot(ev);
         while (todo) {
           const int leader = __builtin_ctzll(todo);
           const int key = __builtin_amdgcn_readlane(cellkey, leader);
           const bool mine = ev && (cellkey == key);
-          const unsigned long long grp = __ballot(mine);
+          const unsigned long long grp = gol_ballot(mine);
           todo &= ~grp;
           // always reduce (even a one-lane group): memory-side atomics, not instructions, are the cost.  The two
           // x-neighbour corners of a pair are adjacent 16-byte voxel records, so lanes 14|15 of every DPP row issue them

@@ -140,9 +140,9 @@ __global__ __launch_bounds__(128) void raster_fwd_kernel(
     // Each wave walks ONLY the entries whose alpha >= 1/255 region touches its half: one ballot per
     // 64 entries, then a scalar loop over the set bits (s_ff1) -- culled entries cost nothing.
     for (int chunk = 0; chunk < batch_size; chunk += 64) {
-      unsigned long long bits = __ballot((s_mask[chunk + lane] >> wave) & 1);
+      unsigned long long bits = gol_ballot((s_mask[chunk + lane] >> wave) & 1);
       while (bits) {
-        if (__ballot((__float_as_uint(live.x) | __float_as_uint(live.y)) != 0u) == 0ull) { chunk = batch_size; break; }  // this wave's half is finished
+        if (gol_ballot((__float_as_uint(live.x) | __float_as_uint(live.y)) != 0u) == 0ull) { chunk = batch_size; break; }  // this wave's half is finished
         const int t = chunk + __builtin_ctzll(bits);
         bits &= bits - 1;
         const float4 a4 = s_a[t];
@@ -156,12 +156,16 @@ __global__ __launch_bounds__(128) void raster_fwd_kernel(
         alpha.x = fminf(GOL_ALPHA_CAP_FWD, b4.y * __builtin_amdgcn_exp2f(-sigma.x));
         alpha.y = fminf(GOL_ALPHA_CAP_FWD, b4.y * __builtin_amdgcn_exp2f(-sigma.y));
         alpha *= live;
-        const bool c0 = !(sigma.x < 0.f || alpha.x < GOL_ALPHA_FLOOR);
-        const bool c1 = !(sigma.y < 0.f || alpha.y < GOL_ALPHA_FLOOR);
+        // contributes: !(sigma < 0 || alpha < 1/255), as scalar lane masks (ballots of the plain compares)
+        const unsigned long long mc0 = gol_ballot(!(sigma.x < 0.f)) & gol_ballot(!(alpha.x < GOL_ALPHA_FLOOR));
+        const unsigned long long mc1 = gol_ballot(!(sigma.y < 0.f)) & gol_ballot(!(alpha.y < GOL_ALPHA_FLOOR));
         f2 vis = alpha * T_cur;
         const f2 next_T = T_cur - vis;  // = T (1 - alpha)
-        const bool stop0 = c0 && (next_T.x <= GOL_T_STOP), stop1 = c1 && (next_T.y <= GOL_T_STOP);
-        const bool take0 = c0 && !stop0, take1 = c1 && !stop1;
+        // stop / take as scalar lane-mask algebra: one compare per pixel (written with bools the compiler issues a second,
+        // NaN-aware compare for the negation)
+        const unsigned long long ms0 = gol_ballot(next_T.x <= GOL_T_STOP), ms1 = gol_ballot(next_T.y <= GOL_T_STOP);
+        const bool stop0 = __builtin_amdgcn_inverse_ballot_w64(mc0 & ms0), stop1 = __builtin_amdgcn_inverse_ballot_w64(mc1 & ms1);
+        const bool take0 = __builtin_amdgcn_inverse_ballot_w64(mc0 & ~ms0), take1 = __builtin_amdgcn_inverse_ballot_w64(mc1 & ~ms1);
         live.x = stop0 ? 0.f : live.x; live.y = stop1 ? 0.f : live.y;
         vis.x = take0 ? vis.x : 0.f; vis.y = take1 ? vis.y : 0.f;
         acc0 += b4.z * vis; acc1 += b4.w * vis; acc2 += c2.x * vis;
@@ -321,7 +325,7 @@ __global__ __launch_bounds__(128) void raster_bwd_kernel(
     __syncthreads();
 
     const int t0 = max(0, batch_end - wmax);
-    unsigned long long bits = __ballot((s_mask[lane] >> wave) & 1);  // kBatchB == 64: one chunk
+    unsigned long long bits = gol_ballot((s_mask[lane] >> wave) & 1);  // kBatchB == 64: one chunk
     if (t0 > 0) bits &= ~0ull << t0;
     while (bits) {
       const int t = __builtin_ctzll(bits);
@@ -337,9 +341,12 @@ __global__ __launch_bounds__(128) void raster_bwd_kernel(
       vis.x = __builtin_amdgcn_exp2f(-sigma.x); vis.y = __builtin_amdgcn_exp2f(-sigma.y);  // sigma = log2e * gsplat's
       f2 alpha = b4.y * vis;
       alpha.x = fminf(GOL_ALPHA_CAP_BWD, alpha.x); alpha.y = fminf(GOL_ALPHA_CAP_BWD, alpha.y);
-      const bool v0 = (li <= bin_final.x) && !(sigma.x < 0.f || alpha.x < GOL_ALPHA_FLOOR);
-      const bool v1 = (li <= bin_final.y) && !(sigma.y < 0.f || alpha.y < GOL_ALPHA_FLOOR);
-      if (__ballot(v0 || v1) == 0ull) continue;
+      // taken by the pixel: within its list && !(sigma < 0 || alpha < 1/255) -- as scalar lane masks (ballots of the plain
+      // compares; the ballot of a combined bool costs a v_cndmask + v_cmp)
+      const unsigned long long mv0 = gol_ballot(li <= bin_final.x) & gol_ballot(!(sigma.x < 0.f)) & gol_ballot(!(alpha.x < GOL_ALPHA_FLOOR));
+      const unsigned long long mv1 = gol_ballot(li <= bin_final.y) & gol_ballot(!(sigma.y < 0.f)) & gol_ballot(!(alpha.y < GOL_ALPHA_FLOOR));
+      if ((mv0 | mv1) == 0ull) continue;
+      const bool v0 = __builtin_amdgcn_inverse_ballot_w64(mv0), v1 = __builtin_amdgcn_inverse_ballot_w64(mv1);
       // an entry the pixel did not take enters with alpha = 0: 1 / (1 - 0) = 1 exactly, so T and the running sums pass
       // through unchanged without further selects
       alpha.x = v0 ? alpha.x : 0.f; alpha.y = v1 ? alpha.y : 0.f;
