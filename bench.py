@@ -153,8 +153,9 @@ def algorithmic_bytes(name, N, I, P, n_mips_bytes):
         "gol_project_bwd": (44 + 24 + 16 + 4 + 4) * N + 36 * N + 44 * N,
         "gol_bin_sort": 16 * N + 8 * I + 8 * I + 4 * I,
         # rgb 12 + depth 4 + T 4 + idx 4 + alpha 4 + depth_norm 4 out; fused L1: target 12 in, sign image 12 out
-        "gol_rasterize_fwd": 4 * I + 44 * I + 32 * P + 24 * P,
-        "gol_rasterize_bwd": 4 * I + 44 * I + 20 * P + 36 * N,
+        # per pixel: final_T, final_idx, rgb, alpha, depth_norm written (28 B) + fused L1: target read, sign byte written
+        "gol_rasterize_fwd": 4 * I + 44 * I + 28 * P + 13 * P,
+        "gol_rasterize_bwd": 4 * I + 44 * I + 9 * P + 36 * N,   # per pixel: final_T, final_idx, sign byte
         "gol_l1_fwd": 24 * P,           # rendered + target image
         "gol_l1_bwd": 24 * P + 12 * P,  # ... and the image gradient
     }[name]

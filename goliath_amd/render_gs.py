@@ -40,7 +40,8 @@ def render_batch(K: th.Tensor, Rt: th.Tensor, preds: Dict[str, Any], height: int
     (rgb_l1, ca_code/loss/__init__.py:391-411), fused into the raster passes."""
     intr = th.stack([K[:, 0, 0], K[:, 1, 1], K[:, 0, 2], K[:, 1, 2]], dim=-1)
     out = render_views(preds["primpos"], preds["primscale"], preds["primqvec"], preds["opacity"],
-                       preds["color"], Rt, intr, height, width, with_depth=True, l1_target=l1_target, l1_mask=l1_mask)
+                       preds["color"], Rt, intr, height, width, with_depth=True, l1_target=l1_target, l1_mask=l1_mask,
+                       raw_depth=False)  # only depth / alpha.clamp(0.05, 1) leaves AutoEncoder.render
     # alpha = 1 - T.detach() and depth / alpha.clamp(0.05, 1) are written by the raster kernel's epilogue
     if l1_target is not None:
         return out["render"], out["alpha"].detach(), out["depth_norm"], out["l1_loss"]

@@ -295,8 +295,8 @@ class _RasterizeGaussians(torch.autograd.Function):
                           iptr(ws.tile_bins), iptr(ws.sorted_ids), c_i64(ws.capacity), fptr(xys), fptr(conics),
                           fptr(colors), fptr(None), fptr(opacity), fptr(background), fptr(final_Ts),
                           iptr(final_idx), fptr(vo), fptr(None), fptr(va), fptr(v_xy),
-                          fptr(v_conic), fptr(v_colors), fptr(None), fptr(v_opacity), c_int(0), fptr(None),
-                          stream_ptr())
+                          fptr(v_conic), fptr(v_colors), fptr(None), fptr(v_opacity), c_int(0), fptr(None), fptr(None),
+                          c_int(0), fptr(None), stream_ptr())
             ctx.ws = None
         return (v_xy, None, None, v_conic, None, v_colors, v_opacity[:, None]) + (None,) * 5
 
@@ -334,7 +334,8 @@ def rasterize_gaussians(xys, depths, radii, conics, num_tiles_hit, colors, opaci
 class _RenderViews(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means, scales, quats, opacity, colors, viewmats, intrins, background, img_h, img_w,
-                glob_scale, clip_thresh, with_depth, capacity, depth_norm_lo, plan_key, l1_target, l1_mask):
+                glob_scale, clip_thresh, with_depth, capacity, depth_norm_lo, plan_key, l1_target, l1_mask,
+                raw_depth=True):
         B, N = means.shape[:2]
         dev = means.device
         T = _tiles(img_h, img_w)
@@ -343,14 +344,15 @@ class _RenderViews(torch.autograd.Function):
                 B, N, means, scales, glob_scale, quats, viewmats, intrins, img_h, img_w, clip_thresh,
                 opacities=opacity)
             out_img = torch.empty(B, 3, img_h, img_w, device=dev)  # planar, as the model consumes it
-            out_depth = torch.empty(B, img_h, img_w, device=dev) if with_depth else None
+            out_depth = torch.empty(B, img_h, img_w, device=dev) if with_depth and raw_depth else None
             final_Ts = torch.empty(B, img_h, img_w, device=dev)
             final_idx = torch.empty(B, img_h, img_w, dtype=torch.int32, device=dev)
             # alpha = 1 - T and depth / clamp(alpha, lo, 1) come out of the raster epilogue (rgca.py:137,144-145)
             alpha = torch.empty(B, img_h, img_w, device=dev)
             depth_norm = torch.empty(B, img_h, img_w, device=dev) if with_depth else None
-            # optional fused L1 against a target image: sign image (the loss gradient up to a scalar) + per-tile sums
-            l1_sign = torch.empty(B, 3, img_h, img_w, device=dev) if l1_target is not None else None
+            # optional fused L1 against a target image: sign codes (the loss gradient up to mask x scalar; one byte per
+            # pixel) + per-tile sums
+            l1_sign = torch.empty(B, img_h, img_w, dtype=torch.uint8, device=dev) if l1_target is not None else None
             l1_partial = torch.empty(B, T, device=dev) if l1_target is not None else None
             l1_mask_c = 0 if l1_mask is None else l1_mask.shape[1]
 
@@ -363,7 +365,7 @@ class _RenderViews(torch.autograd.Function):
                           fptr(colors), fptr(depths if with_depth else None), fptr(opac_eff), fptr(background),
                           fptr(out_img), fptr(out_depth), fptr(final_Ts), iptr(final_idx), fptr(alpha),
                           fptr(depth_norm), c_float(depth_norm_lo), fptr(l1_target), fptr(l1_mask), c_int(l1_mask_c),
-                          fptr(l1_sign), fptr(l1_partial), stream_ptr())
+                          ptr(l1_sign, torch.uint8), fptr(l1_partial), stream_ptr())
                 return ws, pending
 
             ws, pending = bin_and_raster(capacity)
@@ -384,7 +386,7 @@ class _RenderViews(torch.autograd.Function):
         ctx.l1_inv_n = 1.0 / max(B * 3 * img_h * img_w, 1)
         l1 = l1_partial.sum() * ctx.l1_inv_n if l1_target is not None else None  # == mean(|(rgb - target) * mask|)
         ctx.save_for_backward(means, scales, quats, opacity, colors, viewmats, intrins, background, cov3d, xys,
-                              depths, radii, conics, comp, opac_eff, final_Ts, final_idx, l1_sign)
+                              depths, radii, conics, comp, opac_eff, final_Ts, final_idx, l1_sign, l1_mask)
         ctx.mark_non_differentiable(radii, ws.n_isect, final_Ts, final_idx, ws.sorted_ids, ws.tile_bins)
         ctx.set_materialize_grads(False)
         return (out_img, alpha, out_depth, depth_norm, l1, radii, ws.n_isect, final_Ts, final_idx, ws.sorted_ids,
@@ -393,7 +395,7 @@ class _RenderViews(torch.autograd.Function):
     @staticmethod
     def backward(ctx, v_img, v_alpha, v_depth, v_depth_norm, v_l1, *_non_differentiable):
         (means, scales, quats, opacity, colors, viewmats, intrins, background, cov3d, xys, depths, radii,
-         conics, comp, opac_eff, final_Ts, final_idx, l1_sign) = ctx.saved_tensors
+         conics, comp, opac_eff, final_Ts, final_idx, l1_sign, l1_mask) = ctx.saved_tensors
         img_h, img_w, glob_scale, with_depth, depth_norm_lo = ctx.cfg
         B, N = means.shape[:2]
         dev = means.device
@@ -405,21 +407,19 @@ class _RenderViews(torch.autograd.Function):
             v_l1 = None
         if v_img is None and v_alpha is None and v_depth is None and v_l1 is None:
             ctx.ws = None
-            return (None,) * 18
-        # fused L1: d loss / d rgb = l1_sign * (v_l1 / n).  When the image has no other consumer the sign image goes to
-        # the raster backward as it is, with the scalar as v_img_scale (a device scalar: no sync, no pass over the image)
-        v_scale = None
+            return (None,) * 19
+        # fused L1: d loss / d rgb = (sign code - 1) * mask * (v_l1 / n).  The raster backward decodes the sign bytes itself
+        # and adds the term to v_img (if the image has another consumer); the scalar goes in as a device value: no sync,
+        # no pass over the image
+        v_scale, v_sign, v_sign_mask = None, None, None
         if v_l1 is not None:
             v_scale = (v_l1.to(torch.float32) * ctx.l1_inv_n).reshape(1).contiguous()
-            if v_img is None:
-                v_img = l1_sign
-            else:
-                v_img, v_scale = torch.addcmul(_f32c(v_img), l1_sign, v_scale), None
-        if v_img is None:
+            v_sign, v_sign_mask = l1_sign, l1_mask
+        if v_img is None and v_sign is None:
             v_img = torch.zeros(B, 3, img_h, img_w, device=dev)
         use_depth = with_depth and v_depth is not None
         # converted upstream gradients stay bound to locals until the launches below are issued
-        v_img_c = _f32c(v_img)
+        v_img_c = None if v_img is None else _f32c(v_img)
         v_depth_c = _f32c(v_depth) if use_depth else None
         v_alpha_c = None if v_alpha is None else _f32c(v_alpha)
         # one zeroed buffer of 64-byte gradient records per Gaussian (include/goliath_hip.h: GOL_GRAD_RECORD):
@@ -436,19 +436,21 @@ class _RenderViews(torch.autograd.Function):
                       fptr(colors), fptr(depths if use_depth else None), fptr(opac_eff), fptr(background),
                       fptr(final_Ts), iptr(final_idx), fptr(v_img_c), fptr(v_depth_c), fptr(v_alpha_c),
                       field(4), field(6), field(0),
-                      field(9) if use_depth else fptr(None), field(3), c_int(GRAD_RECORD), fptr(v_scale), stream_ptr())
+                      field(9) if use_depth else fptr(None), field(3), c_int(GRAD_RECORD), ptr(v_sign, torch.uint8),
+                      fptr(v_sign_mask), c_int(0 if v_sign_mask is None else v_sign_mask.shape[1]), fptr(v_scale),
+                      stream_ptr())
             _lib.call("gol_project_bwd", c_int(B), c_int(N), fptr(means), fptr(scales), c_float(glob_scale),
                       fptr(quats), fptr(viewmats), fptr(intrins), fptr(cov3d), iptr(radii), fptr(conics),
                       fptr(comp), field(4), field(9) if use_depth else fptr(None), field(6), fptr(None), fptr(opacity),
                       field(3), c_int(GRAD_RECORD), fptr(v_mean), fptr(v_scale_g), fptr(v_quat), fptr(v_opacity),
                       stream_ptr())
         ctx.ws = None  # the tile lists (the largest buffers of a step) go back to the allocator now
-        return (v_mean, v_scale_g, v_quat, v_opacity, rec[..., :3]) + (None,) * 13
+        return (v_mean, v_scale_g, v_quat, v_opacity, rec[..., :3]) + (None,) * 14
 
 
 def render_views(means, scales, quats, opacity, colors, viewmats, intrins, img_h, img_w,
                  background=None, glob_scale=1.0, clip_thresh=0.1, with_depth=True, capacity=None, depth_norm_lo=0.05,
-                 l1_target=None, l1_mask=None):
+                 l1_target=None, l1_mask=None, raw_depth=True):
     """Render B views in one launch sequence.
 
     means[B,N,3] scales[B,N,3] quats[B,N,4] opacity[B,N] or [B,N,1] colors[B,N,3]  (fp32, GPU)
@@ -461,6 +463,8 @@ def render_views(means, scales, quats, opacity, colors, viewmats, intrins, img_h
     l1_target[B,3,H,W] (+ l1_mask[B,1|3,H,W]): also returns "l1_loss" = mean(|(render - target) * mask|), the masked
     L1 of rgb_l1 (ca_code/loss/__init__.py:391-411), computed in the raster epilogue and back-propagated by the raster
     backward itself (no separate passes over the image; no gradient to target / mask).
+    raw_depth=False: only depth_norm is produced (what AutoEncoder.render returns, rgca.py:144-145) -- the forward
+    writes one image less; "depth" is then absent from the result.
     """
     B, N = means.shape[:2]
     dev = means.device
@@ -501,7 +505,7 @@ def render_views(means, scales, quats, opacity, colors, viewmats, intrins, img_h
         l1_mask = None
     out = _RenderViews.apply(means, scales, quats, opacity, colors, viewmats, intrins, background, img_h,
                              img_w, float(glob_scale), float(clip_thresh), bool(with_depth), int(capacity),
-                             float(depth_norm_lo), plan_key, l1_target, l1_mask)
+                             float(depth_norm_lo), plan_key, l1_target, l1_mask, bool(raw_depth))
     img, alpha, depth, depth_norm, l1, radii, n_isect, final_T, final_idx, sorted_ids, tile_bins = out
     if PLANNER.frozen:
         PLANNER.frozen_log.append((n_isect, capacity))
@@ -511,7 +515,8 @@ def render_views(means, scales, quats, opacity, colors, viewmats, intrins, img_h
            # per-pixel index of the last contributor in its view's depth-sorted list, and that list (diagnostics)
            "final_idx": final_idx, "sorted_ids": sorted_ids, "tile_bins": tile_bins}
     if with_depth:
-        res["depth"] = depth[:, None]
+        if depth is not None:
+            res["depth"] = depth[:, None]
         res["depth_norm"] = depth_norm[:, None]  # depth / clamp(alpha.detach(), depth_norm_lo, 1)
     if l1 is not None:
         res["l1_loss"] = l1

@@ -119,7 +119,8 @@ int gol_bin_sort(int B, int N, const float* xys, const float* depths, const int3
  *   background[3]; out_extra[B,H,W]; final_Ts[B,H,W]; final_idx[B,H,W] int32
  *   (index into the view's sorted_ids segment of the last contributing Gaussian, 0 if none).
  * fwd optional fused epilogue of AutoEncoder.render (rgca.py:137,144-145), NULL = off: out_alpha[B,H,W] = 1 - final_T and
- *   out_extra_norm[B,H,W] = out_extra / clamp(1 - final_T, norm_lo, 1)  (the reference divides depth by alpha.clamp(0.05, 1)).
+ *   out_extra_norm[B,H,W] = extra image / clamp(1 - final_T, norm_lo, 1)  (the reference divides depth by alpha.clamp(0.05, 1));
+ *   with out_extra_norm given, out_extra (the un-normalised image) may be NULL -- one image write less.
  * bwd ACCUMULATES into v_xy[B,N,2] v_conic[B,N,3] v_colors[B,N,3] v_opacity[B,N]
  * (and v_extra[B,N]) which the caller zeroes; v_out_alpha / v_out_extra may be NULL.
  * grad_stride = 0: the five gradient outputs are dense arrays (gsplat's layout);
@@ -128,11 +129,13 @@ int gol_bin_sort(int B, int N, const float* xys, const float* depths, const int3
  *   v_conic = rec+6, v_extra = rec+9 (checked): the float atomics of a Gaussian then hit one cache line and 16
  *   consecutive lanes issue them together -- the memory-side atomic units see 1/10 of the requests.
  * Optional fused masked L1 loss (rgb_l1, ca_code/loss/__init__.py:391-411), planar layout only: with l1_target[B,3,H,W]
- *   (l1_mask[B,l1_mask_c,H,W], l1_mask_c = 1 or 3, or NULL) the forward also writes l1_sign[B,3,H,W] = sign((rgb - target)
- *   * mask) * mask and l1_partial[B, tiles] = per-tile sums of |(rgb - target) * mask| (tiles = ceil(W/16) * ceil(H/16);
- *   loss = sum(l1_partial) / (B*3*H*W)).  The backward takes v_img_scale (device scalar, NULL = 1) as a factor on
- *   v_out_img, so passing v_out_img = l1_sign, v_img_scale = d loss_total / d l1 / (B*3*H*W) back-propagates the loss
- *   without the two extra passes over the image a separate loss kernel needs.
+ *   (l1_mask[B,l1_mask_c,H,W], l1_mask_c = 1 or 3, or NULL) the forward also writes l1_sign[B,H,W], ONE BYTE per pixel
+ *   holding sign((rgb_c - target_c) * mask_c) + 1 of channel c in bits 2c..2c+1, and l1_partial[B, tiles] = per-tile sums
+ *   of |(rgb - target) * mask| (tiles = ceil(W/16) * ceil(H/16); loss = sum(l1_partial) / (B*3*H*W)).
+ *   The backward's upstream image gradient is  v_out_img (NULL = 0)  +  (code_c - 1) * mask_c * v_img_scale[0]  of
+ *   v_sign[B,H,W] (NULL = none; v_sign_mask[B,v_sign_mask_c,H,W] or NULL = 1; v_img_scale device scalar, NULL = 1), so
+ *   passing v_sign = l1_sign, v_sign_mask = l1_mask, v_img_scale = d loss_total / d l1 / (B*3*H*W) back-propagates the
+ *   loss without the two extra passes over the image a separate loss kernel needs; at least one of v_out_img / v_sign.
  * ---------------------------------------------------------------------------------------- */
 #define GOL_GRAD_RECORD 16
 int gol_rasterize_fwd(int B, int N, int img_h, int img_w, int block, int planar, const int32_t* tile_bins,
@@ -141,14 +144,15 @@ int gol_rasterize_fwd(int B, int N, int img_h, int img_w, int block, int planar,
                       const float* opacities, const float* background, float* out_img,
                       float* out_extra, float* final_Ts, int32_t* final_idx, float* out_alpha,
                       float* out_extra_norm, float norm_lo, const float* l1_target, const float* l1_mask, int l1_mask_c,
-                      float* l1_sign, float* l1_partial, void* stream);
+                      uint8_t* l1_sign, float* l1_partial, void* stream);
 int gol_rasterize_bwd(int B, int N, int img_h, int img_w, int block, int planar, const int32_t* tile_bins,
                       const int32_t* sorted_ids, int64_t capacity, const float* xys,
                       const float* conics, const float* colors, const float* extra,
                       const float* opacities, const float* background, const float* final_Ts,
                       const int32_t* final_idx, const float* v_out_img, const float* v_out_extra,
                       const float* v_out_alpha, float* v_xy, float* v_conic, float* v_colors,
-                      float* v_extra, float* v_opacity, int grad_stride, const float* v_img_scale, void* stream);
+                      float* v_extra, float* v_opacity, int grad_stride, const uint8_t* v_sign, const float* v_sign_mask,
+                      int v_sign_mask_c, const float* v_img_scale, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Fused RGCA shading tail.  Replaces the chain of ATen kernels in PrimDecoder.forward after the
