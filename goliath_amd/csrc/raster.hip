@@ -24,6 +24,12 @@
 
 namespace {
 
+// element at a 32-bit BYTE offset from a (wave-uniform) base pointer: the SGPR-base + VGPR-offset addressing form
+template <typename T>
+__device__ __forceinline__ T* gol_at(T* base, unsigned byte_off) {
+  return reinterpret_cast<T*>(reinterpret_cast<char*>(const_cast<typename std::remove_const<T>::type*>(base)) + byte_off);
+}
+
 constexpr int kBatch = 256;
 // conics are staged in LDS pre-multiplied by log2(e) -- alpha = opacity * 2^(-sigma') is one v_exp_f32 with a negated
 // operand instead of a multiply + exp per pixel -- and the diagonal terms by the 1/2 of sigma = (a dx^2 + c dy^2) / 2 +
@@ -176,44 +182,60 @@ __global__ __launch_bounds__(128) void raster_fwd_kernel(
     }
   }
 
-  // planar: [B,3,H,W] (what the model consumes, rgca.py:139); else gsplat's [B,H,W,3]
-  const size_t hw = (size_t)img_h * img_w;
-  const size_t os = planar ? hw : 1;
+  // planar: [B,3,H,W] (what the model consumes, rgca.py:139); else gsplat's [B,H,W,3].
+  // Addressing: wave-uniform per-view base pointers (scalar registers) + one 32-bit pixel offset per lane, so every
+  // access is the SGPR-base + VGPR-offset form -- the epilogue runs for ALL tiles (71 % of them empty at the benchmarked
+  // views) and 64-bit per-lane address arithmetic was a visible share of the kernel's vector instructions.
+  const unsigned hw = (unsigned)img_h * (unsigned)img_w;
+  const size_t vplane = (size_t)view * hw;
+  float* __restrict__ o_T = final_Ts + vplane;
+  int32_t* __restrict__ o_idx = final_idx + vplane;
+  float* __restrict__ o_img = out_img + 3 * vplane;
+  float* __restrict__ o_ex = (EXTRA && out_extra) ? out_extra + vplane : nullptr;
+  float* __restrict__ o_alpha = out_alpha ? out_alpha + vplane : nullptr;
+  float* __restrict__ o_norm = (EXTRA && out_extra_norm) ? out_extra_norm + vplane : nullptr;
+  const float* __restrict__ i_tgt = l1_target ? l1_target + 3 * vplane : nullptr;
+  const float* __restrict__ i_mask = l1_mask ? l1_mask + (size_t)l1_mask_c * vplane : nullptr;
+  uint8_t* __restrict__ o_sign = l1_target ? l1_sign + vplane : nullptr;
+  const float bg0 = background[0], bg1 = background[1], bg2 = background[2];
+  // channel planes as separate uniform bases (non-planar: element 3 * pix + c)
+  float* __restrict__ o_img1 = o_img + (planar ? hw : 1u);
+  float* __restrict__ o_img2 = o_img + (planar ? 2u * hw : 2u);
   float l1_acc = 0.f;
 #pragma unroll
   for (int q = 0; q < 2; ++q) {
     const bool in = q ? in1 : in0;
     if (!in) continue;
-    const int i = i0 + q;
+    const unsigned pix = (unsigned)(i0 + q) * (unsigned)img_w + (unsigned)j;
+    const unsigned b4 = pix * 4u;                  // byte offset inside a one-channel plane (checked < 4 GiB on the host)
+    const unsigned bimg = planar ? b4 : 3u * b4;
     const float Tq = q ? T_cur.y : T_cur.x;
-    const float c0 = (q ? acc0.y : acc0.x) + Tq * background[0], c1 = (q ? acc1.y : acc1.x) + Tq * background[1],
-                c2 = (q ? acc2.y : acc2.x) + Tq * background[2], ex = q ? acc3.y : acc3.x;
-    const size_t p = ((size_t)view * img_h + i) * img_w + j;
-    final_Ts[p] = Tq;
-    final_idx[p] = q ? cur_idx.y : cur_idx.x;
-    const size_t o0 = planar ? (size_t)view * 3 * hw + (size_t)i * img_w + j : 3 * p;
-    out_img[o0] = c0; out_img[o0 + os] = c1; out_img[o0 + 2 * os] = c2;
-    if (EXTRA && out_extra) out_extra[p] = ex;
+    const float c0 = (q ? acc0.y : acc0.x) + Tq * bg0, c1 = (q ? acc1.y : acc1.x) + Tq * bg1,
+                c2 = (q ? acc2.y : acc2.x) + Tq * bg2, ex = q ? acc3.y : acc3.x;
+    *gol_at(o_T, b4) = Tq;
+    *gol_at(o_idx, b4) = q ? cur_idx.y : cur_idx.x;
+    *gol_at(o_img, bimg) = c0; *gol_at(o_img1, bimg) = c1; *gol_at(o_img2, bimg) = c2;
+    if (o_ex) *gol_at(o_ex, b4) = ex;
     // optional fused epilogue of AutoEncoder.render (rgca.py:137,144-145): alpha = 1 - T, depth / clamp(alpha, lo, 1)
-    if (out_alpha) out_alpha[p] = 1.f - Tq;
-    if (EXTRA && out_extra_norm) out_extra_norm[p] = ex / fminf(fmaxf(1.f - Tq, norm_lo), 1.f);
+    if (o_alpha) *gol_at(o_alpha, b4) = 1.f - Tq;
+    if (o_norm) *gol_at(o_norm, b4) = ex / fminf(fmaxf(1.f - Tq, norm_lo), 1.f);
     // optional fused masked L1 against a target image (rgb_l1, ca_code/loss/__init__.py:391-411; planar layout): the
     // |difference| goes into a per-tile partial sum and its sign -- the loss gradient up to mask x scalar -- into ONE
     // byte per pixel (2 bits per channel: sign + 1), which the backward decodes as its upstream image gradient: the two
     // separate passes over the image of the loss disappear, and the epilogue writes 1 instead of 12 bytes per pixel for
     // it (the epilogue's traffic is not hidden: 71 % of the tiles of the benchmarked views are empty and do nothing else)
-    if (l1_target) {
-      const float m0 = l1_mask ? l1_mask[((size_t)view * l1_mask_c) * hw + (size_t)i * img_w + j] : 1.f;
+    if (i_tgt) {
+      const float m0 = i_mask ? *gol_at(i_mask, b4) : 1.f;
       const float cs[3] = {c0, c1, c2};
       unsigned code = 0u;
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
-        const float m = (l1_mask && l1_mask_c == 3) ? l1_mask[((size_t)view * 3 + c) * hw + (size_t)i * img_w + j] : m0;
-        const float d = (cs[c] - l1_target[o0 + c * os]) * m;
+        const float m = (i_mask && l1_mask_c == 3) ? *gol_at(i_mask + (size_t)c * hw, b4) : m0;
+        const float d = (cs[c] - *gol_at(i_tgt + (size_t)c * hw, b4)) * m;
         l1_acc += fabsf(d);
         code |= (d > 0.f ? 2u : (d < 0.f ? 0u : 1u)) << (2 * c);
       }
-      l1_sign[p] = (uint8_t)code;
+      *gol_at(o_sign, pix) = (uint8_t)code;
     }
   }
   if (l1_target) {  // (kernel-uniform) per-tile sum of |difference|: the caller adds the tiles up (deterministic)
@@ -481,6 +503,7 @@ extern "C" int gol_rasterize_fwd(int B, int N, int img_h, int img_w, int block, 
   if (B == 0) return GOL_OK;
   GOL_REQUIRE(B <= 65535, "B > 65535");
   GOL_REQUIRE(tile_bins && background && out_img && final_Ts && final_idx, "null pointer");
+  GOL_REQUIRE((uint64_t)img_h * (uint64_t)img_w * 12ull < (1ull << 32), "image too large (32-bit byte offsets inside a view)");
   GOL_REQUIRE(capacity == 0 || sorted_ids, "null sorted_ids");
   GOL_REQUIRE(N == 0 || (xys && conics && colors && opacities), "null Gaussian attribute");
   GOL_REQUIRE((!out_extra && !out_extra_norm) || extra || N == 0, "out_extra / out_extra_norm need the extra channel");
