@@ -1,6 +1,7 @@
 // gol_common.h -- device helpers shared by the gfx950 kernels of libgoliath_hip.so.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include <stdint.h>
 
 #include "../../include/goliath_hip.h"
@@ -80,6 +81,13 @@ __device__ __forceinline__ float gol_wave_sum4(float a, float b, float c, float 
   const float bd = gol_swap32_sum(b, d);   // lower: b, upper: d
   const float q = gol_swap16_sum(ac, bd);  // rows: a, b, c, d
   return gol_row_sum_to_lane15(q);
+}
+
+// element at a 32-bit BYTE offset from a (wave-uniform) base pointer: the SGPR-base + VGPR-offset addressing form
+// (64-bit per-lane address arithmetic costs several quarter-rate vector instructions per access)
+template <typename T>
+__device__ __forceinline__ T* gol_at(T* base, unsigned byte_off) {
+  return reinterpret_cast<T*>(reinterpret_cast<char*>(const_cast<typename std::remove_const<T>::type*>(base)) + byte_off);
 }
 
 // lane mask of a predicate as a scalar (s_and with exec); HIP's __ballot(int) goes through an int (v_cndmask + v_cmp_ne)

@@ -180,7 +180,12 @@ struct Ray {
 
 struct Tri { int idx[8]; float w[8]; float fx, fy, fz; int x0, y0, z0; };
 
-// utils.h:523-560 (align_corners=True coordinates, zero padding): corner indices (-1 = outside) + weights
+// utils.h:523-560 (align_corners=True coordinates, zero padding): corner indices (-1 = outside) + weights, for a
+// position strictly inside the box (valid_pos: every sample the march evaluates).  Then (pos + 1) / 2 is in (0, 1) and
+// the floor of the voxel coordinate in [0, W-1], so the lower corner always exists and the upper one of an axis is
+// missing only when the coordinate rounded up to W-1 exactly: three compares decide all eight corners (the general
+// form tested 6 bounds per corner).  Executed by every lane (the clamp keeps the integers defined for the positions of
+// lanes that do not evaluate; their indices are never used).
 __device__ __forceinline__ void tri_setup(Tri& q, int D, int H, int W, V3 pos) {
   const float ix = fmaxf(-100.f, fminf(100.f, (pos.x + 1.f) * 0.5f)) * (float)(W - 1);
   const float iy = fmaxf(-100.f, fminf(100.f, (pos.y + 1.f) * 0.5f)) * (float)(H - 1);
@@ -188,13 +193,21 @@ __device__ __forceinline__ void tri_setup(Tri& q, int D, int H, int W, V3 pos) {
   const float fx0 = floorf(ix), fy0 = floorf(iy), fz0 = floorf(iz);
   const int x0 = (int)fx0, y0 = (int)fy0, z0 = (int)fz0;
   q.fx = ix - fx0; q.fy = iy - fy0; q.fz = iz - fz0; q.x0 = x0; q.y0 = y0; q.z0 = z0;
-#pragma unroll
-  for (int c = 0; c < 8; ++c) {
-    const int dx = c & 1, dy = (c >> 1) & 1, dz = (c >> 2) & 1;
-    const int x = x0 + dx, y = y0 + dy, z = z0 + dz;
-    q.w[c] = (dx ? q.fx : 1.f - q.fx) * (dy ? q.fy : 1.f - q.fy) * (dz ? q.fz : 1.f - q.fz);
-    q.idx[c] = (x >= 0 && x < W && y >= 0 && y < H && z >= 0 && z < D) ? (z * H + y) * W + x : -1;
-  }
+  const bool vx = x0 + 1 < W, vy = y0 + 1 < H, vz = z0 + 1 < D;
+  const int sy = W, sz = H * W;
+  const int b = z0 * sz + y0 * sy + x0;
+  q.idx[0] = b;
+  q.idx[1] = vx ? b + 1 : -1;
+  q.idx[2] = vy ? b + sy : -1;
+  q.idx[3] = (vx && vy) ? b + sy + 1 : -1;
+  q.idx[4] = vz ? b + sz : -1;
+  q.idx[5] = (vx && vz) ? b + sz + 1 : -1;
+  q.idx[6] = (vy && vz) ? b + sz + sy : -1;
+  q.idx[7] = (vx && vy && vz) ? b + sz + sy + 1 : -1;
+  const float gx = 1.f - q.fx, gy = 1.f - q.fy, gz = 1.f - q.fz;
+  const float w00 = gx * gy, w10 = q.fx * gy, w01 = gx * q.fy, w11 = q.fx * q.fy;
+  q.w[0] = w00 * gz; q.w[1] = w10 * gz; q.w[2] = w01 * gz; q.w[3] = w11 * gz;
+  q.w[4] = w00 * q.fz; q.w[5] = w10 * q.fz; q.w[6] = w01 * q.fz; q.w[7] = w11 * q.fz;
 }
 
 // Builds the wave's hit list (LDS) + per-box iteration windows, and positions the ray at its first
@@ -354,13 +367,13 @@ __global__ __launch_bounds__(256) void march_fwd_kernel(MarchArgs a, float* __re
           const float* tp = tplate_a + (size_t)k * vox;
 #pragma unroll
           for (int c = 0; c < 8; ++c)
-            if (q.idx[c] >= 0) s3 += tp[q.idx[c]] * q.w[c];
+            if (q.idx[c] >= 0) s3 += *gol_at(tp, (unsigned)q.idx[c] * 4u) * q.w[c];
         } else {
           const float4* tp = tplate + (size_t)k * vox;
 #pragma unroll
           for (int c = 0; c < 8; ++c) {
             if (q.idx[c] >= 0) {
-              const float4 v = tp[q.idx[c]];
+              const float4 v = *gol_at(tp, (unsigned)q.idx[c] * 16u);  // uniform box base + 32-bit byte offset
               s0 += v.x * q.w[c]; s1 += v.y * q.w[c]; s2 += v.z * q.w[c]; s3 += v.w * q.w[c];
             }
           }
@@ -466,22 +479,22 @@ __global__ __launch_bounds__(256) void march_bwd_kernel(MarchArgs a, const float
       const bool ev = ray.live && valid_pos(y0) && !sat && ray.t < ray.rt1 + 1e-5f;
       if (gol_ballot(ev) == 0ull) continue;
       V3 dLy = v3(0.f, 0.f, 0.f);
-      float sd0 = 0.f, sd1 = 0.f, sd2 = 0.f, sd3 = 0.f, cw[8];
-      int cidx[8], cellkey = -1;
-#pragma unroll
-      for (int c = 0; c < 8; ++c) { cidx[c] = -1; cw[c] = 0.f; }
+      float sd0 = 0.f, sd1 = 0.f, sd2 = 0.f, sd3 = 0.f;
+      // corner indices / weights of every lane (plain arithmetic; only lanes with `ev` use theirs): kept in `q` for the
+      // scatter below instead of being copied out of the branch
+      Tri q;
+      tri_setup(q, a.TD, a.TH, a.TW, y0);
+      const int cellkey = ((q.z0 + 1) * (a.TH + 1) + (q.y0 + 1)) * (a.TW + 1) + (q.x0 + 1);
       if (ev) {
         const float ax = fabsf(y0.x), ay = fabsf(y0.y), az = fabsf(y0.z);
         const bool e8 = fe == 8.f;
         const float fade = __expf(-fs * (fade_pow(ax, fe, e8) + fade_pow(ay, fe, e8) + fade_pow(az, fe, e8)));
-        Tri q;
-        tri_setup(q, a.TD, a.TH, a.TW, y0);
         const float4* tp = tplate + (size_t)k * vox;
         float4 cv[8];
         float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
-          cv[c] = (q.idx[c] >= 0) ? tp[q.idx[c]] : make_float4(0.f, 0.f, 0.f, 0.f);
+          cv[c] = (q.idx[c] >= 0) ? *gol_at(tp, (unsigned)q.idx[c] * 16u) : make_float4(0.f, 0.f, 0.f, 0.f);
           s0 += cv[c].x * q.w[c]; s1 += cv[c].y * q.w[c]; s2 += cv[c].z * q.w[c]; s3 += cv[c].w * q.w[c];
         }
         s3 *= fade;
@@ -513,9 +526,6 @@ __global__ __launch_bounds__(256) void march_bwd_kernel(MarchArgs a, const float
         }
         dLy = dLy + v3(gix * 0.5f * (float)(a.TW - 1), giy * 0.5f * (float)(a.TH - 1), giz * 0.5f * (float)(a.TD - 1));
         sd0 = d0; sd1 = d1; sd2 = d2; sd3 = d3;
-        cellkey = ((q.z0 + 1) * (a.TH + 1) + (q.y0 + 1)) * (a.TW + 1) + (q.x0 + 1);
-#pragma unroll
-        for (int c = 0; c < 8; ++c) { cidx[c] = q.idx[c]; cw[c] = q.w[c]; }
       }
       // Template-gradient scatter.  The 64 rays of a wave sample only a handful of distinct voxel cells
       // of this box at this step, and every device-scope float atomic is a fabric transaction on
@@ -536,14 +546,14 @@ __global__ __launch_bounds__(256) void march_bwd_kernel(MarchArgs a, const float
           // together: one request covers both corners whenever they share a cache line.
 #pragma unroll
           for (int c = 0; c < 8; c += 2) {
-            const int i0 = __builtin_amdgcn_readlane(cidx[c], leader), i1 = __builtin_amdgcn_readlane(cidx[c + 1], leader);
+            const int i0 = __builtin_amdgcn_readlane(q.idx[c], leader), i1 = __builtin_amdgcn_readlane(q.idx[c + 1], leader);
             if (i0 < 0 && i1 < 0) continue;
-            const float w0 = mine ? cw[c] : 0.f, w1 = mine ? cw[c + 1] : 0.f;
+            const float w0 = mine ? q.w[c] : 0.f, w1 = mine ? q.w[c + 1] : 0.f;
             const float ra = gol_wave_sum4(w0 * sd0, w0 * sd1, w0 * sd2, w0 * sd3);   // lanes 15, 31, 47, 63
             const float rb = gol_dpp_mov0<0x101>(gol_wave_sum4(w1 * sd0, w1 * sd1, w1 * sd2, w1 * sd3));  // row_shl:1 -> 14, 30, ..
             const int l15 = lane & 15;
             const int idx = (l15 == 15) ? i0 : i1;
-            if (l15 >= 14 && idx >= 0) atomicAdd(gt + (size_t)idx * 4 + (lane >> 4), (l15 == 15) ? ra : rb);
+            if (l15 >= 14 && idx >= 0) atomicAdd(gol_at(gt, (unsigned)idx * 16u + (unsigned)(lane >> 4) * 4u), (l15 == 15) ? ra : rb);
           }
         }
       }

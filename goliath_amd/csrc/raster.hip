@@ -24,11 +24,6 @@
 
 namespace {
 
-// element at a 32-bit BYTE offset from a (wave-uniform) base pointer: the SGPR-base + VGPR-offset addressing form
-template <typename T>
-__device__ __forceinline__ T* gol_at(T* base, unsigned byte_off) {
-  return reinterpret_cast<T*>(reinterpret_cast<char*>(const_cast<typename std::remove_const<T>::type*>(base)) + byte_off);
-}
 
 constexpr int kBatch = 256;
 // conics are staged in LDS pre-multiplied by log2(e) -- alpha = opacity * 2^(-sigma') is one v_exp_f32 with a negated
