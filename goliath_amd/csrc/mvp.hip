@@ -178,7 +178,7 @@ struct Ray {
   bool live;
 };
 
-struct Tri { int idx[8]; float w[8]; float fx, fy, fz; int x0, y0, z0; };
+struct Tri { int idx[8]; float w[8]; float fx, fy, fz; int x0, y0, z0; bool allv; };
 
 // utils.h:523-560 (align_corners=True coordinates, zero padding): corner indices (-1 = outside) + weights, for a
 // position strictly inside the box (valid_pos: every sample the march evaluates).  Then (pos + 1) / 2 is in (0, 1) and
@@ -194,6 +194,7 @@ __device__ __forceinline__ void tri_setup(Tri& q, int D, int H, int W, V3 pos) {
   const int x0 = (int)fx0, y0 = (int)fy0, z0 = (int)fz0;
   q.fx = ix - fx0; q.fy = iy - fy0; q.fz = iz - fz0; q.x0 = x0; q.y0 = y0; q.z0 = z0;
   const bool vx = x0 + 1 < W, vy = y0 + 1 < H, vz = z0 + 1 < D;
+  q.allv = vx && vy && vz;  // all eight corners exist (always, but for a coordinate that rounded up to the last voxel)
   const int sy = W, sz = H * W;
   const int b = z0 * sz + y0 * sy + x0;
   q.idx[0] = b;
@@ -356,12 +357,13 @@ __global__ __launch_bounds__(256) void march_fwd_kernel(MarchArgs a, float* __re
       // shadow splat state of this lane (filled inside the branch, scattered wave-wide after it)
       int sh_idx[SHADOW ? 8 : 1], sh_key = -1;
       float sh_w[SHADOW ? 8 : 1], sh_vis = 0.f;
+      Tri q;  // (every lane; only evaluating lanes use theirs)
+      tri_setup(q, a.TD, a.TH, a.TW, y0);
+      const bool all_corners = gol_ballot(ev && !q.allv) == 0ull;
       if (ev) {
         const bool e8 = a.fadeexp == 8.f;
         const float fade = __expf(-a.fadescale * (fade_pow(fabsf(y0.x), a.fadeexp, e8) + fade_pow(fabsf(y0.y), a.fadeexp, e8) +
                                                   fade_pow(fabsf(y0.z), a.fadeexp, e8)));
-        Tri q;
-        tri_setup(q, a.TD, a.TH, a.TW, y0);
         float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
         if (a.alpha_only) {  // (kernel-uniform) shadow march: 4 bytes per voxel instead of 16
           const float* tp = tplate_a + (size_t)k * vox;
@@ -370,11 +372,19 @@ __global__ __launch_bounds__(256) void march_fwd_kernel(MarchArgs a, float* __re
             if (q.idx[c] >= 0) s3 += *gol_at(tp, (unsigned)q.idx[c] * 4u) * q.w[c];
         } else {
           const float4* tp = tplate + (size_t)k * vox;
+          if (all_corners) {  // (wave-uniform) the common case: eight unguarded loads, no exec-mask regions
 #pragma unroll
-          for (int c = 0; c < 8; ++c) {
-            if (q.idx[c] >= 0) {
+            for (int c = 0; c < 8; ++c) {
               const float4 v = *gol_at(tp, (unsigned)q.idx[c] * 16u);  // uniform box base + 32-bit byte offset
               s0 += v.x * q.w[c]; s1 += v.y * q.w[c]; s2 += v.z * q.w[c]; s3 += v.w * q.w[c];
+            }
+          } else {
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+              if (q.idx[c] >= 0) {
+                const float4 v = *gol_at(tp, (unsigned)q.idx[c] * 16u);
+                s0 += v.x * q.w[c]; s1 += v.y * q.w[c]; s2 += v.z * q.w[c]; s3 += v.w * q.w[c];
+              }
             }
           }
         }
