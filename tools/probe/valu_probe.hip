@@ -48,6 +48,18 @@ __global__ __launch_bounds__(256) void probe(float* out, int iters) {
       REP8(asm volatile("v_mul_f32 %0, %0, %8\n v_mul_f32 %1, %1, %8\n v_mul_f32 %2, %2, %8\n v_mul_f32 %3, %3, %8\n"
                         "v_mul_f32 %4, %4, %8\n v_mul_f32 %5, %5, %8\n v_mul_f32 %6, %6, %8\n v_mul_f32 %7, %7, %8\n"
                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(m));)
+    } else if (KIND == 9) {  // v_cmp_lt_u64 (the key compare of the tile sort)
+      REP8(asm volatile("v_cmp_lt_u64 vcc, %0, %1\n v_cmp_lt_u64 vcc, %1, %2\n v_cmp_lt_u64 vcc, %2, %3\n v_cmp_lt_u64 vcc, %3, %0\n"
+                        "v_cmp_lt_u64 vcc, %0, %2\n v_cmp_lt_u64 vcc, %1, %3\n v_cmp_lt_u64 vcc, %2, %0\n v_cmp_lt_u64 vcc, %3, %1\n"
+                        : : "v"(*(double*)&a0), "v"(*(double*)&a2), "v"(*(double*)&a4), "v"(*(double*)&a6) : "vcc");)
+    } else if (KIND == 10) {  // v_cmp_lt_u32
+      REP8(asm volatile("v_cmp_lt_u32 vcc, %0, %1\n v_cmp_lt_u32 vcc, %1, %2\n v_cmp_lt_u32 vcc, %2, %3\n v_cmp_lt_u32 vcc, %3, %0\n"
+                        "v_cmp_lt_u32 vcc, %0, %2\n v_cmp_lt_u32 vcc, %1, %3\n v_cmp_lt_u32 vcc, %2, %0\n v_cmp_lt_u32 vcc, %3, %1\n"
+                        : : "v"(a0), "v"(a1), "v"(a2), "v"(a3) : "vcc");)
+    } else if (KIND == 11) {  // ds_bpermute_b32 (the cross-lane exchange of the tile sort)
+      REP8(asm volatile("ds_bpermute_b32 %0, %8, %0\n ds_bpermute_b32 %1, %8, %1\n ds_bpermute_b32 %2, %8, %2\n ds_bpermute_b32 %3, %8, %3\n"
+                        "ds_bpermute_b32 %4, %8, %4\n ds_bpermute_b32 %5, %8, %5\n ds_bpermute_b32 %6, %8, %6\n ds_bpermute_b32 %7, %8, %7\n s_waitcnt lgkmcnt(0)\n"
+                        : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b0));)
     } else if (KIND == 8) {  // v_rcp_f32
       REP8(asm volatile("v_rcp_f32 %0, %8\n v_rcp_f32 %1, %8\n v_rcp_f32 %2, %8\n v_rcp_f32 %3, %8\n"
                         "v_rcp_f32 %4, %8\n v_rcp_f32 %5, %8\n v_rcp_f32 %6, %8\n v_rcp_f32 %7, %8\n"
@@ -94,5 +106,8 @@ int main() {
   run<4>("v_cmp_gt_f32", out, cus, ghz);
   run<5>("v_add_f32_dpp", out, cus, ghz);
   run<6>("v_permlane32_swap", out, cus, ghz);
+  run<9>("v_cmp_lt_u64", out, cus, ghz);
+  run<10>("v_cmp_lt_u32", out, cus, ghz);
+  run<11>("ds_bpermute_b32", out, cus, ghz);
   return 0;
 }
