@@ -113,7 +113,9 @@ def step(t, cfg, world):
     for stream in t["streams"]:
         main.wait_stream(stream)
     # the path's only parameter (albedo, rgca.py:462-464) is shared by all views: sum the micro-batch grads
-    t["_albedo_grad"] = torch.stack([mb["albedo"].grad for mb in t["micro"]]).sum(0)
+    grads = [mb["albedo"].grad for mb in t["micro"]]
+    t["_albedo_grad"] = grads[0] if len(grads) == 1 else (
+        torch.add(grads[0], grads[1]) if len(grads) == 2 else torch.stack(grads).sum(0))
     t["albedo"].grad = t["_albedo_grad"]
     return loss
 
