@@ -78,7 +78,32 @@ def iptr(t, name="tensor"):
 
 
 def stream_ptr():
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    """The current PyTorch HIP stream of the current device as a raw handle.  (torch.cuda.current_stream() builds a Python
+    Stream object, ~10 us per call and 20 calls per step; the raw query is what the launch path needs.)"""
+    return ctypes.c_void_p(torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice()))
+
+
+class device_guard:
+    """`with device_guard(t.device):` -- make the tensor's GPU current for the enclosed launches (the reference extensions
+    use a CUDAGuard, sg.cu:204; mvpraymarch has none).  A cheap stand-in for torch.cuda.device(): no
+    device switch at all in the common case that the device already is current."""
+    __slots__ = ("idx", "prev")
+
+    def __init__(self, dev):
+        self.idx = dev.index if isinstance(dev, torch.device) else dev
+        self.prev = None
+
+    def __enter__(self):
+        if self.idx is not None:
+            self.prev = torch._C._cuda_getDevice()
+            if self.prev != self.idx:
+                torch._C._cuda_setDevice(self.idx)
+        return self
+
+    def __exit__(self, *exc):
+        if self.idx is not None and self.prev != self.idx:
+            torch._C._cuda_setDevice(self.prev)
+        return False
 
 
 TIMING = None  # set to a list to record (name, start_event, end_event) around every ABI call

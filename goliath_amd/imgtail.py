@@ -23,7 +23,7 @@ class _ImageTail(torch.autograd.Function):
     def forward(ctx, rgb, alpha, bg, bg_scale, cal_M, cal_b, blur_w):
         B, _, H, W = rgb.shape
         out = torch.empty_like(rgb)
-        with torch.cuda.device(rgb.device):
+        with _lib.device_guard(rgb.device):
             _lib.call("gol_imgtail_fwd", c_int(B), c_int(H), c_int(W), fptr(rgb), fptr(alpha), fptr(bg), fptr(bg_scale),
                       fptr(cal_M), fptr(cal_b), fptr(blur_w), fptr(out), stream_ptr())
         ctx.save_for_backward(rgb, alpha, bg, bg_scale, cal_M, cal_b, blur_w)
@@ -39,7 +39,7 @@ class _ImageTail(torch.autograd.Function):
         fn.restype = ctypes.c_int64
         n = int(fn(c_int(B), c_int(H), c_int(W)))
         partials = torch.empty(B, max(n // max(B, 1) // 16, 1), 16, device=rgb.device)
-        with torch.cuda.device(rgb.device):
+        with _lib.device_guard(rgb.device):
             _lib.call("gol_imgtail_bwd", c_int(B), c_int(H), c_int(W), fptr(rgb), fptr(alpha), fptr(bg), fptr(bg_scale),
                       fptr(cal_M), fptr(cal_b), fptr(blur_w), fptr(g), fptr(g_rgb), fptr(partials), stream_ptr())
         s = partials.sum(1)  # [B,16]: blur weights 0..2 | bias 3..5 | M 6..14 (per-workgroup partial sums, no atomics)

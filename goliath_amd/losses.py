@@ -19,7 +19,7 @@ class _L1(torch.autograd.Function):
         mask_c = 0 if mask is None else mask.shape[1]
         nb = _lib.load().gol_l1_blocks(HW)
         partial = torch.empty(B * C * nb, device=pred.device)
-        with torch.cuda.device(pred.device):
+        with _lib.device_guard(pred.device):
             _lib.call("gol_l1_fwd", c_int(B), c_int(C), c_int(HW), c_int(mask_c), fptr(pred), fptr(target), fptr(mask),
                       fptr(partial), stream_ptr())
         ctx.save_for_backward(pred, target, mask)
@@ -33,7 +33,7 @@ class _L1(torch.autograd.Function):
         mask_c = 0 if mask is None else mask.shape[1]
         out = torch.empty_like(pred)
         g = g.to(torch.float32).reshape(1).contiguous()
-        with torch.cuda.device(pred.device):
+        with _lib.device_guard(pred.device):
             _lib.call("gol_l1_bwd", c_int(B), c_int(C), c_int(HW), c_int(mask_c), fptr(pred), fptr(target), fptr(mask),
                       fptr(g), fptr(out), stream_ptr())
         return out, None, None
@@ -86,7 +86,7 @@ class _Ssim(torch.autograd.Function):
         nb = _lib.load().gol_ssim_blocks(H, W)
         partial = torch.empty(B * C * nb, device=pred.device)
         dmap = torch.empty(3, B, C, H, W, device=pred.device) if ctx.needs_input_grad[0] else None
-        with torch.cuda.device(pred.device):
+        with _lib.device_guard(pred.device):
             _lib.call("gol_ssim_fwd", c_int(B), c_int(C), c_int(H), c_int(W), c_int(mask_c), fptr(target), fptr(pred),
                       fptr(mask), fptr(partial), fptr(dmap), stream_ptr())
         if mask is None:
@@ -102,7 +102,7 @@ class _Ssim(torch.autograd.Function):
         B, C, H, W = pred.shape
         out = torch.empty_like(pred)
         gs = (g.to(torch.float32) / denom).reshape(1).contiguous()
-        with torch.cuda.device(pred.device):
+        with _lib.device_guard(pred.device):
             _lib.call("gol_ssim_bwd", c_int(B), c_int(C), c_int(H), c_int(W), fptr(target), fptr(pred), fptr(dmap),
                       fptr(gs), fptr(out), stream_ptr())
         return out, None, None

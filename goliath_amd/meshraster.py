@@ -42,7 +42,7 @@ def rasterize(v_pix: torch.Tensor, vi: torch.Tensor, height: int, width: int, wi
     fn = _lib.load().gol_mesh_raster_workspace_bytes
     fn.restype = ctypes.c_int64
     ws = torch.empty(max(int(fn(c_int(B), c_int(Fc))), 4) // 4, dtype=torch.int32, device=dev)
-    with torch.cuda.device(dev):
+    with _lib.device_guard(dev):
         _lib.call("gol_mesh_raster", c_int(B), c_int(V), c_int(Fc), c_int(height), c_int(width), fptr(v_pix), iptr(vi),
                   iptr(index_img), fptr(depth_img), fptr(bary_img), iptr(ws), stream_ptr())
     return index_img, depth_img, bary_img

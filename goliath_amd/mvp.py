@@ -48,7 +48,7 @@ class _MvpLib:
     def compute_aabb(primpos, primrot, primscale, sortedobjid, nodechildren, nodeparent, nodeaabb, algo=0):
         N, K = primpos.shape[:2]
         _need_gpu(primpos, "primpos")
-        with torch.cuda.device(primpos.device):
+        with _lib.device_guard(primpos.device):
             _lib.call("gol_mvp_aabb", c_int(N), c_int(K), fptr(primpos, "primpos"), fptr(primrot, "primrot"),
                       fptr(primscale, "primscale"), fptr(nodeaabb, "nodeaabb"), stream_ptr())
         return []
@@ -67,7 +67,7 @@ class _MvpLib:
         N, H, W = raypos.shape[:3]
         K, TD, TH, TW = _dims(template)
         _need_gpu(raypos, "raypos")
-        with torch.cuda.device(raypos.device):
+        with _lib.device_guard(raypos.device):
             _lib.call("gol_mvp_march_fwd", c_int(N), c_int(H), c_int(W), c_int(K), fptr(raypos, "raypos"),
                       fptr(raydir, "raydir"), c_float(stepsize), fptr(tminmax, "tminmax"), fptr(nodeaabb, "nodeaabb"),
                       fptr(primpos, "primpos"), fptr(primrot, "primrot"), fptr(primscale, "primscale"),
@@ -87,7 +87,7 @@ class _MvpLib:
         N, H, W = raypos.shape[:3]
         K, TD, TH, TW = _dims(template)
         _need_gpu(raypos, "raypos")
-        with torch.cuda.device(raypos.device):
+        with _lib.device_guard(raypos.device):
             _lib.call("gol_mvp_march_bwd", c_int(N), c_int(H), c_int(W), c_int(K), fptr(raypos), fptr(raydir),
                       c_float(stepsize), fptr(tminmax), fptr(nodeaabb), fptr(primpos), fptr(primrot), fptr(primscale),
                       fptr(template), c_int(TD), c_int(TH), c_int(TW), c_float(fadescale), c_float(fadeexp),
@@ -201,7 +201,7 @@ def shadow_march(raypos, raydir, stepsize, tminmax, primtransf, alpha_template, 
         TD, TH, TW = tpl.shape[2:5]
         shadow = torch.zeros(N, K, TD, TH, TW, 2, device=tpl.device)
         img = torch.empty(N, H, W, 4, device=tpl.device) if return_image else None
-        with torch.cuda.device(tpl.device):
+        with _lib.device_guard(tpl.device):
             _lib.call("gol_mvp_shadow_march", c_int(N), c_int(L), c_int(H), c_int(W), c_int(K), fptr(raypos), fptr(raydir),
                       c_float(float(stepsize)), fptr(tminmax), fptr(nodeaabb), fptr(primpos), fptr(primrot),
                       fptr(primscale), fptr(tpl), c_int(1), c_int(TD), c_int(TH), c_int(TW), c_float(float(fadescale)),
@@ -217,7 +217,7 @@ class _UtilsLib:
                                 tminmax):
         N = viewpos.shape[0]
         _need_gpu(viewpos, "viewpos")
-        with torch.cuda.device(viewpos.device):
+        with _lib.device_guard(viewpos.device):
             _lib.call("gol_raydirs_fwd", c_int(N), c_int(H), c_int(W), fptr(viewpos, "viewpos"),
                       fptr(viewrot, "viewrot"), fptr(focal, "focal"), fptr(princpt, "princpt"),
                       fptr(pixelcoords, "pixelcoords"), c_float(volradius), fptr(raypos), fptr(raydir),

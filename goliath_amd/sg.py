@@ -38,7 +38,7 @@ class _Lib:
                               integral, w_type):
         N, D, L = _dims(lobe_dirs, lobe_sigmas, light_values, light_pts, prim_pts, n_lights,
                         extra=[("integral", integral)])
-        with torch.cuda.device(lobe_dirs.device):
+        with _lib.device_guard(lobe_dirs.device):
             _lib.call("gol_sg_eval_fwd", c_int(N), c_int(D), c_int(L), fptr(lobe_dirs, "lobe_dirs"),
                       fptr(lobe_sigmas, "lobe_sigmas"), fptr(light_values, "light_values"),
                       fptr(light_pts, "light_pts"), fptr(prim_pts, "prim_pts"),
@@ -50,7 +50,7 @@ class _Lib:
     def evaluate_gaussian_bwd(lobe_dirs, lobe_sigmas, light_values, light_pts, prim_pts, n_lights,
                               grad_integral, grad_dirs, grad_lobe_sigmas, grad_light_values, w_type):
         N, D, L = _dims(lobe_dirs, lobe_sigmas, light_values, light_pts, prim_pts, n_lights)
-        with torch.cuda.device(lobe_dirs.device):
+        with _lib.device_guard(lobe_dirs.device):
             _lib.call("gol_sg_eval_bwd", c_int(N), c_int(D), c_int(L), fptr(lobe_dirs, "lobe_dirs"),
                       fptr(lobe_sigmas, "lobe_sigmas"), fptr(light_values, "light_values"),
                       fptr(light_pts, "light_pts"), fptr(prim_pts, "prim_pts"),

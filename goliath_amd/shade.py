@@ -100,14 +100,14 @@ class _Shade(torch.autograd.Function):
         need_grad = any(ctx.needs_input_grad[:5])
         outs = {n: torch.empty(B, N, k, device=dev) for n, k in OUT_FIELDS
                 if (rand or n != "color_rand") and (n != "env_saved" or (mips and need_grad))}
-        with torch.cuda.device(dev):
+        with _lib.device_guard(dev):
             packed = pack_envmap(mips) if mips else None
         sin = _make_in(f_vnocond, f_vcond, postex, tn, albedo, light_sh, light_sh_rand, campos,
                        light_intensity, light_pos, n_lights, list(mips), lightrot, ncol, nmono, packed)
         sout = ShadeOut()
         for n, t in outs.items():
             setattr(sout, n, _p(t))
-        with torch.cuda.device(dev):
+        with _lib.device_guard(dev):
             _lib.call("gol_shade_fwd", ctypes.byref(sin), ctypes.byref(sout), stream_ptr())
         ctx.cfg = (ncol, nmono, len(mips), rand)
         ctx.packed = packed  # not an input/output of the node: plain attribute
@@ -148,7 +148,7 @@ class _Shade(torch.autograd.Function):
         gin = ShadeInGrad()
         gin.f_vnocond, gin.f_vcond, gin.postex, gin.tn = _p(g_vn), _p(g_vc), _p(g_pt), _p(g_tn)
         gin.albedo_per_view = _p(g_alb)
-        with torch.cuda.device(dev):
+        with _lib.device_guard(dev):
             _lib.call("gol_shade_bwd", ctypes.byref(sin), ctypes.byref(saved), ctypes.byref(up), ctypes.byref(gin),
                       stream_ptr())
         g_albedo = g_alb.sum(0).reshape(albedo.shape) if ctx.needs_input_grad[4] else None

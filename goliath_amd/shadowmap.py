@@ -29,7 +29,7 @@ def shadow_pcf(depth, Rt, postex, nml=None, exp_scale=0.0, focal=1000.0):
     depth, Rt, postex, nml = c(depth), c(Rt), c(postex), c(nml)
     out = torch.empty(BL, 1, H, W, device=postex.device)
     f = ctypes.c_float
-    with torch.cuda.device(postex.device):
+    with _lib.device_guard(postex.device):
         _lib.call("gol_shadow_pcf", c_int(B), c_int(L), c_int(H), c_int(W), c_int(dh), c_int(dw), fptr(depth), fptr(Rt),
                   f(focal), f(focal), f(dw / 2), f(dh / 2), fptr(postex), fptr(nml), f(exp_scale), fptr(out), stream_ptr())
     return out

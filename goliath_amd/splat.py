@@ -195,7 +195,7 @@ class _ProjectGaussians(torch.autograd.Function):
         means3d, scales, quats = _f32c(means3d), _f32c(scales), _f32c(quats)
         vm = _f32c(viewmat).reshape(-1)[:12].contiguous().view(1, 12)
         intr = torch.tensor([[fx, fy, cx, cy]], dtype=torch.float32).to(dev, non_blocking=True)
-        with torch.cuda.device(dev):
+        with _lib.device_guard(dev):
             cov3d, xys, depths, radii, conics, comp, nth, _ = _project_fwd(
                 1, N, means3d, scales, float(glob_scale), quats, vm, intr, img_height, img_width,
                 float(clip_thresh))
@@ -216,7 +216,7 @@ class _ProjectGaussians(torch.autograd.Function):
         c = lambda t: None if t is None else _f32c(t)
         # converted gradients are bound to locals so they outlive the launch
         g_xy, g_depth, g_conic, g_comp = c(v_xys), c(v_depths), c(v_conics), c(v_compensation)
-        with torch.cuda.device(means3d.device):
+        with _lib.device_guard(means3d.device):
             _lib.call("gol_project_bwd", c_int(1), c_int(N), fptr(means3d), fptr(scales), c_float(ctx.glob_scale),
                       fptr(quats), fptr(vm), fptr(intr), fptr(cov3d), iptr(radii), fptr(conics), fptr(comp),
                       fptr(g_xy), fptr(g_depth), fptr(g_conic), fptr(g_comp),
@@ -261,7 +261,7 @@ class _RasterizeGaussians(torch.autograd.Function):
             out_img = torch.empty(1, img_height, img_width, 3, device=dev)
             final_Ts = torch.empty(1, img_height, img_width, device=dev)
             final_idx = torch.empty(1, img_height, img_width, dtype=torch.int32, device=dev)
-            with torch.cuda.device(dev):
+            with _lib.device_guard(dev):
                 _bin_sort(1, N, xys, depths, radii, img_height, img_width, ws, conics, opacity)
                 _lib.call("gol_rasterize_fwd", c_int(1), c_int(N), c_int(img_height), c_int(img_width),
                           c_int(BLOCK), c_int(0), iptr(ws.tile_bins), iptr(ws.sorted_ids), c_i64(ws.capacity), fptr(xys),
@@ -290,7 +290,7 @@ class _RasterizeGaussians(torch.autograd.Function):
             ws = ctx.ws
             va = None if v_out_alpha is None else _f32c(v_out_alpha)
             vo = _f32c(v_out_img)
-            with torch.cuda.device(xys.device):
+            with _lib.device_guard(xys.device):
                 _lib.call("gol_rasterize_bwd", c_int(1), c_int(N), c_int(H), c_int(W), c_int(BLOCK), c_int(0),
                           iptr(ws.tile_bins), iptr(ws.sorted_ids), c_i64(ws.capacity), fptr(xys), fptr(conics),
                           fptr(colors), fptr(None), fptr(opacity), fptr(background), fptr(final_Ts),
@@ -339,7 +339,7 @@ class _RenderViews(torch.autograd.Function):
         B, N = means.shape[:2]
         dev = means.device
         T = _tiles(img_h, img_w)
-        with torch.cuda.device(dev):
+        with _lib.device_guard(dev):
             cov3d, xys, depths, radii, conics, comp, nth, opac_eff = _project_fwd(
                 B, N, means, scales, glob_scale, quats, viewmats, intrins, img_h, img_w, clip_thresh,
                 opacities=opacity)
@@ -430,7 +430,7 @@ class _RenderViews(torch.autograd.Function):
         v_scale_g = torch.empty_like(scales)
         v_quat = torch.empty_like(quats)
         v_opacity = torch.empty_like(opacity)
-        with torch.cuda.device(dev):
+        with _lib.device_guard(dev):
             _lib.call("gol_rasterize_bwd", c_int(B), c_int(N), c_int(img_h), c_int(img_w), c_int(BLOCK), c_int(1),
                       iptr(ws.tile_bins), iptr(ws.sorted_ids), c_i64(ws.capacity), fptr(xys), fptr(conics),
                       fptr(colors), fptr(depths if use_depth else None), fptr(opac_eff), fptr(background),

@@ -41,7 +41,7 @@ class _TailConv(torch.autograd.Function):
         wB, _, CH = weff.shape[:3]
         nd, E = (lc.shape[0], lc.shape[2]) if lc is not None else (0, 0)   # lc is plane-major [nd,B,E]
         out = torch.empty(B, CH, 2 * h, 2 * w, device=x.device)
-        with torch.cuda.device(x.device):
+        with _lib.device_guard(x.device):
             _lib.call("gol_tail_conv_fwd", c_int(B), c_int(Ci), c_int(h), c_int(w), c_int(CH), c_int(E), c_int(nd),
                       c_int(wB), fptr(x, "x"), fptr(weff, "weff"), fptr(lc, "lc"), fptr(bias, "bias"), fptr(out),
                       stream_ptr())
@@ -64,7 +64,7 @@ class _TailConv(torch.autograd.Function):
             fn = _lib.load().gol_tail_conv_bwd_scratch_floats
             fn.restype = ctypes.c_longlong
             scratch = torch.empty(int(fn(c_int(B), c_int(h), c_int(w), c_int(CH))), device=x.device)
-        with torch.cuda.device(x.device):
+        with _lib.device_guard(x.device):
             _lib.call("gol_tail_conv_bwd", c_int(B), c_int(Ci), c_int(h), c_int(w), c_int(CH), c_int(E), c_int(nd),
                       c_int(wB), fptr(x, "x"), fptr(wt, "weff_t"), fptr(lc, "lc"), fptr(g, "g_out"), fptr(g_x),
                       fptr(g_w), fptr(g_b), fptr(scratch), stream_ptr())

@@ -55,7 +55,7 @@ class _Phong(torch.autograd.Function):
         s = _mk(*args, powers)
         diff = torch.empty(B, 1, H, W, device=p_uv.device)
         spec = torch.empty(B, len(powers), 1, H, W, device=p_uv.device)
-        with torch.cuda.device(p_uv.device):
+        with _lib.device_guard(p_uv.device):
             _lib.call("gol_uvlight_phong_fwd", ctypes.byref(s), _lib.fptr(diff), _lib.fptr(spec), stream_ptr())
         ctx.args, ctx.powers = args, powers
         return diff, spec
@@ -66,7 +66,7 @@ class _Phong(torch.autograd.Function):
         s = _mk(*ctx.args, ctx.powers)
         g_p, g_n = torch.empty_like(p_uv), torch.empty_like(p_uv)
         u_diff, u_spec = _c(u_diff), _c(u_spec)  # bound to locals: must outlive the launch
-        with torch.cuda.device(p_uv.device):
+        with _lib.device_guard(p_uv.device):
             _lib.call("gol_uvlight_phong_bwd", ctypes.byref(s), _lib.fptr(u_diff), _lib.fptr(u_spec),
                       _lib.fptr(g_p), _lib.fptr(g_n), stream_ptr())
         return g_p, g_n, None, None, None, None, None
@@ -81,7 +81,7 @@ class _Ggx(torch.autograd.Function):
         s = _mk(*args, powers, **extra)
         feat = torch.empty(B, 1 + len(powers), H, W, device=p_uv.device)
         rgb = torch.empty(B, 3, H, W, device=p_uv.device)
-        with torch.cuda.device(p_uv.device):
+        with _lib.device_guard(p_uv.device):
             _lib.call("gol_uvlight_ggx_fwd", ctypes.byref(s), _lib.fptr(feat), _lib.fptr(rgb), stream_ptr())
         ctx.args, ctx.powers, ctx.extra = args, powers, extra
         return feat, rgb
@@ -93,7 +93,7 @@ class _Ggx(torch.autograd.Function):
         g_p, g_n = torch.empty_like(p_uv), torch.empty_like(p_uv)
         g_r, g_t = torch.empty_like(ctx.extra["roughness"]), torch.empty_like(ctx.extra["tex_mean"])
         u_feat, u_rgb = _c(u_feat), _c(u_rgb)  # bound to locals: must outlive the launch
-        with torch.cuda.device(p_uv.device):
+        with _lib.device_guard(p_uv.device):
             _lib.call("gol_uvlight_ggx_bwd", ctypes.byref(s), _lib.fptr(u_feat), _lib.fptr(u_rgb),
                       _lib.fptr(g_p), _lib.fptr(g_n), _lib.fptr(g_r), _lib.fptr(g_t), stream_ptr())
         return g_p, g_n, g_r, g_t, None, None, None, None, None, None
