@@ -52,6 +52,8 @@ def make_inputs(cfg, device, rank=0):
     d = torch.randn(N, 3, generator=g)
     d = d / d.norm(dim=-1, keepdim=True)
     pos = d * torch.rand(N, 1, generator=g) ** (1 / 3) * torch.tensor([90.0, 120.0, 100.0])
+    if cfg.get("coherent_uv"):
+        pos = _uv_coherent_order(pos, S)
     postex = pos.t().reshape(1, 3, S, S).expand(B, -1, -1, -1).contiguous()
     tn = F.normalize(pos, dim=-1).t().reshape(1, 3, S, S).expand(B, -1, -1, -1).contiguous()
     scale = torch.exp(math.log(0.3) + (math.log(3.0) - math.log(0.3)) * torch.rand(B, 3, S, S, generator=g))
@@ -88,6 +90,33 @@ def make_inputs(cfg, device, rank=0):
     for k in ("f_vn", "f_vc", "postex", "tn", "albedo"):
         t[k].requires_grad_(True)
     return t
+
+
+def _morton2(x, y):
+    """Interleave the low 16 bits of two int64 tensors (x -> even bits, y -> odd bits)."""
+    def spread(v):
+        v = (v | (v << 8)) & 0x00FF00FF
+        v = (v | (v << 4)) & 0x0F0F0F0F
+        v = (v | (v << 2)) & 0x33333333
+        return (v | (v << 1)) & 0x55555555
+    return spread(x) | (spread(y) << 1)
+
+
+def _uv_coherent_order(pos, S):
+    """--coherent-uv: the same point set, laid out over the S x S slab the way a UV atlas lays out a surface -- texels that
+    are neighbours in the slab hold points that are neighbours in direction (the default layout is a random permutation:
+    every slab neighbour is an unrelated point, the worst case for the env-map gathers of the shading kernel).  Points are
+    sorted along the Z-order curve of their direction's (azimuth, polar) cell and dealt out along the Z-order curve of the
+    slab."""
+    n = F.normalize(pos, dim=-1)
+    az = (torch.atan2(n[:, 0], n[:, 2]) / (2 * math.pi) + 0.5).clamp(0, 1 - 1e-7)
+    po = (torch.acos(n[:, 1].clamp(-1, 1)) / math.pi).clamp(0, 1 - 1e-7)
+    order = torch.argsort(_morton2((az * 65536).long(), (po * 65536).long()))
+    yy, xx = torch.meshgrid(torch.arange(S), torch.arange(S), indexing="ij")
+    slots = torch.argsort(_morton2(xx.reshape(-1).long(), yy.reshape(-1).long()))   # slab texels in Z-order
+    out = torch.empty_like(pos)
+    out[slots] = pos[order]
+    return out
 
 
 def step(t, cfg, world):
@@ -582,6 +611,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--views", type=int, default=CFG["views_per_gpu"])
     ap.add_argument("--micro", type=int, default=2, help="micro-batches (HIP streams) per step")
+    ap.add_argument("--coherent-uv", action="store_true",
+                    help="lay the synthetic Gaussians out over the slab like a UV atlas (slab neighbours = spatial neighbours) "
+                         "instead of the default random permutation; the point set is the same")
     ap.add_argument("--grad-floats", type=int, default=-1,
                     help="size of the gradient set exchanged per step besides the albedo map (default: 60 M fp32 = the "
                          "config-3 decoder parameter set when N > 1, 0 when N = 1)")
@@ -601,7 +633,7 @@ def main():
     args = ap.parse_args()
     if args.workload != "rgca":
         return {"mvp": mvp_main, "urhand": urhand_main, "sg": sg_main, "e2e": e2e_main}[args.workload](args)
-    cfg = dict(CFG, views_per_gpu=args.views)
+    cfg = dict(CFG, views_per_gpu=args.views, coherent_uv=bool(args.coherent_uv))
     while args.views % args.micro:  # micro-batches must divide the views of a rank
         args.micro -= 1
 
@@ -738,7 +770,8 @@ def main():
             "config": {"workload": cfg["workload"], "gaussians": N, "image": [cfg["height"], cfg["width"]],
                        "views_per_gpu": B, "micro_batches": args.micro,
                        "launch": "eager" if graph is None else "hip_graph_replay (kernels_ms_per_call / roofline: eager "
-                                                                "instrumented pass after the timed replays)", "relight": "envmap_4mips", "intersections_per_view": I,
+                                                                "instrumented pass after the timed replays)", "relight": "envmap_4mips", "slab_layout": "uv-coherent" if args.coherent_uv else "random permutation",
+                       "intersections_per_view": I,
                        "mean_alpha": mean_alpha, "parallelism": f"view-parallel x{world}",
                        "rccl_world_size": world,
                        "grad_exchange_bytes_per_step": 4 * (grad_floats + t["albedo"].numel()) if world > 1 else 0},
