@@ -31,12 +31,14 @@ import torch
 import torch.nn.functional as F
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
-# VALU issue ceiling, measured on the bench box class with tools/probe/valu_probe.hip (profiles/r02c_valu_probe.txt):
-# the cheapest instruction class (v_fma_f32 / v_mul_f32) sustains one wave-instruction per 2.94 nominal cycles per SIMD
-# at 8 waves per SIMD; 1024 SIMDs x 2.4 GHz / 2.94 = 836 G wave-instructions/s.  Packed fp32 (7.6 cycles), transcendentals
-# and permlane swaps (8.2) are dearer, so a kernel made of them cannot reach frac = 1.
-VALU_PEAK_GINST = 1024 * 2.4 / 2.94
-VALU_BOUND_CALLS = {"gol_rasterize_fwd": "raster_fwd_kernel", "gol_rasterize_bwd": "raster_bwd_kernel"}
+# VALU issue peak from the guide (MI355X_MICROARCH.md: v_fma_f32 = 2 cycles per wave64 instruction on a SIMD-32; 256 CUs x 4
+# SIMDs x 2.4 GHz / 2 = 1229 G wave-instructions/s).  `frac` is quoted against THIS.  Beside it, as `probe_ceiling`: what
+# tools/probe/valu_probe.hip sustains for the cheapest class on the bench box class (2.94 cycles -> 836 G/s,
+# profiles/r02c_valu_probe.txt; packed fp32 7.6, transcendentals / permlane swaps 8.2 cycles).
+VALU_PEAK_GINST = 1024 * 2.4 / 2.0
+VALU_PROBE_GINST = 1024 * 2.4 / 2.94
+VALU_BOUND_CALLS = {"gol_rasterize_fwd": "raster_fwd_kernel", "gol_rasterize_bwd": "raster_bwd_kernel",
+                    "gol_render_fwd": "raster_fwd_kernel", "gol_render_bwd": "raster_bwd_kernel"}
 
 CFG = dict(workload="rgca_config2_envrelight", gaussians=250_000, slab=500, height=2048, width=1334,
            views_per_gpu=8, focal=3000.0, cam_radius_mm=700.0, n_mips=4, seed=1234)
@@ -62,6 +64,12 @@ def make_inputs(cfg, device, rank=0):
     f_vn[:, 113 + 10] = 1.5 * torch.randn(B, S, S, generator=g)          # opacity logit
     f_vn[:, 113 + 11] = -1.0 + 0.5 * torch.randn(B, S, S, generator=g)   # roughness: sigma ~ 0.04
     f_vc = 0.3 * torch.randn(B, 4, S, S, generator=g)
+    if cfg.get("smooth_normals"):
+        # --smooth-normals: what a convolutional decoder emits -- offsets that vary slowly over the slab (white noise on a
+        # S/25 grid, bilinearly upsampled, same 0.3 standard deviation) instead of SURVEY 8d's per-texel white noise
+        low = torch.randn(B, 4, max(S // 25, 2), max(S // 25, 2), generator=g)
+        f_vc = F.interpolate(low, size=(S, S), mode="bilinear", align_corners=False)
+        f_vc = 0.3 * f_vc / f_vc.std()
     albedo = 0.2 + 0.6 * torch.rand(1, N, 3, generator=g)
     light_sh = 0.3 * torch.randn(B, 3, 81, generator=g) / (1 + torch.arange(81.0)) ** 0.5
     light_sh[:, :, 0] = 1.5
@@ -154,14 +162,25 @@ def _split(n, parts):
 
 
 def run_step(t, cfg, world, graph=None):
-    """One timed step: the compute part (eager, or one replay of its captured HIP graph) + the gradient exchange."""
-    if graph is None:
+    """One timed step: the compute part (eager, or one replay of its captured HIP graph) + the gradient exchange.
+    Exchange modes (N > 1): "overlap" (default) -- step k's reduce-scatter + all-gather is launched asynchronously after
+    step k's compute and waited for right before step k+1 launches its own, so it runs beside step k+1's kernels (the
+    hot-path-only step has no decoder backward of its own to hide it behind); "serial" -- launched and waited for
+    inside the step (--serial-exchange)."""
+    if t.get("stub"):
+        t["albedo"].grad = t["albedo"].detach() * float(t["rank"] + 1)   # launcher self-test: no kernels
+    elif graph is None:
         step(t, cfg, world)
     else:
         graph.replay()
         t["albedo"].grad = t["_albedo_grad"]  # the tensor the captured step writes (GradSync re-points .grad to its bucket)
-    if world > 1:
-        t["_sync"].sync()  # reduce-scatter + all-gather over RCCL
+    sync = t.get("_sync")
+    if sync is not None:
+        if t.get("overlap_exchange"):
+            sync.wait()          # the previous step's exchange
+            sync.launch_all()    # this step's: in flight during the next step's compute
+        else:
+            sync.sync()          # reduce-scatter + all-gather over RCCL, inside the step
 
 
 def make_step_inputs(cfg, device, rank, n_micro):
@@ -220,18 +239,33 @@ def make_roofline(call, ms, views_per_launch, N, I, P, mip_bytes):
     # the rasterizer moves ~1/10 of what HBM could deliver in its run time and keeps the vector ALUs busy instead:
     # report the instruction-issue roofline (and the HBM numbers beside it)
     valu = _stamped("valu.json")
-    insts = busy = None
-    if valu is not None:
-        for k, v in valu.items():
-            if k.startswith(VALU_BOUND_CALLS[call]) and "SQ_INSTS_VALU" in v:
-                insts = v["SQ_INSTS_VALU"] * views_per_launch / 8.0
+    return dict(_valu_roofline(valu, VALU_BOUND_CALLS[call], ms, views_per_launch / 8.0), kernel=call, traffic=traffic,
+                hbm=hbm)
+
+
+def _valu_roofline(record, kernel_prefix, ms, scale=1.0):
+    """Instruction-issue roofline of a VALU-bound kernel from a stamped PMC record (profiles/valu*.json; counters per
+    launch, `scale` = this launch's share of the recorded launch).  achieved = SQ_INSTS_VALU / live duration;
+    peak = the guide's v_fma_f32 rate; useful_lane_frac = SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU): the mean
+    fraction of the 64 lanes that an issued VALU instruction had enabled (exec mask), i.e. issue utilisation x this =
+    lane-level utilisation."""
+    insts = busy = lanes = None
+    if record is not None:
+        for k, v in record.items():
+            if k.startswith(kernel_prefix) and isinstance(v, dict) and "SQ_INSTS_VALU" in v:
+                insts = v["SQ_INSTS_VALU"] * scale
                 if "SQ_ACTIVE_INST_VALU" in v and "GRBM_GUI_ACTIVE" in v:  # quad-cycles over 1024 SIMDs / XCD-summed cycles
                     busy = 4.0 * v["SQ_ACTIVE_INST_VALU"] / 1024.0 / (v["GRBM_GUI_ACTIVE"] / 8.0)
+                if v.get("SQ_THREAD_CYCLES_VALU") and v.get("SQ_ACTIVE_INST_VALU"):
+                    lanes = v["SQ_THREAD_CYCLES_VALU"] / (64.0 * v["SQ_ACTIVE_INST_VALU"])
+                break
     ach = None if insts is None else insts / (ms * 1e-3) / 1e9
-    return {"bound": "valu", "kernel": call, "achieved": ach, "peak": VALU_PEAK_GINST, "unit": "G wave-instructions/s",
-            "frac": None if ach is None else ach / VALU_PEAK_GINST, "valu_busy_frac_pmc": busy,
-            "valu_instructions_per_launch": insts, "traffic": traffic, "hbm": hbm,
-            "evidence": "profiles/valu.json, profiles/traffic.json (rocprofv3 --pmc, same source digest)" if valu else
+    return {"bound": "valu", "achieved": ach, "peak": VALU_PEAK_GINST, "unit": "G wave-instructions/s",
+            "frac": None if ach is None else ach / VALU_PEAK_GINST,
+            "peak_source": "MI355X_MICROARCH.md: v_fma_f32 2 cycles / wave64 / SIMD-32 -> 1024 SIMDs x 2.4 GHz / 2",
+            "probe_ceiling": VALU_PROBE_GINST, "frac_of_probe_ceiling": None if ach is None else ach / VALU_PROBE_GINST,
+            "valu_busy_frac_pmc": busy, "useful_lane_frac": lanes, "valu_instructions_per_launch": insts,
+            "evidence": "profiles/valu*.json, profiles/traffic.json (rocprofv3 --pmc, same source digest)" if insts else
                         "no PMC record for this source digest under profiles/: instruction count unavailable"}
 
 
@@ -290,36 +324,79 @@ def mvp_inputs(cfg, device, rank=0):
     return t
 
 
+def _window_stats(ms_list):
+    """median / min / max of the per-window step times (ms per step)."""
+    if not ms_list:
+        return None
+    v = sorted(ms_list)
+    n = len(v)
+    med = v[n // 2] if n % 2 else 0.5 * (v[n // 2 - 1] + v[n // 2])
+    return {"n": n, "ms_per_step_median": med, "ms_per_step_min": v[0], "ms_per_step_max": v[-1],
+            "spread_frac": (v[-1] - v[0]) / med if med > 0 else None}
+
+
+def _window_plan(steps, n_windows=5):
+    """Split K steps into up to n_windows consecutive windows (sizes differ by at most one)."""
+    w = max(1, min(n_windows, steps))
+    return _split(steps, w)
+
+
 def _time_steps(step, args):
-    """warmup + timed steps of a secondary workload; returns (last output, seconds, mean ms per ABI call)."""
+    """warmup + timed steps of a secondary workload; returns (last output, seconds, mean ms per ABI call, window stats).
+    The K timed steps are ONE region (sync on both sides); HIP events recorded between windows of it give the spread."""
     from goliath_amd import _lib
 
     for _ in range(args.warmup):
         out = step()
     torch.cuda.synchronize()
     _lib.TIMING = []
+    plan = _window_plan(args.steps)
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(len(plan) + 1)]
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step()
+    marks[0].record()
+    for wi, n in enumerate(plan):
+        for _ in range(n):
+            out = step()
+        marks[wi + 1].record()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     timing, _lib.TIMING = _lib.TIMING, None
     per = {}
     for name, e0, e1 in timing:
         per.setdefault(name, []).append(e0.elapsed_time(e1))
-    return out, dt, {k: sum(v) / len(v) for k, v in per.items()}
+    win = _window_stats([marks[i].elapsed_time(marks[i + 1]) / n for i, n in enumerate(plan)])
+    return out, dt, {k: sum(v) / len(v) for k, v in per.items()}, win
 
 
-def _secondary_line(metric, unit, units_per_step, args, dt, ms, alg, config):
+# secondary workloads: which calls are VALU-bound (kernel-name prefix in profiles/valu_secondary.json, produced by
+# tools/secondary_pmc.sh + tools/make_profile_record.py --secondary and stamped with the kernel-source digest)
+SECONDARY_VALU = {"gol_mvp_march_fwd": "march_fwd_kernel", "gol_mvp_march_bwd": "march_bwd_kernel",
+                  "gol_mvp_shadow_march": "march_fwd_kernel", "gol_mesh_raster": "mesh_raster_kernel",
+                  "gol_sg_eval_fwd": "sg_fwd_kernel", "gol_sg_eval_bwd": "sg_bwd_kernel",
+                  "gol_uvlight_phong_fwd": "phong_kernel", "gol_uvlight_phong_bwd": "phong_kernel",
+                  "gol_uvlight_ggx_fwd": "ggx_kernel", "gol_uvlight_ggx_bwd": "ggx_kernel"}
+
+
+def _secondary_line(metric, unit, units_per_step, args, dt, ms, alg, config, windows=None):
+    """JSON line of a secondary workload.  Roofline of the longest call: the instruction-issue roofline (guide peak, PMC
+    instruction count of the stamped record for THIS workload) when the call is VALU-bound and a record of this tree
+    exists, the HBM roofline (algorithmic bytes / live time) otherwise -- with the other one beside it."""
     dom = max(ms, key=ms.get)
     ach = alg.get(dom, 0) / (ms[dom] * 1e-3) / 1e9
+    hbm = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+           "frac": ach / HBM_PEAK_GBS, "traffic": None}
+    roof = hbm
+    rec = _stamped("valu_secondary.json")
+    rec = None if rec is None else rec.get(config["workload"])
+    if dom in SECONDARY_VALU:
+        v = _valu_roofline(rec, SECONDARY_VALU[dom], ms[dom])
+        roof = dict(v, kernel=dom, traffic=None, hbm={k: hbm[k] for k in ("achieved", "peak", "unit", "frac")})
     print(json.dumps({
         "metric": metric, "value": units_per_step * args.steps / dt, "unit": unit, "n_gpus": 1, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic", "config": config, "kernels_ms_per_call": ms,
         "algorithmic_GBs_per_call": {k: alg[k] / (ms[k] * 1e-3) / 1e9 for k in ms if k in alg},
-        "roofline": {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": ach / HBM_PEAK_GBS, "traffic": None}}), flush=True)
+        "roofline": roof, "windows": windows}), flush=True)
 
 
 URHAND_CFG = dict(workload="urhand_config4_uvlight", uv=1024, lights=32, frames_per_gpu=1, seed=4)
@@ -386,7 +463,7 @@ def urhand_main(args):
         torch.autograd.backward([diff, spec, feat, rgb], [t["u1"], t["u2"], t["u3"], t["u4"]])
         return rgb
 
-    _, dt, ms = _time_steps(step, args)
+    _, dt, ms, win = _time_steps(step, args)
     T = B * S * S
     sh = 4 * L * T  # the shadow map is the dominant stream: one float per texel per light
     alg = {"gol_mesh_raster": B * L * (8 * 1024 * 1024 + 64 * 5120),  # index + depth images out, face records
@@ -396,7 +473,7 @@ def urhand_main(args):
     _secondary_line("URHand UV light-loop frames/sec (Phong + GGX, fwd+bwd), 1024x1024 texels x 32 lights",
                     "frames/s", B, args, dt, ms, alg,
                     {"workload": cfg["workload"], "uv": [S, S], "lights": L, "frames_per_gpu": B,
-                     "shadow_depth_render": "32 x 1024^2 mesh z-buffer renders of a 5120-face closed mesh per frame"})
+                     "shadow_depth_render": "32 x 1024^2 mesh z-buffer renders of a 5120-face closed mesh per frame"}, windows=win)
 
 
 SG_CFG = dict(workload="sgutils_native", gaussians=1_048_576, views=8, lights=8, seed=7)
@@ -426,10 +503,10 @@ def sg_main(args):
         out.backward(t["up"])
         return out
 
-    _, dt, ms = _time_steps(step, args)
+    _, dt, ms, win = _time_steps(step, args)
     alg = {"gol_sg_eval_fwd": 40 * B * N, "gol_sg_eval_bwd": 56 * B * N}
     _secondary_line("sgutils evaluate_gaussian Gaussians/sec (fwd+bwd), 8 lights", "Gaussians/s", B * N, args, dt, ms, alg,
-                    {"workload": cfg["workload"], "gaussians": N, "views": B, "lights": L})
+                    {"workload": cfg["workload"], "gaussians": N, "views": B, "lights": L}, windows=win)
 
 
 def mvp_main(args):
@@ -451,13 +528,13 @@ def mvp_main(args):
         (out - t["target"]).abs().mean().backward()
         return out
 
-    out, dt, ms = _time_steps(step, args)
+    out, dt, ms, win = _time_steps(step, args)
     P = H * W
     tpl_bytes = t["template"].numel() * 4
     alg = {"gol_mvp_march_fwd": 32 * P + 28 * P + tpl_bytes, "gol_mvp_march_bwd": 32 * P + 28 * P + 3 * tpl_bytes}
     _secondary_line("MVP ray-march views/sec (fwd+bwd) at 2048x1334, 4096 primitives", "views/s", 1, args, dt, ms, alg,
                     {"workload": cfg["workload"], "prims": cfg["prims"], "template": list(cfg["tdim"]),
-                     "image": [H, W], "stepsize": 1.0 / 64, "mean_alpha": float(out[..., 3].mean())})
+                     "image": [H, W], "stepsize": 1.0 / 64, "mean_alpha": float(out[..., 3].mean())}, windows=win)
 
 
 E2E_CFG = dict(workload="rgca_e2e_native_slab1024", slab=1024, height=2048, width=1334, views_per_gpu=8, focal=3000.0,
@@ -605,7 +682,9 @@ def e2e_main(args):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=1,
+                    help="N > 1 without torchrun: this script re-executes itself as N ranks (one per GPU) under "
+                         "torch.distributed.run; under torchrun WORLD_SIZE must equal N.  Never a silent N = 1")
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -614,13 +693,27 @@ def main():
     ap.add_argument("--coherent-uv", action="store_true",
                     help="lay the synthetic Gaussians out over the slab like a UV atlas (slab neighbours = spatial neighbours) "
                          "instead of the default random permutation; the point set is the same")
+    ap.add_argument("--smooth-normals", action="store_true",
+                    help="decoder-like low-frequency normal offsets (f_vcond smooth over the slab) instead of SURVEY 8d's "
+                         "white noise; with --coherent-uv this is the realistic case for the env-map gathers")
     ap.add_argument("--grad-floats", type=int, default=-1,
                     help="size of the gradient set exchanged per step besides the albedo map (default: 60 M fp32 = the "
                          "config-3 decoder parameter set when N > 1, 0 when N = 1)")
+    ap.add_argument("--serial-exchange", action="store_true",
+                    help="N > 1: wait for the gradient exchange inside the step instead of overlapping it with the next "
+                         "step's compute")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="functional test mode for a 1-GPU box: the N ranks share the visible GPU(s) and exchange "
+                         "gradients over gloo with device tensors (RCCL refuses two ranks on one device); the line says so "
+                         "and is not a scaling measurement")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="create the process group (RCCL) even for one rank and route the gradient exchange through it: "
+                         "HIP-graph capture / replay next to a live RCCL communicator on a 1-GPU box")
+    ap.add_argument("--stub", action="store_true",
+                    help="launcher self-test on CPU (gloo): no kernels, no measurement -- checks the rank plumbing and "
+                         "the gradient exchange of the N-rank command line")
     ap.add_argument("--no-graph", action="store_true",
-                    help="time eager launches instead of replays of the step captured as one HIP graph.  The ~120 launches "
-                         "of a step cost the host almost as long as the GPU needs to run them, so the eager number moves "
-                         "with host load (1.7-2.2 k views/s observed); replay is host-independent.  Per-call HIP events "
+                    help="time eager launches instead of replays of the step captured as one HIP graph.  Per-call HIP events "
                          "cannot be taken inside a graph: they come from an eager pass right after the timed replays")
     ap.add_argument("--workload", choices=["rgca", "mvp", "urhand", "sg", "e2e"], default="rgca",
                     help="rgca = the BASELINE metric (default); mvp = secondary BASELINE config 5 line")
@@ -631,53 +724,63 @@ def main():
     ap.add_argument("--no-ssim", action="store_true", help="e2e: L1 loss only (default: 10*L1 + 0.2*(1-SSIM))")
     ap.add_argument("--segments", action="store_true", help="e2e: also report per-segment times (adds a sync per step)")
     args = ap.parse_args()
+    from goliath_amd import launch
+
+    # N > 1 asked for and not started by torchrun: become the launcher of N ranks (the driver's own command line)
+    rc = launch.maybe_spawn(args.gpus)
+    if rc is not None:
+        sys.exit(rc)
     if args.workload != "rgca":
         return {"mvp": mvp_main, "urhand": urhand_main, "sg": sg_main, "e2e": e2e_main}[args.workload](args)
-    cfg = dict(CFG, views_per_gpu=args.views, coherent_uv=bool(args.coherent_uv))
+    cfg = dict(CFG, views_per_gpu=args.views, coherent_uv=bool(args.coherent_uv), smooth_normals=bool(args.smooth_normals))
     while args.views % args.micro:  # micro-batches must divide the views of a rank
         args.micro -= 1
-
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
-    if world > 1:
-        import torch.distributed as dist
-
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
-    from goliath_amd import _lib, splat
-
-    t = make_step_inputs(cfg, dev, rank, args.micro)
+    try:
+        D = launch.init(args.gpus, share_gpu=args.share_gpu, cpu=args.stub, force_group=args.force_dist)
+    except launch.LaunchError as e:
+        raise SystemExit(f"bench.py: {e}")
+    world, rank, dev = D.world, D.rank, D.device
+    on_gpu = dev.type == "cuda"
     from goliath_amd import parallel
+
+    if args.stub:
+        t = {"stub": True, "rank": rank, "albedo": torch.nn.Parameter(torch.arange(1000.0) / 1000.0), "micro": []}
+    else:
+        from goliath_amd import _lib, splat
+
+        t = make_step_inputs(cfg, dev, rank, args.micro)
 
     # Gradient exchange of the step.  Mode A has a single trainable tensor on the path (the albedo map, 3 MB); BASELINE
     # config 3 specifies the exchange of the 512^2-slab RGCA decoder parameter set (~60 M fp32) every step, so
     # for N > 1 a gradient set of that size travels with it (its values are irrelevant to the timing; in training it is
     # produced by the decoder backward, which is not part of mode A) -- a SCALE line must pay the real message size.
-    grad_floats = args.grad_floats if args.grad_floats >= 0 else (60_000_000 if world > 1 else 0)
+    exchanging = D.backend != "none"
+    grad_floats = args.grad_floats if args.grad_floats >= 0 else (60_000_000 if world > 1 and not args.stub else 0)
     dec = [torch.nn.Parameter(torch.zeros(n, device=dev)) for n in _split(grad_floats, 4)]
     for p in dec:
         p.grad = torch.zeros_like(p)
-    t["_sync"] = parallel.GradSync([t["albedo"]] + dec)
+    t["_sync"] = parallel.GradSync([t["albedo"]] + dec, single_rank_collectives=args.force_dist) if exchanging else None
+    t["overlap_exchange"] = exchanging and not args.serial_exchange
     B, N = cfg["views_per_gpu"], cfg["gaussians"]
     P = cfg["height"] * cfg["width"]
 
-    def barrier():
-        if world > 1:
-            import torch.distributed as dist
+    def drain():
+        if t["_sync"] is not None and t["overlap_exchange"]:
+            t["_sync"].wait()   # the last step's exchange belongs to the timed region
 
-            dist.barrier()
-        torch.cuda.synchronize()
+    def mark():
+        if not on_gpu:
+            return time.perf_counter()
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        return e
 
     for _ in range(args.warmup):
         run_step(t, cfg, world)
-    barrier()
+    drain()
+    D.barrier()
     graph = None
-    if not args.no_graph:
+    if not args.no_graph and on_gpu:
         # The step is ~60 launches per micro-batch; issued from Python they cost about as much host time as the GPU
         # needs to execute them.  Capture the whole compute step (both streams, forward + backward) in ONE HIP graph
         # and replay it: the timed loop is then launch-overhead-free.  Capacities are frozen at their calibrated
@@ -686,10 +789,11 @@ def main():
         splat.PLANNER.frozen = True
         try:
             graph = torch.cuda.CUDAGraph()
-            # thread_local: other threads (e.g. the RCCL watchdog of a multi-GPU run) may keep issuing HIP calls
+            # thread_local: other threads (the RCCL watchdog of a multi-GPU run) keep issuing HIP calls meanwhile
             with torch.cuda.graph(graph, capture_error_mode="thread_local"):
                 step(t, cfg, world)
             run_step(t, cfg, world, graph)  # one untimed replay
+            drain()
         except Exception as e:  # capture is an optimisation: fall back to eager issue
             print(f"bench.py: HIP-graph capture failed ({type(e).__name__}: {e}); timing eager launches", file=sys.stderr)
             graph = None
@@ -697,42 +801,85 @@ def main():
             splat.PLANNER.frozen_log.clear()
             torch.cuda.synchronize()
             run_step(t, cfg, world)
-        barrier()
-    if graph is None:
+            drain()
+        D.barrier()
+    if graph is None and on_gpu:
         _lib.TIMING = []
+    # the K timed steps are ONE region (barrier + synchronize on both sides); events recorded between up to five windows
+    # of it give the spread without adding a sync
+    plan = _window_plan(args.steps)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        run_step(t, cfg, world, graph)
-    barrier()
+    marks = [mark()]
+    for n in plan:
+        for _ in range(n):
+            run_step(t, cfg, world, graph)
+        marks.append(mark())
+    drain()
+    D.barrier()
     dt = time.perf_counter() - t0
-    if graph is not None:
-        splat.PLANNER.check_frozen()  # raises if a replayed render overflowed its intersection capacity
-        splat.PLANNER.frozen = False
-        # HIP events cannot bracket nodes inside a captured graph: the per-call durations come from an eager,
-        # instrumented pass of the same K steps right after the timed replays (same buffers, same streams)
-        # (the micro-batches are issued on ONE stream here, so a call's events bracket that kernel sequence alone and the
-        # durations agree with rocprofv3's per-kernel trace; with two streams in flight they would include time-sharing)
-        streams, t["streams"] = t["streams"], [torch.cuda.current_stream()] * len(t["streams"])
-        _lib.TIMING = []
+    win_ms = [(marks[i].elapsed_time(marks[i + 1]) if on_gpu else 1e3 * (marks[i + 1] - marks[i])) / n
+              for i, n in enumerate(plan)]
+    exchange_ms = None
+    if exchanging and args.steps > 0:
+        # the exchange alone, serial, right after the timed region (same buffers): what it costs when nothing hides it
+        D.barrier()
+        te = time.perf_counter()
         for _ in range(args.steps):
-            run_step(t, cfg, world)
-        barrier()
-        t["streams"] = streams
-    timing, _lib.TIMING = _lib.TIMING, None
-    splat.PLANNER.poll(block=True)  # raises if any step overflowed its intersection capacity
-
-    if world > 1:
-        import torch.distributed as dist
-
-        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax)
+            t["_sync"].launch_all()
+            t["_sync"].wait()
+        D.barrier()
+        exchange_ms = 1e3 * D.max_over_ranks(time.perf_counter() - te) / args.steps
+    timing = []
+    if on_gpu:
+        if graph is not None:
+            splat.PLANNER.check_frozen()  # raises if a replayed render overflowed its intersection capacity
+            splat.PLANNER.frozen = False
+            # HIP events cannot bracket nodes inside a captured graph: the per-call durations come from an eager,
+            # instrumented pass of the same K steps right after the timed replays (same buffers, same streams)
+            # (the micro-batches are issued on ONE stream here, so a call's events bracket that kernel sequence alone and the
+            # durations agree with rocprofv3's per-kernel trace; with two streams in flight they would include time-sharing)
+            streams, t["streams"] = t["streams"], [torch.cuda.current_stream()] * len(t["streams"])
+            _lib.TIMING = []
+            sync_keep, t["_sync"] = t["_sync"], None   # compute only
+            for _ in range(args.steps):
+                run_step(t, cfg, world)
+            t["_sync"] = sync_keep
+            D.barrier()
+            t["streams"] = streams
+        timing, _lib.TIMING = _lib.TIMING, None
+        splat.PLANNER.poll(block=True)  # raises if any step overflowed its intersection capacity
+    dt = D.max_over_ranks(dt)
     per_call = {}
     for name, e0, e1 in timing:
         per_call.setdefault(name, []).append(e0.elapsed_time(e1))
     kernels_ms = {k: sum(v) / len(v) for k, v in per_call.items()}
+    stub_ok = None
+    if args.stub:
+        # every rank's "gradient" was albedo * (rank + 1): the average is albedo * (world + 1) / 2
+        want = t["albedo"].detach() * (world + 1) / 2.0
+        stub_ok = bool(torch.allclose(t["albedo"].grad, want, atol=1e-6)) if exchanging else None
 
     if rank == 0:
+        views = B * world * args.steps
+        par = {"parallelism": f"view-parallel x{world}", "rccl_world_size": world if D.backend == "nccl" else 0,
+               "world_size": world, "dist_backend": D.backend,
+               "ranks_share_gpu": bool(D.shared_gpu),
+               "grad_exchange_bytes_per_step": 4 * (grad_floats + t["albedo"].numel()) if exchanging else 0,
+               "grad_exchange": None if not exchanging else (
+                   "reduce-scatter + all-gather of step k overlapped with the compute of step k+1 (waited before the next "
+                   "launch; the last one inside the timed region)" if t["overlap_exchange"] else
+                   "reduce-scatter + all-gather inside the step (serial)"),
+               "grad_exchange_ms_alone": exchange_ms}
+        if args.stub:
+            print(json.dumps({"metric": "STUB launcher self-test (no kernels ran; not a measurement)", "value": views / dt,
+                              "unit": "stub steps x views/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                              "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
+                              "vs_baseline": None, "dtype": "f32", "data": "stub", "config": dict(par, workload="stub"),
+                              "stub_gradients_averaged": stub_ok}), flush=True)
+            D.shutdown()
+            if stub_ok is False:
+                sys.exit(3)
+            return
         # measured intersection count (determines the raster/sort work)
         with torch.no_grad():
             from goliath_amd import render_gs, shade
@@ -761,32 +908,31 @@ def main():
             per_call[k] = {"GBs": round(gbs, 1), "hbm_frac": round(gbs / HBM_PEAK_GBS, 4),
                            "traffic_over_algorithmic": None if tr is None or k not in tr else
                            round(tr[k] * views_per_launch / 8.0 / alg, 3)}
-        views = B * world * args.steps
         res = {
             "metric": "relit views/sec (fwd+bwd) at 2048x1334, 250k Gaussians",
             "value": views / dt, "unit": "views/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": cfg["workload"], "gaussians": N, "image": [cfg["height"], cfg["width"]],
-                       "views_per_gpu": B, "micro_batches": args.micro,
-                       "launch": "eager" if graph is None else "hip_graph_replay (kernels_ms_per_call / roofline: eager "
-                                                                "instrumented pass after the timed replays)", "relight": "envmap_4mips", "slab_layout": "uv-coherent" if args.coherent_uv else "random permutation",
-                       "intersections_per_view": I,
-                       "mean_alpha": mean_alpha, "parallelism": f"view-parallel x{world}",
-                       "rccl_world_size": world,
-                       "grad_exchange_bytes_per_step": 4 * (grad_floats + t["albedo"].numel()) if world > 1 else 0},
+            "config": dict({"workload": cfg["workload"], "gaussians": N, "image": [cfg["height"], cfg["width"]],
+                            "views_per_gpu": B, "micro_batches": args.micro,
+                            "launch": "eager" if graph is None else "hip_graph_replay (kernels_ms_per_call / roofline: "
+                                                                     "eager instrumented pass after the timed replays)",
+                            "relight": "envmap_4mips",
+                            "slab_layout": "uv-coherent" if args.coherent_uv else "random permutation",
+                            "normal_offsets": "smooth (decoder-like)" if args.smooth_normals else "white noise (SURVEY 8d)",
+                            "intersections_per_view": I, "mean_alpha": mean_alpha}, **par),
+            "windows": _window_stats(win_ms),
             "kernels_ms_per_call": kernels_ms,
             "roofline": roofline,
             "hbm_per_call": per_call,
         }
+        if D.shared_gpu:
+            res["note"] = ("ranks share one GPU and exchange over gloo: a functional run of the N-rank path, NOT a scaling "
+                           "measurement")
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(cfg)
         print(json.dumps(res), flush=True)
-    if world > 1:
-        import torch.distributed as dist
-
-        dist.barrier()
-        dist.destroy_process_group()
+    D.shutdown()
 
 
 if __name__ == "__main__":

@@ -69,20 +69,37 @@ class GradSync:
     Every bucket owns ONE persistent flat buffer; the `.grad` of its parameters are views into it, so autograd
     accumulates straight into the communication buffer -- no flatten / copy-back passes over the gradients.  Buckets are
     filled in reverse parameter order (the order backward produces gradients); a post-accumulate hook per parameter
-    counts arrivals and launches the bucket's collectives asynchronously as soon as its last gradient is in, while
-    backward keeps computing the earlier layers.  `finish()` (or `sync()`) after `backward()` launches what is left
-    (buckets holding parameters that received no gradient contribute zeros for them) and waits.
+    marks arrivals, and a bucket's collectives are launched asynchronously once its last gradient is in AND every bucket
+    before it has been launched, while backward keeps computing the earlier layers.  `finish()` (or `sync()`) after
+    `backward()` launches what is left (buckets holding parameters that received no gradient contribute zeros for
+    them) and waits.
+
+    Launch order.  Collectives are matched across ranks by ISSUE ORDER, so the order must not depend on the local
+    autograd schedule: buckets are launched strictly in index order (0, 1, 2 ...) on every rank, from the hooks as far
+    as the ready prefix reaches and the rest from `finish()`.  A rank whose graph leaves a parameter unused (or that
+    skipped backward because it had no views) therefore launches the same sequence, only later -- the sizes always
+    pair up.  What all ranks must still agree on: the parameter list, the bucket size and one `finish()` per step.
+
+    One backward per step.  A second gradient arrival for a parameter before `finish()` (gradient accumulation, a
+    `retain_graph` second loss) would add local gradients to a bucket that is already averaged or still in flight:
+    it raises.  Accumulate under `no_sync()` (hooks only keep the `.grad` views; nothing is launched) and run the last
+    micro-batch outside it, or call `finish()` between the backwards.
 
     Use `sync.zero_grad()` instead of `optimizer.zero_grad()`: it zeroes the flat buffers and keeps the views.  If a
     `.grad` is replaced behind its back (zero_grad(set_to_none=True), a fresh tensor from autograd), the hook copies it
     into the bucket and re-points `.grad` -- correct, one extra copy for that parameter.
+
+    `launch_all()` / `wait()` split `finish()` for callers that overlap the exchange with work of their own (bench.py
+    overlaps step k's exchange with step k+1's compute).  `single_rank_collectives=True` issues the collectives even in
+    a process group of one rank (a test hook: it puts a live RCCL communicator on a 1-GPU box).
     """
 
     def __init__(self, params: Iterable[torch.nn.Parameter], bucket_bytes: int = 256 << 20, average: bool = True,
-                 overlap: bool = True):
+                 overlap: bool = True, single_rank_collectives: bool = False):
         self.params = [p for p in params if p.requires_grad]
         self.average = average
         self.overlap = overlap
+        self.single_rank_collectives = single_rank_collectives
         self.buckets: List[List[torch.nn.Parameter]] = []
         cur, size = [], 0
         for p in reversed(self.params):  # gradients arrive last-layer first
@@ -97,14 +114,24 @@ class GradSync:
         self._flat: List[torch.Tensor] = []     # per bucket: padded flat gradient buffer
         self._shard: List[torch.Tensor] = []    # per bucket: this rank's 1/world slice (reduce-scatter output)
         self._view = {}                          # id(param) -> (bucket index, view into the flat buffer)
+        self._seen = set()                       # id(param) of the gradients that arrived this step
         self._arrived: List[int] = []
         self._work: List[list] = []
         self._launched: List[bool] = []
+        self._next = 0                           # first bucket not launched yet (launches are in index order)
         self._hooks = []
         self._built_for = None
         self._avg_op = False
+        self._rs_ag = True                       # reduce-scatter + all-gather available (else: all-reduce)
+        self._accumulating = False               # inside no_sync()
 
     # ---------------------------------------------------------------------------------------------------------
+    def _active(self, w: int) -> bool:
+        """Is there anything to exchange?  (no process group, or one rank without the test hook: no)"""
+        if not (dist.is_available() and dist.is_initialized()):
+            return False
+        return w > 1 or self.single_rank_collectives
+
     def _build(self, w: int):
         """Allocate the flat buffers (first use, or the world size changed) and point the .grad views into them."""
         self._flat, self._shard, self._view = [], [], {}
@@ -125,30 +152,48 @@ class GradSync:
         for h in self._hooks:
             h.remove()
         self._hooks = []
-        if self.overlap and w > 1:
+        if self.overlap and self._active(w):
             for p in self.params:
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
         self._built_for = w
-        self._avg_op = self._probe_avg(w)
+        self._avg_op, self._rs_ag = False, True
+        if self._active(w) and self._flat:
+            self._rs_ag = self._probe_rs_ag(w)
+            self._avg_op = self._rs_ag and self._probe_avg(w)
         self._reset()
+
+    def _probe_rs_ag(self, w: int) -> bool:
+        """Does the backend reduce-scatter / all-gather tensors of this device?  (RCCL: yes.  gloo: CPU tensors yes;
+        device tensors depend on the build -- then the bucket goes through one all-reduce instead.)  Every rank runs
+        the same probe on the same kind of tensor, so all ranks reach the same answer."""
+        try:
+            src = torch.ones(w, dtype=self._flat[0].dtype, device=self._flat[0].device)
+            dst = torch.empty(1, dtype=src.dtype, device=src.device)
+            dist.reduce_scatter_tensor(dst, src)
+            dist.all_gather_into_tensor(src, dst)
+            return bool(abs(float(src[0]) - w) < 1e-6)
+        except Exception:  # noqa: BLE001 -- an unsupported op must not take the job down
+            return False
 
     def _probe_avg(self, w: int) -> bool:
         """Can the backend average inside the collective (RCCL: ReduceOp.AVG)?  Probed once with a tiny synchronous
         reduce-scatter; any refusal falls back to dividing the bucket before the sum (gloo always does)."""
-        if not self.average or w == 1 or dist.get_backend() != "nccl" or not self._flat:
+        if not self.average or dist.get_backend() != "nccl":
             return False
         try:
             src = torch.ones(w, dtype=self._flat[0].dtype, device=self._flat[0].device)
             dst = torch.empty(1, dtype=src.dtype, device=src.device)
             dist.reduce_scatter_tensor(dst, src, op=dist.ReduceOp.AVG)
             return bool(abs(float(dst) - 1.0) < 1e-6)
-        except Exception:  # noqa: BLE001 -- an unsupported op must not take the job down
+        except Exception:  # noqa: BLE001
             return False
 
     def _reset(self):
         self._arrived = [0] * len(self.buckets)
         self._launched = [False] * len(self.buckets)
         self._work = [[] for _ in self.buckets]
+        self._seen = set()
+        self._next = 0
 
     def _adopt(self, p):
         """Make sure p.grad IS the bucket view (copy a foreign gradient tensor in once)."""
@@ -161,26 +206,66 @@ class GradSync:
         return bi
 
     def _on_grad(self, p):
-        bi = self._adopt(p)
+        bi, _ = self._view[id(p)]
+        if self._accumulating:
+            self._adopt(p)       # keep .grad a view of the bucket; nothing is counted or launched
+            return
+        if self._launched[bi]:
+            raise RuntimeError(
+                "GradSync: a gradient arrived for a parameter whose bucket is already being averaged (a second "
+                "backward() before finish() / wait()).  Accumulate under `with sync.no_sync():` and run the last "
+                "backward outside it, or call finish() between the backwards.")
+        if id(p) in self._seen:
+            self._adopt(p)       # bucket still local: autograd accumulated in place, nothing else to do
+            return
+        self._seen.add(id(p))
+        self._adopt(p)
         self._arrived[bi] += 1
-        if self._arrived[bi] == len(self.buckets[bi]) and not self._launched[bi]:
-            self._launch(bi)
+        self._drain()
+
+    def _drain(self):
+        """Launch the ready prefix: bucket i only after buckets 0..i-1 (the issue order is what pairs collectives
+        across ranks, so it may not follow the local autograd completion order)."""
+        while self._next < len(self.buckets) and self._arrived[self._next] == len(self.buckets[self._next]):
+            self._launch(self._next)
 
     def _launch(self, bi: int):
+        assert bi == self._next, "buckets are launched in index order"
         w = self._built_for
         flat, shard = self._flat[bi], self._shard[bi]
         avg_op = self._avg_op   # RCCL reduces with AVG natively (probed); otherwise divide first, sum in the collective
-        if self.average and not avg_op:
+        if self.average and not avg_op and w > 1:
             flat.div_(w)
-        h1 = dist.reduce_scatter_tensor(shard, flat, op=dist.ReduceOp.AVG if avg_op else dist.ReduceOp.SUM,
-                                        async_op=True)   # every rank reduces 1/w of the bucket
-        if dist.get_backend() != "nccl":
-            h1.wait()   # RCCL orders the two collectives on its stream; gloo's worker threads do not
-        h2 = dist.all_gather_into_tensor(flat, shard, async_op=True)   # ... and shares it
-        self._work[bi] = [h1, h2]
+        if self._rs_ag:
+            h1 = dist.reduce_scatter_tensor(shard, flat, op=dist.ReduceOp.AVG if avg_op else dist.ReduceOp.SUM,
+                                            async_op=True)   # every rank reduces 1/w of the bucket
+            if dist.get_backend() != "nccl":
+                h1.wait()   # RCCL orders the two collectives on its stream; gloo's worker threads do not
+            h2 = dist.all_gather_into_tensor(flat, shard, async_op=True)   # ... and shares it
+            self._work[bi] = [h1, h2]
+        else:
+            self._work[bi] = [dist.all_reduce(flat, async_op=True)]
         self._launched[bi] = True
+        self._next = bi + 1
 
     # ---------------------------------------------------------------------------------------------------------
+    class _NoSync:
+        def __init__(self, owner):
+            self.owner = owner
+
+        def __enter__(self):
+            self.owner._accumulating = True
+            return self.owner
+
+        def __exit__(self, *exc):
+            self.owner._accumulating = False
+            return False
+
+    def no_sync(self):
+        """Context for gradient accumulation: backward() calls inside only accumulate into the bucket views.  The
+        backward that ends the step runs outside (its hooks launch the buckets), then finish()."""
+        return GradSync._NoSync(self)
+
     def zero_grad(self):
         """Zero the gradients in place (keeps the bucket views; replaces optimizer.zero_grad())."""
         _, w = world()
@@ -190,22 +275,32 @@ class GradSync:
             flat.zero_()
         self._reset()
 
-    def finish(self):
-        """After backward: launch the buckets that are not in flight yet, wait for all of them."""
+    def launch_all(self):
+        """After backward: launch, in index order, every bucket that is not in flight yet (does not wait)."""
         _, w = world()
-        if w == 1:
+        if not self._active(w):
             return
         if self._built_for != w:
             self._build(w)     # first use without zero_grad(): adopt the existing .grad tensors
-        for bi, ps in enumerate(self.buckets):
-            if not self._launched[bi]:
-                for p in ps:
-                    self._adopt(p)   # (a parameter that received no gradient contributes zeros)
-                self._launch(bi)
+        for bi in range(self._next, len(self.buckets)):
+            for p in self.buckets[bi]:
+                self._adopt(p)   # (a parameter that received no gradient contributes zeros)
+            self._launch(bi)
+
+    def wait(self):
+        """Wait for the launched collectives (the current stream waits on RCCL's; gloo blocks the host)."""
         for hs in self._work:
             for h in hs:
                 h.wait()
         self._reset()
+
+    def finish(self):
+        """After backward: launch the buckets that are not in flight yet, wait for all of them."""
+        _, w = world()
+        if not self._active(w):
+            return
+        self.launch_all()
+        self.wait()
 
     def sync(self):
         """Average (or sum) .grad over all ranks, in place.  Call after backward, before clipping."""

@@ -67,6 +67,51 @@ def main():
     loss.backward()
     sync2.finish()
     check("set_to_none")
+    # (4) launch order is the bucket order on every rank, whatever the local autograd order: rank 1 leaves the LAST
+    # parameter (= bucket 0) unused, so its hooks can launch nothing and finish() issues the whole sequence, while rank 0
+    # launches everything from its hooks -- the collectives (all of different sizes) must still pair up
+    sync2.close()
+    extra2 = torch.nn.Parameter(torch.ones(5))
+    sync3 = parallel.GradSync(list(model.parameters()) + [extra2], bucket_bytes=16)
+    assert len(sync3.buckets) >= 3 and len(sync3.buckets[0]) == 1 and sync3.buckets[0][0] is extra2
+    sync3.zero_grad()
+    loss = ((model(mine["x"]) - mine["y"]) ** 2).sum() * world / B
+    if rank == 0:
+        loss = loss + extra2.sum() * 2.0
+    loss.backward()
+    if rank == 0:
+        assert all(sync3._launched)
+    else:
+        assert not any(sync3._launched), "bucket 0 never became ready here: nothing may overtake it"
+    sync3.finish()
+    check("ordered")
+    assert torch.allclose(extra2.grad, torch.full((5,), 2.0 / world)), extra2.grad
+    # (5) a second backward before finish() must not silently add local gradients to averaged buckets
+    sync3.zero_grad()
+    loss = ((model(mine["x"]) - mine["y"]) ** 2).sum() * world / B + extra2.sum()
+    loss.backward(retain_graph=True)
+    try:
+        loss.backward()
+        raise AssertionError("second backward before finish() went unnoticed")
+    except RuntimeError as e:
+        assert "no_sync" in str(e)
+    sync3.finish()
+    # (6) accumulation under no_sync(): two half-batches == the full batch
+    sync3.zero_grad()
+    half = mine["x"].shape[0] // 2
+    with sync3.no_sync():
+        (((model(mine["x"][:half]) - mine["y"][:half]) ** 2).sum() * world / B).backward()
+        assert not any(sync3._launched)
+    (((model(mine["x"][half:]) - mine["y"][half:]) ** 2).sum() * world / B + 0.0 * extra2.sum()).backward()
+    assert all(sync3._launched)
+    sync3.finish()
+    check("no_sync")
+    # (7) launch_all() / wait() split (what bench.py uses to overlap the exchange with the next step's compute)
+    sync3.zero_grad()
+    (((model(mine["x"]) - mine["y"]) ** 2).sum() * world / B).backward()
+    sync3.launch_all()
+    sync3.wait()
+    check("split")
     gn = parallel.global_grad_norm(model.parameters())
     gathered = [torch.zeros(()) for _ in range(world)]
     dist.all_gather(gathered, gn)

@@ -1,0 +1,67 @@
+"""CPU: the N-rank command line of bench.py (`--gpus N`) -- it must launch N ranks itself or fail loudly, never report a
+one-rank run as N GPUs (the driver's SCALE runs use exactly this command).  The kernels need a GPU, so the
+launcher is driven here with `--stub` (no kernels, gloo, CPU tensors): rank plumbing + the gradient exchange."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def _run(args, env=None, timeout=300):
+    e = dict(os.environ if env is None else env, OMP_NUM_THREADS="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        if env is None:
+            e.pop(k, None)
+    return subprocess.run([sys.executable, BENCH] + args, capture_output=True, text=True, timeout=timeout, env=e)
+
+
+def _json_line(stdout):
+    lines = [l for l in stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, stdout
+    return json.loads(lines[0])
+
+
+def test_gpus_2_spawns_two_ranks_and_exchanges_gradients():
+    r = _run(["--gpus", "2", "--stub", "--steps", "4", "--warmup", "1"])
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    line = _json_line(r.stdout)
+    assert line["n_gpus"] == 2 and line["config"]["world_size"] == 2
+    assert line["config"]["dist_backend"] == "gloo" and line["data"] == "stub"
+    assert line["stub_gradients_averaged"] is True
+    assert "overlapped" in line["config"]["grad_exchange"]
+    assert line["config"]["grad_exchange_bytes_per_step"] == 4000
+
+
+def test_gpus_2_serial_exchange():
+    r = _run(["--gpus", "2", "--stub", "--steps", "2", "--warmup", "1", "--serial-exchange"])
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    line = _json_line(r.stdout)
+    assert line["n_gpus"] == 2 and "serial" in line["config"]["grad_exchange"] and line["stub_gradients_averaged"] is True
+
+
+def test_gpus_2_without_gpus_fails_loudly():
+    """No GPU here: the real workload must refuse (non-zero exit, a reason), not fall back to one rank or to the CPU."""
+    r = _run(["--gpus", "2", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"])
+    assert r.returncode != 0
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")], r.stdout
+    assert "no GPU visible" in r.stderr or "needs" in r.stderr, r.stderr[-2000:]
+
+
+def test_world_size_mismatch_is_an_error():
+    """Started by a launcher with a different world size than --gpus says: refuse to mislabel the line."""
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29577")
+    r = _run(["--gpus", "4", "--stub", "--steps", "1", "--warmup", "0"], env=env)
+    assert r.returncode != 0 and "WORLD_SIZE=1" in r.stderr, r.stderr[-2000:]
+
+
+def test_spawn_command_is_the_drivers_command_line():
+    sys.path.insert(0, ROOT)
+    from goliath_amd import launch
+
+    cmd = launch.spawn_command(8, ["bench.py", "--gpus", "8"], port=1234)
+    assert cmd[1:] == ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=8", "--master-addr", "127.0.0.1",
+                       "--master-port", "1234", "bench.py", "--gpus", "8"]
+    assert launch.maybe_spawn(1) is None
