@@ -4,9 +4,12 @@
     rasterize(v_pix, vi, h, w)              drtk.rasterize + drtk.render (:44-46): index_img, depth_img, bary_img
     RenderLayer(h, w, vi, vt, vti)          ca_code/utils/render_drtk.py:14-82 (same constructor / forward / dict keys)
 drtk is a third-party dependency that is NOT in the reference tree (requirements.txt:6); the sampling conventions are
-stated in csrc/meshraster.hip.  Forward only: the hot-path consumer is the shadow-map depth render
-(ca_code/utils/shadowmap.py:39-50, under no_grad in ca_code/models/urhand.py:404,492); drtk's edge-gradient estimator
-has no counterpart here, so a differentiable call raises instead of silently dropping gradients.
+stated in csrc/meshraster.hip (pixel centres at (j + 0.5, i + 0.5), as pytorch3d's cameras_from_opencv_projection places
+them for the reference's other back-end, render_pytorch3d.py:49-51; if drtk samples at integer coordinates instead the
+shadow depth map is shifted by half a pixel -- not verifiable here, and below the 3x3 PCF footprint of its only consumer).
+The hot-path consumer is the shadow-map depth render (ca_code/utils/shadowmap.py:39-50, under no_grad in
+ca_code/models/urhand.py:404,492).  Texture gradients flow (autograd through grid_sample); drtk's edge-gradient
+estimator (vertex gradients) has no counterpart here, so a call that needs it raises instead of silently dropping them.
 """
 import ctypes
 from typing import List, Optional
@@ -80,9 +83,13 @@ class RenderLayer(torch.nn.Module):
                 edge_grad: bool = True):
         assert output_filters is None
         assert background is None
-        if torch.is_grad_enabled() and (verts.requires_grad or tex.requires_grad):
-            raise NotImplementedError("goliath_amd.meshraster.RenderLayer is forward-only (no edge-gradient estimator): "
-                                      "call it under torch.no_grad(), as the shadow-map path does (urhand.py:404,492)")
+        # Gradients: the texture gradient is plain autograd through grid_sample (vt_img comes from detached rasterizer
+        # outputs); what is missing is drtk's edge_grad_estimator, i.e. the gradient w.r.t. the vertices -- a call that
+        # needs it raises instead of silently dropping it.
+        if torch.is_grad_enabled() and verts.requires_grad:
+            raise NotImplementedError("goliath_amd.meshraster.RenderLayer has no edge-gradient estimator: gradients flow "
+                                      "to `tex` only; pass verts.detach() (or call under torch.no_grad(), as the "
+                                      "shadow-map path does, urhand.py:404,492)")
         v_pix = transform(verts, K=K, Rt=Rt)
         index_img, depth_img, bary_img = rasterize(v_pix, self.vi, self.h, self.w)
         vt_img = interpolate((self.vt * 2.0 - 1.0)[None].expand(verts.shape[0], -1, -1), self.vti, index_img, bary_img)

@@ -297,7 +297,8 @@ class _RasterizeGaussians(torch.autograd.Function):
                           iptr(final_idx), fptr(vo), fptr(None), fptr(va), fptr(v_xy),
                           fptr(v_conic), fptr(v_colors), fptr(None), fptr(v_opacity), c_int(0), fptr(None), fptr(None),
                           c_int(0), fptr(None), stream_ptr())
-            ctx.ws = None
+        # ctx.ws stays: a second backward through this node (retain_graph=True, per-loss backward calls) needs the tile
+        # lists again; autograd frees them with the graph
         return (v_xy, None, None, v_conic, None, v_colors, v_opacity[:, None]) + (None,) * 5
 
 
@@ -406,7 +407,6 @@ class _RenderViews(torch.autograd.Function):
         if l1_sign is None:
             v_l1 = None
         if v_img is None and v_alpha is None and v_depth is None and v_l1 is None:
-            ctx.ws = None
             return (None,) * 19
         # fused L1: d loss / d rgb = (sign code - 1) * mask * (v_l1 / n).  The raster backward decodes the sign bytes itself
         # and adds the term to v_img (if the image has another consumer); the scalar goes in as a device value: no sync,
@@ -444,7 +444,8 @@ class _RenderViews(torch.autograd.Function):
                       fptr(comp), field(4), field(9) if use_depth else fptr(None), field(6), fptr(None), fptr(opacity),
                       field(3), c_int(GRAD_RECORD), fptr(v_mean), fptr(v_scale_g), fptr(v_quat), fptr(v_opacity),
                       stream_ptr())
-        ctx.ws = None  # the tile lists (the largest buffers of a step) go back to the allocator now
+        # ctx.ws stays alive with the node (retain_graph / a second backward re-reads the tile lists; the result dict of
+        # render_views holds sorted_ids / tile_bins anyway)
         return (v_mean, v_scale_g, v_quat, v_opacity, rec[..., :3]) + (None,) * 14
 
 
