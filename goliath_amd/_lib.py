@@ -10,7 +10,8 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libgoliath_hip.so")
+# GOLIATH_HIP_LIB: load another build of the same ABI instead (the test-only exact-math twin, goliath_amd/build.py)
+LIB_PATH = os.environ.get("GOLIATH_HIP_LIB") or os.path.join(_HERE, "lib", "libgoliath_hip.so")
 
 _lib = None
 

@@ -16,6 +16,17 @@ OBJ = os.path.join(CSRC, "_obj")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libgoliath_hip.so")
 
+# Build variants.  "" = the product library.  "exact" = a TEST-ONLY twin (libgoliath_hip_exact.so, -DGOL_EXACT_MATH): the
+# rasterizer evaluates sigma in the oracle's operation order without contraction, exp through double precision and the
+# transmittance recurrence as T (1 - alpha) -- no fast-math threshold flips -- so tests/test_gpu_exact_math.py can show that
+# the gradient residuals of the fast build are flips and nothing else.  Loaded only when GOLIATH_HIP_LIB points at it.
+VARIANTS = {"": [], "exact": ["-DGOL_EXACT_MATH=1"]}
+
+
+def lib_path(variant=""):
+    return os.path.join(LIBDIR, f"libgoliath_hip{'_' + variant if variant else ''}.so")
+
+
 HIPCC = os.environ.get("HIPCC") or shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 FLAGS = [
     "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics",
@@ -59,9 +70,9 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def _compile(src, verbose):
-    obj = os.path.join(OBJ, os.path.basename(src)[:-4] + ".o")
-    cmd = [HIPCC, *FLAGS, *EXTRA_FLAGS.get(os.path.basename(src), []), "-c", src, "-o", obj]
+def _compile(src, verbose, variant=""):
+    obj = os.path.join(OBJ + ("_" + variant if variant else ""), os.path.basename(src)[:-4] + ".o")
+    cmd = [HIPCC, *FLAGS, *VARIANTS[variant], *EXTRA_FLAGS.get(os.path.basename(src), []), "-c", src, "-o", obj]
     if verbose:
         print(" ".join(cmd), flush=True)
     r = subprocess.run(cmd, capture_output=True, text=True)
@@ -72,26 +83,29 @@ def _compile(src, verbose):
     return obj
 
 
-def build(force=False, verbose=False):
+def build(force=False, verbose=False, variant=""):
     """Compile every HIP source for gfx950 and link the C-ABI shared library.  Returns its path."""
-    os.makedirs(OBJ, exist_ok=True)
+    objdir = OBJ + ("_" + variant if variant else "")
+    lib = lib_path(variant)
+    os.makedirs(objdir, exist_ok=True)
     os.makedirs(LIBDIR, exist_ok=True)
     srcs, hdrs = _sources(), _headers()
     todo = [s for s in srcs
-            if force or _stale(os.path.join(OBJ, os.path.basename(s)[:-4] + ".o"), [s, *hdrs])]
+            if force or _stale(os.path.join(objdir, os.path.basename(s)[:-4] + ".o"), [s, *hdrs])]
     if todo:
         with concurrent.futures.ThreadPoolExecutor(max_workers=min(8, len(todo))) as ex:
-            list(ex.map(lambda s: _compile(s, verbose), todo))
-    objs = [os.path.join(OBJ, os.path.basename(s)[:-4] + ".o") for s in srcs]
-    if force or todo or _stale(LIB, objs):
-        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", LIB]
+            list(ex.map(lambda s: _compile(s, verbose, variant), todo))
+    objs = [os.path.join(objdir, os.path.basename(s)[:-4] + ".o") for s in srcs]
+    if force or todo or _stale(lib, objs):
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", lib]
         if verbose:
             print(" ".join(cmd), flush=True)
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
-    return LIB
+    return lib
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose="--verbose" in sys.argv or "-v" in sys.argv))
+    for v in (["", "exact"] if "--all" in sys.argv else ["exact"] if "--exact" in sys.argv else [""]):
+        print(build(force="--force" in sys.argv, verbose="--verbose" in sys.argv or "-v" in sys.argv, variant=v))

@@ -30,7 +30,28 @@ constexpr int kBatch = 256;
 // operand instead of a multiply + exp per pixel -- and the diagonal terms by the 1/2 of sigma = (a dx^2 + c dy^2) / 2 +
 // b dx dy as well; kUnA / kUnB bring the true conic back where the backward needs it
 constexpr float kLog2e = 1.4426950408889634f, kLn2 = 0.6931471805599453f;
+#ifndef GOL_EXACT_MATH
 constexpr float kScA = 0.5f * kLog2e, kScB = kLog2e, kUnA = 2.f * kLn2, kUnB = kLn2;
+#else
+// TEST-ONLY exact-math twin (goliath_amd/build.py, variant "exact"): the conic is staged unscaled, sigma is evaluated in
+// the order the CPU oracle (and gsplat) writes it -- 0.5 (a dx^2 + c dy^2) + b dx dy, every product and sum rounded
+// separately -- exp goes through double precision (correctly rounded to fp32) and the transmittance recurrence is
+// T (1 - alpha) instead of T - alpha T.  With bit-identical inputs the alpha >= 1/255 and T <= 1e-4 decisions then
+// coincide with the oracle's: what remains between the two is rounding noise, no threshold flips.
+constexpr float kScA = 1.f, kScB = 1.f, kUnA = 1.f, kUnB = 1.f;
+__device__ __forceinline__ float exact_sigma(float a, float b, float c, float dx, float dy) {
+#pragma clang fp contract(off)
+  const float t1 = (a * dx) * dx, t2 = (c * dy) * dy, t3 = (b * dx) * dy;
+  const float h = 0.5f * (t1 + t2);
+  return h + t3;
+}
+__device__ __forceinline__ float exact_exp_neg(float s) { return (float)exp(-(double)s); }
+__device__ __forceinline__ float exact_next_T(float T, float alpha) {
+#pragma clang fp contract(off)
+  const float om = 1.f - alpha;
+  return T * om;
+}
+#endif
 
 struct TileCoord { int tile, tx, ty; bool ok; };
 
@@ -152,16 +173,27 @@ __global__ __launch_bounds__(128) void raster_fwd_kernel(
         // branch-free pixel update: selects instead of exec-mask regions (the loop is issue-bound)
         const float dx = a4.x - px;
         const f2 dy = a4.y - py;
+#ifndef GOL_EXACT_MATH
         const f2 sigma = (a4.z * dx * dx + b4.x * dy * dy) + (a4.w * dx) * dy;  // log2e * gsplat's sigma
         f2 alpha;
         alpha.x = fminf(GOL_ALPHA_CAP_FWD, b4.y * __builtin_amdgcn_exp2f(-sigma.x));
         alpha.y = fminf(GOL_ALPHA_CAP_FWD, b4.y * __builtin_amdgcn_exp2f(-sigma.y));
+#else
+        const f2 sigma = {exact_sigma(a4.z, a4.w, b4.x, dx, dy.x), exact_sigma(a4.z, a4.w, b4.x, dx, dy.y)};
+        f2 alpha;
+        alpha.x = fminf(GOL_ALPHA_CAP_FWD, b4.y * exact_exp_neg(sigma.x));
+        alpha.y = fminf(GOL_ALPHA_CAP_FWD, b4.y * exact_exp_neg(sigma.y));
+#endif
         alpha *= live;
         // contributes: !(sigma < 0 || alpha < 1/255), as scalar lane masks (ballots of the plain compares)
         const unsigned long long mc0 = gol_ballot(!(sigma.x < 0.f)) & gol_ballot(!(alpha.x < GOL_ALPHA_FLOOR));
         const unsigned long long mc1 = gol_ballot(!(sigma.y < 0.f)) & gol_ballot(!(alpha.y < GOL_ALPHA_FLOOR));
         f2 vis = alpha * T_cur;
+#ifndef GOL_EXACT_MATH
         const f2 next_T = T_cur - vis;  // = T (1 - alpha)
+#else
+        const f2 next_T = {exact_next_T(T_cur.x, alpha.x), exact_next_T(T_cur.y, alpha.y)};
+#endif
         // stop / take as scalar lane-mask algebra: one compare per pixel (written with bools the compiler issues a second,
         // NaN-aware compare for the negation)
         const unsigned long long ms0 = gol_ballot(next_T.x <= GOL_T_STOP), ms1 = gol_ballot(next_T.y <= GOL_T_STOP);
@@ -171,7 +203,11 @@ __global__ __launch_bounds__(128) void raster_fwd_kernel(
         vis.x = take0 ? vis.x : 0.f; vis.y = take1 ? vis.y : 0.f;
         acc0 += b4.z * vis; acc1 += b4.w * vis; acc2 += c2.x * vis;
         if (EXTRA) acc3 += c2.y * vis;
+#ifndef GOL_EXACT_MATH
         T_cur -= vis;                   // unchanged where the entry is not taken
+#else
+        T_cur.x = take0 ? next_T.x : T_cur.x; T_cur.y = take1 ? next_T.y : T_cur.y;
+#endif
         cur_idx.x = take0 ? (batch_start + t) : cur_idx.x; cur_idx.y = take1 ? (batch_start + t) : cur_idx.y;
       }
     }
@@ -371,9 +407,15 @@ __global__ __launch_bounds__(128) void raster_bwd_kernel(
       const int li = batch_end - t;
       const float dx = a4.x - px;
       const f2 dy = a4.y - py;
+#ifndef GOL_EXACT_MATH
       const f2 sigma = (a4.z * dx * dx + b4.x * dy * dy) + (a4.w * dx) * dy;
       f2 vis;
       vis.x = __builtin_amdgcn_exp2f(-sigma.x); vis.y = __builtin_amdgcn_exp2f(-sigma.y);  // sigma = log2e * gsplat's
+#else
+      const f2 sigma = {exact_sigma(a4.z, a4.w, b4.x, dx, dy.x), exact_sigma(a4.z, a4.w, b4.x, dx, dy.y)};
+      f2 vis;
+      vis.x = exact_exp_neg(sigma.x); vis.y = exact_exp_neg(sigma.y);
+#endif
       f2 alpha = b4.y * vis;
       alpha.x = fminf(GOL_ALPHA_CAP_BWD, alpha.x); alpha.y = fminf(GOL_ALPHA_CAP_BWD, alpha.y);
       // taken by the pixel: within its list && !(sigma < 0 || alpha < 1/255) -- as scalar lane masks (ballots of the plain

@@ -39,7 +39,10 @@ def cpu_view(t, height, width, loss_scale=None, backward=True):
     diff = img[..., :3] - t["target"][0].permute(1, 2, 0)
     out = dict(rgb=rgb, alpha=alpha, depth_norm=img[..., 3] / alpha.clamp(0.05, 1.0), final_T=Ts,
                last_id=torch.where(Ts < 1.0, ids[idx.long()] if ids.numel() else idx, torch.full_like(idx, -1)),
-               loss=float(diff.abs().sum()) * loss_scale, n_isect=int(ids.numel()))
+               loss=float(diff.abs().sum()) * loss_scale, n_isect=int(ids.numel()),
+               # diagnostics for the parity tests' "explained by" predicates: the screen-space footprints and the
+               # shading state of this view
+               xys=xys, radii=radii, depths=depths, conics=conics, opac_eff=opac, preds={k: v.detach() for k, v in preds.items()})
     if not backward:
         return out
     v_out = torch.zeros(H, W, 4)
@@ -57,3 +60,21 @@ def cpu_view(t, height, width, loss_scale=None, backward=True):
     out["stage_grads"] = dict(color=v_col[:, :3], opacity=(v_op[:, 0] * comp)[:, None], primpos=v_mean,
                               primscale=v_scale, primqvec=v_quat)
     return out
+
+
+def shade_leaf_grads(t, stage_grads, dtype=torch.float64):
+    """Leaf gradients of ONE view's shading tail for given gradients at the raster / projection boundary (the `stage_grads`
+    of cpu_view), with the whole tail evaluated in `dtype`.  In fp64 this is the yardstick for the fp32 oracle's own
+    rounding: where the fp32 evaluation of the reference's formulation is itself far from the fp64 one (a lookup at a
+    derivative jump, the acos pole), no fp32 implementation can be expected to reproduce it to 1e-4."""
+    leaves = ("f_vn", "f_vc", "postex", "tn", "albedo")
+    tt = {k: (v.detach().to(dtype).requires_grad_(k in leaves) if torch.is_tensor(v) and v.is_floating_point() else v)
+          for k, v in t.items() if k != "mips"}
+    mips = [m.to(dtype) for m in t["mips"]]
+    pr = shade_ref.shade(tt["f_vn"], tt["f_vc"], tt["postex"], tt["tn"], tt["albedo"], tt["light_sh"], tt["campos"],
+                         envmips=mips, lightrot=tt["lightrot"])
+    g = {k: v.to(dtype) for k, v in stage_grads.items()}
+    (pr["primpos"][0] * g["primpos"]).sum().add((pr["primscale"][0] * g["primscale"]).sum()).add(
+        (pr["primqvec"][0] * g["primqvec"]).sum()).add((pr["color"][0] * g["color"]).sum()).add(
+        (pr["opacity"][0] * g["opacity"]).sum()).backward()
+    return {k: tt[k].grad for k in leaves}

@@ -21,28 +21,102 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-TOL_OUT = 1e-4       # north_star: outputs within 1e-4 L2 (rgb, alpha)
-TOL_DEPTH = 2e-4     # depth / clamp(alpha, 0.05, 1): the division by a clamped alpha amplifies threshold-flip pixels 20x
-TOL_ROBUST = 2e-4    # every gradient, with the 1e-4 fraction of Gaussians with the largest error left out (see below)
-TOL_ALL = 3e-3       # every gradient, every Gaussian: the ~4e-5 fraction of threshold-flip pixels (a Gaussian at
-                     # alpha ~ 1/255 or a pixel at T ~ 1e-4 is composited by one implementation and skipped by the
-                     # other -- fast exp vs expf) concentrates O(1) relative errors on the few Gaussians of those pixels
+TOL = 1e-4           # north_star: within 1e-4 L2 -- outputs AND gradients
+MAX_EXPLAINED = 2e-3  # at most this fraction of the Gaussians may need an explanation (measured: ~1e-4)
 LEAVES = ("f_vn", "f_vc", "postex", "tn", "albedo")
 STAGE = ("color", "opacity", "primpos", "primscale", "primqvec")
 
+# How the gradient bar is applied.  Every stage of the chain, run on identical inputs, agrees with the oracle to ~1e-6
+# (tests/test_gpu_exact_math.py, tools/stage_isolation.py -> profiles/r03_stage_isolation.json).  In the CHAIN the stages
+# inherit each other's rounding (conics differ by 5e-7 rms after shade + projection), which moves alpha across the
+# 1/255 cut -- or T across 1e-4 -- for a few 1e-5 of the pixels: one implementation composites a Gaussian the other skips.
+# Such a "flip pixel" puts an O(1) relative error on the gradient of the Gaussians under it, and the env-map term (piecewise
+# linear in the reflection direction: bilinear texel lookups, acos at the pole, clamps) does the same for a lookup within
+# rounding of a derivative jump.  The test does NOT drop "the worst k" blindly: it removes the smallest set W of Gaussians
+# whose removal brings the rel-L2 under the bar and asserts that EVERY member of W is explained by one of these
+# predicates, evaluated on the oracle's data:
+#   flip     the Gaussian reaches (alpha >= 0.5/255) a flagged pixel: a pixel whose contributor list differs, or one where
+#            the L1 loss is evaluated at its kink -- rgb equals the target to rounding, so sign(rgb - target), the upstream
+#            gradient, differs between the two implementations (the bench's target is random: +-1 signs cancel, a
+#            Gaussian's gradient is a sum of ~sqrt(pixels) net units and one flipped sign is a few % of it)
+#   border   its env lookup lies within 2e-3 texels of a texel border on one of the two mip levels it blends
+#   pole     |r_y| > 0.98 (2 % of the directions): see fp64 -- there BOTH fp32 evaluations are ill-conditioned, and which of
+#            the two is further from fp64 on a given Gaussian is chance
+#   fp64     the fp32 ORACLE itself is at least 1/4 as far from its own fp64 evaluation (same upstream gradient,
+#            oracle/chain.py:shade_leaf_grads) as HIP is from the fp32 oracle, on this Gaussian: the reference's formulation is
+#            ill-conditioned there in fp32 -- v = acos(r_y), u = atan2(r_x, r_z) have derivatives 1 / sqrt(1 - r_y^2) and
+#            1 / (r_x^2 + r_z^2), which amplify the rounding of the reflection direction by up to (1 - r_y^2)^-3/2 near the
+#            poles, and grid_sample's fp32 texel coordinate can itself fall on the other side of a border (tools/shade_isolation.py:
+#            in 2/3 of the largest HIP-vs-fp32-oracle disagreements of the shade backward HIP agrees with fp64 to 1e-6)
+#   kink     a clamp of the shading tail is active within rounding (diffuse / colour at 0, specular at 1)
+# An unexplained member of W fails the test.
 
-def _robust_rel_l2(a, b, drop=1e-4):  # noqa: C901
-    """rel-L2 over [B, C, N]-shaped per-Gaussian gradients with the `drop` fraction of Gaussians with the largest error
-    left out.  Two legitimate sources put O(1) errors on isolated Gaussians: threshold-flip pixels (above), and the
-    env-map specular term, which is piecewise linear in the reflection direction (bilinear texel lookups,
-    mipmap_sampler.py:13-69) -- its DERIVATIVE jumps at texel borders, so a lookup within rounding of a border gets a
-    different gradient on the two implementations.  Everything systematic shows up in this number."""
+
+def _worst_set(a, b, tol):
+    """Smallest set of Gaussians (indices into the flattened [B*N] axis) whose removal brings rel-L2(a, b) under `tol`.
+    a, b: [B, C, N].  Returns (indices, rel-L2 over everything, rel-L2 over the rest)."""
     a, b = a.double().cpu(), b.double().cpu()
-    err = (a - b).pow(2).sum(1)                     # [B, N]
-    k = max(1, int(drop * err.numel()))
-    thr = err.flatten().kthvalue(err.numel() - k).values
-    keep = (err <= thr)[:, None].expand_as(a)
-    return float(((a - b)[keep]).norm() / b[keep].norm())
+    err = (a - b).pow(2).sum(1).flatten()        # [B*N]
+    ref = b.pow(2).sum(1).flatten()
+    e_tot, r_tot = float(err.sum()), float(ref.sum())
+    order = err.argsort(descending=True)
+    ce = torch.cumsum(err[order], 0)
+    cr = torch.cumsum(ref[order], 0)
+    ok = (e_tot - ce) <= tol * tol * (r_tot - cr).clamp(min=1e-300)
+    k = 0 if e_tot <= tol * tol * r_tot else int(torch.nonzero(ok)[0]) + 1
+    rest = (max(e_tot - float(ce[k - 1]), 0.0) / max(r_tot - float(cr[k - 1]), 1e-300)) ** 0.5 if k else (e_tot / r_tot) ** 0.5
+    return order[:k], (e_tot / r_tot) ** 0.5, rest
+
+
+def _flip_touched(o, flag_yx):
+    """[N] bool: does the Gaussian reach one of the flagged pixels (flag_yx [F, 2] = (row, col)) with alpha >= 1/2 of the
+    1/255 cut (oracle's projected attributes: exactly the Gaussians a flagged pixel composites, plus the one at the cut)?"""
+    xys, conics, op, radii = o["xys"], o["conics"], o["opac_eff"], o["radii"]
+    out = torch.zeros(xys.shape[0], dtype=torch.bool)
+    px, py = flag_yx[:, 1].float() + 0.5, flag_yx[:, 0].float() + 0.5
+    for s in range(0, flag_yx.shape[0], 32):      # [N, 32] blocks
+        dx, dy = xys[:, :1] - px[None, s:s + 32], xys[:, 1:] - py[None, s:s + 32]
+        sigma = 0.5 * (conics[:, :1] * dx * dx + conics[:, 2:] * dy * dy) + conics[:, 1:2] * dx * dy
+        out |= ((op[:, None] * torch.exp(-sigma) >= 0.5 / 255.0) & (sigma >= 0)).any(1)
+    return out & (radii > 0)
+
+
+def _shade_predicates(pr, t):
+    """Per-Gaussian predicates of the env-map shading tail on the oracle's state (oracle/shade_ref.py): border, pole, kink."""
+    import torch.nn.functional as F
+
+    from oracle import shade_ref
+
+    view = F.normalize(pr["primpos"] - t["campos"][:, None], dim=-1)
+    n = pr["spec_nml"]
+    refl = view - 2 * (view * n).sum(-1, keepdim=True) * n
+    r = torch.einsum("bxy,bny->bnx", t["lightrot"], refl)[0]
+    uv = shade_ref.dir2uv(r)
+    q = len(t["mips"])
+    level = (pr["sigma"][0] * 5).clamp(0, q - 1 - 1e-6)
+    l0 = level.floor().long()
+    border = torch.zeros(r.shape[0], dtype=torch.bool)
+    for dl in (0, 1):
+        l = (l0 + dl).clamp(max=q - 1)
+        w, h = (1024 >> l).float(), (512 >> l).float()
+        ix, iy = ((uv[:, 0] + 1) * w - 1) / 2, ((uv[:, 1] + 1) * h - 1) / 2
+        fx, fy = ix - ix.floor(), iy - iy.floor()
+        border |= (torch.minimum(fx, 1 - fx) < 2e-3) | (torch.minimum(fy, 1 - fy) < 2e-3)
+    bdist = torch.full_like(level, 1.0)
+    for dl in (0, 1):
+        l = (l0 + dl).clamp(max=q - 1)
+        w, h = (1024 >> l).float(), (512 >> l).float()
+        ix, iy = ((uv[:, 0] + 1) * w - 1) / 2, ((uv[:, 1] + 1) * h - 1) / 2
+        fx, fy = ix - ix.floor(), iy - iy.floor()
+        bdist = torch.minimum(bdist, torch.minimum(torch.minimum(fx, 1 - fx), torch.minimum(fy, 1 - fy)))
+    border |= (level - level.round()).abs() < 1e-5          # the blend switches mip levels
+    _shade_predicates.diag = {"texel_border_dist": bdist, "r_y": r[:, 1], "u": uv[:, 0], "v": uv[:, 1], "mip_level": level,
+                              "spec_max": pr["spec_color"][0].amax(-1), "spec_vis": pr["spec_vis"][0, :, 0],
+                              "diff_min": pr["diff_color"][0].amin(-1)}
+    pole = r[:, 1].abs() > 0.98
+    kink = (pr["diff_color"][0].abs() < 1e-5).any(-1) | ((pr["spec_color"][0] / pr["spec_vis"][0].clamp(min=1e-6) - 1).abs() < 1e-5).any(-1)
+    kink |= (pr["color"][0].abs() < 1e-6).any(-1) | ((pr["sigma"][0] - 0.01).abs() < 1e-7)
+    return {"border": border, "pole": pole, "kink": kink}
 
 
 def _gpu_step(mb, cfg):
@@ -91,10 +165,13 @@ def test_bench_step_matches_oracle_chain(name):
     cref.set_threads(min(32, os.cpu_count() or 1))
     torch.set_num_threads(min(32, os.cpu_count() or 1))
     ref_grads = {k: [] for k in LEAVES}
+    ref_grads64 = {k: [] for k in LEAVES}
     ref_stage = {k: [] for k in STAGE}
     report = {"views": B, "gaussians": cfg["gaussians"], "image": [H, W], "outputs": {}, "grads": {}}
-    flips, big, ref_loss = 0, 0, 0.0
-    worst = {"rgb": 0.0, "alpha": 0.0, "depth": 0.0}
+    flips, big, ref_loss, sign_flips = 0, 0, 0.0, 0
+    worst = {"rgb": 0.0, "alpha": 0.0, "depth": 0.0, "depth_without_flip_pixels": 0.0}
+    explained = {k: [] for k in ("flip", "border", "pole", "kink")}   # per view: [N] bool
+    view_diag = []
     for b in range(B):
         one = {k: (v[b:b + 1].detach().clone().requires_grad_(v.requires_grad) if torch.is_tensor(v) and k != "albedo"
                    else v) for k, v in cpu.items()}
@@ -107,55 +184,113 @@ def test_bench_step_matches_oracle_chain(name):
         worst["rgb"] = max(worst["rgb"], rel_l2(rgb[b], o["rgb"]))
         worst["alpha"] = max(worst["alpha"], rel_l2(alpha[b, 0], o["alpha"]))
         worst["depth"] = max(worst["depth"], rel_l2(depth[b, 0], o["depth_norm"]))
-        # threshold flips: the last contributor differs, or the transmittance differs by more than rounding
+        # flip pixels: the last contributor differs, or the transmittance differs by more than rounding
         T_h, T_o = diag["final_T"][b, 0].cpu(), o["final_T"]
         flip = (last[b].cpu() != o["last_id"]) | ((T_h - T_o).abs() > 1e-3 * T_o.clamp(min=1e-4))
         flips += int(flip.sum())
+        keep = ~flip
+        worst["depth_without_flip_pixels"] = max(worst["depth_without_flip_pixels"],
+                                                 rel_l2(depth[b, 0].cpu()[keep], o["depth_norm"][keep]))
         big += int(((rgb[b].cpu() - o["rgb"]).abs().amax(0) > 1e-3).sum())
+        # L1 kink: the sign of (rgb - target) differs in some channel
+        tgt = cpu["target"][b]
+        sign_flip = (torch.sign(rgb[b].cpu() - tgt) != torch.sign(o["rgb"] - tgt)).any(0)
+        sign_flips += int(sign_flip.sum())
+        explained["flip"].append(_flip_touched(o, torch.nonzero(flip | sign_flip)))
+        # depth gap to the nearest neighbour in depth order, in ulps
+        dz = o["depths"].double()
+        order = dz.argsort()
+        gap = torch.full_like(dz, 1e30)
+        dd = (dz[order][1:] - dz[order][:-1])
+        gap[order[1:]] = torch.minimum(gap[order[1:]], dd)
+        gap[order[:-1]] = torch.minimum(gap[order[:-1]], dd)
+        ulp = torch.tensor(2.0).pow(torch.floor(torch.log2(dz.clamp(min=1e-30))) - 23)
+        view_diag.append({"radius": o["radii"].float(), "x": o["xys"][:, 0], "y": o["xys"][:, 1], "depth": o["depths"],
+                          "depth_gap_ulps": (gap / ulp).float(), "opacity": o["preds"]["opacity"][0, :, 0]})
+        sp = _shade_predicates(o["preds"], one)
+        for kk in ("border", "pole", "kink"):
+            explained[kk].append(sp[kk])
+        view_diag[-1].update(_shade_predicates.diag)
         for k in LEAVES:
             ref_grads[k].append(one[k].grad)
+        g64 = chain.shade_leaf_grads(one, o["stage_grads"])
+        for k in LEAVES:
+            ref_grads64[k].append(g64[k])
         for k in STAGE:
             ref_stage[k].append(o["stage_grads"][k])
+    N = cfg["gaussians"]
+    ex = {k: torch.stack(v).flatten() for k, v in explained.items()}             # [B*N]
+    ex_raster = ex["flip"]
+    ex_any = ex["flip"] | ex["border"] | ex["pole"] | ex["kink"]
     report["outputs"] = worst
     report["flip_pixel_fraction"] = flips / (B * H * W)
+    report["flip_pixels"] = flips
+    report["l1_sign_flip_pixels"] = sign_flips
     report["pixels_off_by_more_than_1e-3"] = big / (B * H * W)
     report["loss"] = {"hip": loss, "oracle": ref_loss}
-    drop = 1e-4 if name == "config2" else 1e-3   # 100 of 1 M Gaussians / 10 of 10 k
-    report["dropped_fraction"] = drop
-    report["stage_grads"], report["stage_grads_without_worst_1e-4_gaussians"] = {}, {}
-    for k in STAGE:
+    report["predicate_population"] = {k: float(v.float().mean()) for k, v in ex.items()}
+    report["tolerance"] = TOL
+    failures = []
+
+    def judge(kind, k, a, b, allowed, b64=None):
+        """a, b: [B, C, N].  Remove the smallest worst set W that brings the rest under TOL; every member must be explained."""
+        W_idx, all_rel, rest_rel = _worst_set(a, b, TOL)
+        by = {kk: int(ex[kk][W_idx].sum()) for kk in ex}
+        if b64 is not None:   # fp64 predicate: the fp32 oracle's own distance from its fp64 evaluation, per Gaussian
+            e_h = (a.double().cpu() - b.double().cpu()).pow(2).sum(1).flatten()
+            e_o = (b.double().cpu() - b64.double().cpu()).pow(2).sum(1).flatten()
+            fp64 = e_o >= 0.0625 * e_h
+            allowed = allowed | fp64
+            by["fp64"] = int(fp64[W_idx].sum())
+            report.setdefault("fp32_oracle_vs_fp64_oracle_rel_l2", {})[k] = float(
+                (e_o.sum() / b64.double().pow(2).sum()).sqrt())
+        unexplained = int((~allowed[W_idx]).sum())
+        report.setdefault(kind, {})[k] = {"rel_l2_all_gaussians": all_rel, "rel_l2_without_W": rest_rel,
+                                          "W_size": int(W_idx.numel()), "W_fraction": W_idx.numel() / (B * N),
+                                          "W_explained_by": by, "W_unexplained": unexplained}
+        if unexplained:   # diagnostics of the unexplained members (oracle data)
+            bad = W_idx[~allowed[W_idx]][:12]
+            a2, b2 = a.double().cpu(), b.double().cpu()
+            det = []
+            for gi in bad.tolist():
+                vb, g = divmod(gi, a2.shape[2]) if a2.shape[0] > 1 else (0, gi)
+                info = {"view": vb, "g": g, "err_over_ref": float((a2[vb, :, g] - b2[vb, :, g]).norm() / b2[vb, :, g].norm().clamp(min=1e-300)),
+                        "ref_over_median": float(b2[vb, :, g].norm() / b2[vb].norm(dim=0).median().clamp(min=1e-300))}
+                if vb < len(view_diag):
+                    info.update({kk: float(vv[g]) for kk, vv in view_diag[vb].items()})
+                det.append(info)
+            report[kind][k]["unexplained_examples"] = det
+        if unexplained or rest_rel > TOL or W_idx.numel() > MAX_EXPLAINED * B * N:
+            failures.append((kind, k, report[kind][k]))
+
+    for b in range(B):   # per-Gaussian relative error of the stage gradients (diagnostics of the leaf outliers)
+        for k in ("color", "primpos"):
+            a_, b_ = mb["_stage"][k][b].reshape(N, -1).double().cpu(), ref_stage[k][b].reshape(N, -1).double()
+            view_diag[b][f"stage_{k}_relerr"] = ((a_ - b_).norm(dim=1) / b_.norm(dim=1).clamp(min=1e-300)).float()
+            view_diag[b][f"stage_{k}_ref_norm"] = b_.norm(dim=1).float()
+    for k in STAGE:   # gradients at the raster / projection boundary: only a flip pixel explains an outlier there
         ref = torch.stack(ref_stage[k])                                   # [B, N, C]
-        report["stage_grads"][k] = rel_l2(mb["_stage"][k], ref)
-        report["stage_grads_without_worst_1e-4_gaussians"][k] = _robust_rel_l2(
-            mb["_stage"][k].reshape(B, ref.shape[1], -1).transpose(1, 2), ref.transpose(1, 2), drop)
-    report["grads_without_worst_1e-4_gaussians"] = {}
-    for k in LEAVES:
-        ref = torch.stack(ref_grads[k]).sum(0) if k == "albedo" else torch.cat(ref_grads[k], 0)
-        report["grads"][k] = rel_l2(mb[k].grad, ref)
-        if k != "albedo":
-            S2 = ref.shape[-1] * ref.shape[-2]
-            report["grads_without_worst_1e-4_gaussians"][k] = _robust_rel_l2(
-                mb[k].grad.reshape(B, -1, S2), ref.reshape(B, -1, S2), drop)
+        judge("stage_grads", k, mb["_stage"][k].reshape(B, N, -1).transpose(1, 2), ref.transpose(1, 2), ex_raster)
+    for k in LEAVES:  # leaf gradients: flip pixels + the derivative jumps of the env-map shading tail
+        if k == "albedo":
+            # shared by the B views: a texel is explained if it is in ANY view
+            ref = torch.stack(ref_grads[k]).sum(0)                                              # [1, N, 3]
+            ref64 = torch.stack(ref_grads64[k]).sum(0)
+            judge("grads", k, mb[k].grad.reshape(1, N, 3).transpose(1, 2), ref.reshape(1, N, 3).transpose(1, 2),
+                  ex_any.reshape(B, N).any(0), ref64.reshape(1, N, 3).transpose(1, 2))
+            report["grads"][k]["W_fraction"] = report["grads"][k]["W_size"] / N
+            continue
+        ref = torch.cat(ref_grads[k], 0)
+        judge("grads", k, mb[k].grad.reshape(B, -1, N), ref.reshape(B, -1, N), ex_any,
+              torch.cat(ref_grads64[k], 0).reshape(B, -1, N))
     print(f"\nCHAIN_PARITY {name} " + json.dumps(report))
     out_dir = os.path.join(ROOT, "gpurun_out")
     if os.path.isdir(out_dir):
         with open(os.path.join(out_dir, "fullsize_parity.json" if name == "config2" else f"chain_parity_{name}.json"), "w") as f:
             json.dump(report, f, indent=1)
     assert abs(loss - ref_loss) < 1e-5 * abs(ref_loss)
-    for k, v in worst.items():
-        assert v < (TOL_DEPTH if k == "depth" else TOL_OUT), (k, v)
+    for k in ("rgb", "alpha", "depth_without_flip_pixels"):
+        assert worst[k] < TOL, (k, worst[k])
+    assert worst["depth"] < 3e-4, worst["depth"]   # incl. the flip pixels: depth / clamp(alpha, .05, 1) amplifies them 20x
     assert report["flip_pixel_fraction"] < 1e-3, report["flip_pixel_fraction"]  # SURVEY 8c: expected << 0.1 %
-    if name == "config1":  # 10 k Gaussians: the handful of pole / texel-border lookups weighs 100x more than at 1 M
-        for kk, v in report["stage_grads"].items():
-            assert v < 1e-4, (kk, v)
-        for kk, v in report["grads_without_worst_1e-4_gaussians"].items():
-            assert v < 3e-4, (kk, v)
-        for kk, v in report["grads"].items():
-            assert v < 5e-2, (kk, v)
-        return
-    for name in ("stage_grads_without_worst_1e-4_gaussians", "grads_without_worst_1e-4_gaussians"):
-        for k, v in report[name].items():
-            assert v < TOL_ROBUST, (name, k, v)
-    for name in ("stage_grads", "grads"):
-        for k, v in report[name].items():
-            assert v < TOL_ALL, (name, k, v)
+    assert not failures, failures
