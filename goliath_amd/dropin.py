@@ -67,11 +67,28 @@ def patch_losses(registry_module=None):
 
 
 def patch_urhand(urhand_module=None):
-    """Swap the shadow-map lookup of the URHand model (`from ca_code.utils.shadowmap import get_shadow_map`,
-    ca_code/models/urhand.py:44, called at :415 and :503) for the fused PCF kernel."""
-    from . import shadowmap
+    """BASELINE config 4 as a drop-in: `ConvTeacherDecoder.forward` (ca_code/models/urhand.py:349-630) with its two light
+    loops and both shadow-map evaluations on the HIP kernels (goliath_amd.urhand.conv_teacher_decoder_forward), the
+    stand-alone shadow-map lookup (`get_shadow_map`, imported at urhand.py:44) and the render layer the decoder builds for
+    its light cameras (`RenderLayer`, urhand.py:43, 338-345: drtk in the reference) -- models constructed AFTER the patch
+    render their shadow depth maps with gol_mesh_raster.  Returns the patched module."""
+    from . import meshraster, shadowmap, urhand
 
     if urhand_module is None:
         import ca_code.models.urhand as urhand_module
     urhand_module.get_shadow_map = shadowmap.get_shadow_map
+    urhand_module.RenderLayer = meshraster.RenderLayer
+    urhand_module.ConvTeacherDecoder.forward = urhand.conv_teacher_decoder_forward
     return urhand_module
+
+
+def patch_hand_teacher(teacher_module=None):
+    """BASELINE config 5's teacher as a drop-in: `OLATRGBDecoder.forward_rgb` (ca_code/models/hand_teacher_mvp.py:253-494)
+    with the per-light deep-shadow march on gol_mvp_shadow_march (goliath_amd.urhand.olat_rgb_decoder_forward_rgb).
+    The ordinary ray march of the model already runs on the HIP kernels through `install()` (mvpraymarchlib / utilslib)."""
+    from . import urhand
+
+    if teacher_module is None:
+        import ca_code.models.hand_teacher_mvp as teacher_module
+    teacher_module.OLATRGBDecoder.forward_rgb = urhand.olat_rgb_decoder_forward_rgb
+    return teacher_module

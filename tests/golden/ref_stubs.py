@@ -83,8 +83,13 @@ def install(sgutilslib=None):
         sys.modules["torchvision.models"] = tv.models
         for sub in ("efficientnet", "vgg"):
             sys.modules[f"torchvision.models.{sub}"] = _Any(f"torchvision.models.{sub}")
+    _stub("turtle", forward=None)           # ca_code/nn/blocks.py:8 has a stray `from turtle import forward` (needs tkinter)
     _stub("pytorch3d")
-    _stub("pytorch3d.renderer")
+    _stub("pytorch3d.renderer", RasterizationSettings=None, MeshRasterizer=None)
+    _stub("pytorch3d.renderer.mesh.textures", TexturesUV=None)
+    _stub("pytorch3d.utils", cameras_from_opencv_projection=None)
+    _stub("pytorch3d.transforms", axis_angle_to_matrix=None, euler_angles_to_matrix=None, matrix_to_axis_angle=None)
+    _stub("pytorch3d.io", load_ply=None)
     _stub("pytorch3d.renderer.mesh")
     _stub("pytorch3d.renderer.mesh.rasterize_meshes", rasterize_meshes=None)
     _stub("pytorch3d.structures", Meshes=None)
