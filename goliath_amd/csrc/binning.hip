@@ -7,10 +7,20 @@
 //     scattered straight into their tile's segment (count -> scan over T tiles -> scatter with a
 //     per-tile cursor), then every tile sorts ITS list inside LDS (one workgroup per tile);
 //   * the sort key is (depth bits << 32 | gaussian id): the same front-to-back order as gsplat's
-//     (tile << 32 | depth) global sort, with ties broken deterministically by Gaussian id.
+//     (tile << 32 | depth) global sort, with ties broken deterministically by Gaussian id;
 //   * (Gaussian, tile) pairs that cannot reach alpha >= 1/255 anywhere in the tile are dropped at
 //     binning time (output-preserving, see tile_box) and the per-tile counters live in LDS during
-//     the two walks over the Gaussians, so hot tiles do not serialise on global atomics.
+//     the walks over the Gaussians, so hot tiles do not serialise on global atomics;
+//   * round 3: (a) the count pass only RESERVES: it walks the tight tile boxes without the exact per-tile test
+//     (an upper bound of the list lengths, ~1.2x), so the segments of a view are sized generously and the exact test
+//     runs once, in the scatter pass, which keeps its result in registers for its second walk (the 8-byte-per-
+//     Gaussian mask buffer between the passes is gone); tile_bins[t] = (start, start + exact length);
+//     (b) the per-tile sort is a bucket sort, not a compare-exchange network: the depths of a tile are spread over
+//     ~n buckets between the tile's nearest and farthest entry (monotone map, LDS histogram + scan), and every entry
+//     finds its place inside its bucket by counting the smaller keys there (1-3 compares on average) -- ~50
+//     instructions per key instead of the ~330 of the 55-step bitonic network of a 1024-key list, whose 2 x 55
+//     ds_bpermute exchanges per key kept the LDS crossbar busy for 0.32 ms per 8 views.  Lists with pathological
+//     depth clustering (a bucket of more than 48 entries) and lists of more than 2048 entries fall back to the network.
 // Traffic: 8 B written + 8 B read + 4 B written per intersection, everything else stays in LDS.
 #include <atomic>
 
@@ -72,11 +82,9 @@ struct BinArgs {
   int N, tiles_x, tiles_y, chunk;
   float inv_block, block;
   const float* xys; const float* depths; const int32_t* radii; const float* conics; const float* opacities;
-  uint64_t* reach;  // optional [B,N]: bit (y-y0)*w + (x-x0) of a Gaussian's tile box = the exact test of pass 1,
-                    // reused by pass 3 (boxes of more than 64 tiles are re-tested there)
 };
 
-// reached(x, y) from the mask pass 1 left behind, or the exact test when there is none
+// reached(x, y) from the mask of the scatter pass's first walk (bit (y-y0)*w + (x-x0) of the tile box), or the exact test
 __device__ __forceinline__ bool reached_cached(const Reach& rc, const TileBox& tb, bool have_mask, uint64_t mask, int x,
                                                int y, float block) {
   if (have_mask) return (mask >> ((y - tb.y0) * (tb.x1 - tb.x0) + (x - tb.x0))) & 1ull;
@@ -99,10 +107,22 @@ __device__ __forceinline__ TileBox box_of(const BinArgs& a, size_t e, Reach& rc)
   return tile_box(c.x, c.y, (float)r, a.tiles_x, a.tiles_y, a.inv_block, a.block, tight, ca, cb, cc, op);
 }
 
-// ---- pass 1: per-tile intersection counts ------------------------------------------------------
-// One 1024-thread workgroup walks a chunk of Gaussians and histograms their tiles in LDS (one int
-// per tile of the view, ds_add_u32), then flushes the non-zero bins with ONE global atomic each:
-// same-address global atomics drop by the chunk's multiplicity (~20x at 4096 Gaussians/chunk).
+// tile box only (no per-tile test state): what the reserving count pass needs
+__device__ __forceinline__ TileBox box_only(const BinArgs& a, size_t e) {
+  const int r = a.radii[e];
+  if (r <= 0) return TileBox{0, 0, 0, 0};
+  const float2 c = *reinterpret_cast<const float2*>(a.xys + 2 * e);
+  const bool tight = a.conics != nullptr;
+  float ca = 0.f, cb = 0.f, cc = 0.f, op = 1.f;
+  if (tight) { ca = a.conics[3 * e]; cb = a.conics[3 * e + 1]; cc = a.conics[3 * e + 2]; op = a.opacities[e]; }
+  return tile_box(c.x, c.y, (float)r, a.tiles_x, a.tiles_y, a.inv_block, a.block, tight, ca, cb, cc, op);
+}
+
+// ---- pass 1: per-tile RESERVATION counts -------------------------------------------------------
+// One 1024-thread workgroup walks a chunk of Gaussians and histograms the tiles of their (tight) boxes in LDS
+// (one int per tile of the view, ds_add_u32), then flushes the non-zero bins with ONE global atomic each.  No exact
+// per-tile test here: the counts are upper bounds (exact when no conics are given: gsplat's lists), the scatter pass
+// tests once and fills only what passes.
 __global__ __launch_bounds__(1024) void count_lds_kernel(BinArgs a, int32_t* __restrict__ tile_count) {
   extern __shared__ int32_t s_cnt[];
   const int b = blockIdx.y, T = a.tiles_x * a.tiles_y;
@@ -110,17 +130,9 @@ __global__ __launch_bounds__(1024) void count_lds_kernel(BinArgs a, int32_t* __r
   __syncthreads();
   const int i_end = min(a.N, (int)(blockIdx.x + 1) * a.chunk);
   for (int i = blockIdx.x * a.chunk + threadIdx.x; i < i_end; i += 1024) {
-    Reach rc;
-    const TileBox tb = box_of(a, (size_t)b * a.N + i, rc);
-    const int bw = tb.x1 - tb.x0;
-    uint64_t mask = 0;
+    const TileBox tb = box_only(a, (size_t)b * a.N + i);
     for (int y = tb.y0; y < tb.y1; ++y)
-      for (int x = tb.x0; x < tb.x1; ++x)
-        if (tile_reached(rc, x, y, a.block)) {
-          atomicAdd(&s_cnt[y * a.tiles_x + x], 1);
-          mask |= 1ull << (((y - tb.y0) * bw + (x - tb.x0)) & 63);
-        }
-    if (a.reach) a.reach[(size_t)b * a.N + i] = mask;
+      for (int x = tb.x0; x < tb.x1; ++x) atomicAdd(&s_cnt[y * a.tiles_x + x], 1);
   }
   __syncthreads();
   int32_t* tc = tile_count + (size_t)b * T;
@@ -131,14 +143,20 @@ __global__ __launch_bounds__(1024) void count_lds_kernel(BinArgs a, int32_t* __r
 }
 
 // ---- pass 3: scatter (depth bits, id) into the tile segments -----------------------------------
-// Same LDS histogram; each workgroup then reserves a contiguous range per tile with one returning
-// global atomic and hands out slots inside it with LDS atomics.
+// LDS histogram of the pairs that pass the exact test; each workgroup then reserves a contiguous range per tile with
+// one returning global atomic and hands out slots inside it with LDS atomics.  The test results of the first walk
+// stay in registers (one 64-bit mask per Gaussian, kMaskPerLane Gaussians per lane: chunk <= 4096) for the second.
+constexpr int kMaskPerLane = 4;
+
 __global__ __launch_bounds__(1024) void scatter_lds_kernel(BinArgs a, int64_t capacity,
                                                            int32_t* __restrict__ tile_bins,
                                                            uint64_t* __restrict__ isect_keys) {
-  // LDS: per-tile counters packed two to a word (a workgroup sees at most `chunk` <= 32768 Gaussians, so 16 bits
+  // LDS: per-tile counters packed two to a word (a workgroup sees at most `chunk` <= 4096 Gaussians, so 16 bits
   // hold any count) + per-tile 32-bit base offsets: 6 bytes per tile instead of 8, i.e. 64.5 KB at 2048x1334 -- two
-  // workgroups per CU instead of one.  The kernel is latency bound (returning global atomics, barriers).
+  // workgroups per CU instead of one.  The kernel is bound by its barriers (a lane with a 49-tile Gaussian holds up
+  // its 1024-thread workgroup; VALU-busy 35 %), not by instructions: measured and dropped in round 3 -- keeping the
+  // boxes and depths of the first walk in registers for the second (68 -> 102 VGPRs = one workgroup per CU: +8 %),
+  // the same under a 64-register cap (spills: +3 %), four reservation atomics in flight per lane (no change).
   extern __shared__ int32_t s_mem[];
   const int b = blockIdx.y, T = a.tiles_x * a.tiles_y, Tw = (T + 1) >> 1;
   uint32_t* s_cnt = reinterpret_cast<uint32_t*>(s_mem);
@@ -146,17 +164,24 @@ __global__ __launch_bounds__(1024) void scatter_lds_kernel(BinArgs a, int64_t ca
   for (int t = threadIdx.x; t < Tw; t += 1024) s_cnt[t] = 0u;
   __syncthreads();
   const int i_begin = blockIdx.x * a.chunk + threadIdx.x, i_end = min(a.N, (int)(blockIdx.x + 1) * a.chunk);
-  for (int i = i_begin; i < i_end; i += 1024) {
+  uint64_t masks[kMaskPerLane];
+#pragma unroll
+  for (int k = 0; k < kMaskPerLane; ++k) {
+    masks[k] = 0;
+    const int i = i_begin + k * 1024;
+    if (i >= i_end) continue;
     Reach rc;
     const TileBox tb = box_of(a, (size_t)b * a.N + i, rc);
-    const bool hm = a.reach && (tb.x1 - tb.x0) * (tb.y1 - tb.y0) <= 64;
-    const uint64_t mask = hm ? a.reach[(size_t)b * a.N + i] : 0;
+    const int bw = tb.x1 - tb.x0;
+    uint64_t mask = 0;
     for (int y = tb.y0; y < tb.y1; ++y)
       for (int x = tb.x0; x < tb.x1; ++x)
-        if (reached_cached(rc, tb, hm, mask, x, y, a.block)) {
+        if (tile_reached(rc, x, y, a.block)) {
           const int t = y * a.tiles_x + x;
           atomicAdd(&s_cnt[t >> 1], 1u << ((t & 1) << 4));
+          mask |= 1ull << (((y - tb.y0) * bw + (x - tb.x0)) & 63);
         }
+    masks[k] = mask;
   }
   __syncthreads();
   int32_t* bins = tile_bins + (size_t)b * T * 2;
@@ -168,14 +193,17 @@ __global__ __launch_bounds__(1024) void scatter_lds_kernel(BinArgs a, int64_t ca
   for (int t = threadIdx.x; t < Tw; t += 1024) s_cnt[t] = 0u;
   __syncthreads();
   uint64_t* keys = isect_keys + (size_t)b * capacity;
-  for (int i = i_begin; i < i_end; i += 1024) {
+#pragma unroll
+  for (int k = 0; k < kMaskPerLane; ++k) {
+    const int i = i_begin + k * 1024;
+    if (i >= i_end) continue;
     const size_t e = (size_t)b * a.N + i;
     Reach rc;
     const TileBox tb = box_of(a, e, rc);
     if (tb.x1 <= tb.x0 || tb.y1 <= tb.y0) continue;
     const uint64_t key = ((uint64_t)__float_as_uint(a.depths[e]) << 32) | (uint32_t)i;
-    const bool hm = a.reach && (tb.x1 - tb.x0) * (tb.y1 - tb.y0) <= 64;
-    const uint64_t mask = hm ? a.reach[e] : 0;
+    const bool hm = (tb.x1 - tb.x0) * (tb.y1 - tb.y0) <= 64;   // larger boxes are re-tested (their mask wrapped around)
+    const uint64_t mask = masks[k];
     for (int y = tb.y0; y < tb.y1; ++y)
       for (int x = tb.x0; x < tb.x1; ++x) {
         if (!reached_cached(rc, tb, hm, mask, x, y, a.block)) continue;
@@ -259,6 +287,8 @@ __global__ __launch_bounds__(1024) void scan_kernel(int T, const int32_t* __rest
     __syncthreads();
   }
   if (tid == 0) n_isect[b] = carry_s;
+  // the counts are consumed: their buffer becomes the view's two queues of long tile lists (sort_kernel); words 0, 1 = lengths
+  if (tid < 2 && tid < T) const_cast<int32_t*>(cnt)[tid] = 0;
 }
 
 // pass 4: one workgroup per tile sorts its list.  Bitonic network in the "all-ascending" form
@@ -397,26 +427,176 @@ __device__ __forceinline__ void sort_tile_regs(const uint64_t* __restrict__ keys
   }
 }
 
+// ---- bucket sort of one tile's list (n <= kBucketMaxN) ----------------------------------------------------------
+// Keys = (depth bits << 32 | id), depths positive floats.  The tile's depth range [dmin, dmax] is cut into nb ~ n
+// buckets by a MONOTONE map (float subtract, multiply by a positive scale, truncate, clamp), so sorting by
+// (bucket, key) is sorting by key.  The keys stay in registers; LDS holds them a second time in bucket order:
+//   bk[MAXN] u64 (bucket order) | start[kBucketMaxB + 1] u32 (+ 3 words of state)
+// Returns false (nothing written) when a bucket is too full for the quadratic in-bucket ranking to pay, or when a
+// depth is not a positive finite float: the caller falls back to the compare-exchange network.
+constexpr int kBucketMaxB = 1024, kBucketFull = 48;
+
+template <int MAXN>
+__device__ __forceinline__ bool bucket_sort_tile(const uint64_t* __restrict__ keys, int32_t* __restrict__ out, int n,
+                                                 uint64_t* __restrict__ lds, int tid) {
+  constexpr int KPT = MAXN / 256;
+  uint64_t* s_bk = lds;
+  uint32_t* s_start = reinterpret_cast<uint32_t*>(lds + MAXN);                // [kBucketMaxB + 1]
+  uint32_t* s_mmu = s_start + kBucketMaxB + 1;                                // depth bits: [0] = min, [1] = max
+  uint32_t* s_full = s_start + kBucketMaxB + 3;
+  const int lane = tid & 63;
+  int nb = n < 32 ? 32 : n;
+  if (nb > kBucketMaxB) nb = kBucketMaxB;
+  // ---- load, depth range (positive finite floats order like their bit patterns) ----
+  uint64_t k[KPT];
+  uint32_t bmin = 0xffffffffu, bmax = 0u;
+#pragma unroll
+  for (int r = 0; r < KPT; ++r) {
+    const int i = tid + 256 * r;
+    k[r] = 0;
+    if (i < n) {
+      k[r] = keys[i];
+      const uint32_t db = (uint32_t)(k[r] >> 32);
+      bmin = min(bmin, db); bmax = max(bmax, db);
+    }
+  }
+  if (tid == 0) { s_mmu[0] = 0xffffffffu; s_mmu[1] = 0u; *s_full = 0u; }
+  for (int t = tid; t <= nb; t += 256) s_start[t] = 0u;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    bmin = min(bmin, (uint32_t)__shfl_xor((int)bmin, off, 64));
+    bmax = max(bmax, (uint32_t)__shfl_xor((int)bmax, off, 64));
+  }
+  __syncthreads();
+  if (lane == 0) { atomicMin(&s_mmu[0], bmin); atomicMax(&s_mmu[1], bmax); }
+  __syncthreads();
+  // a negative, infinite or NaN depth would break the "bit order == float order" premise: leave those lists to the network
+  if (s_mmu[1] >= 0x7f800000u) return false;
+  const float lo = __uint_as_float(s_mmu[0]), hi = __uint_as_float(s_mmu[1]);
+  const float scale = hi > lo ? (float)nb / (hi - lo) : 0.f;
+  // ---- histogram ----
+  auto bucket_of = [&](uint64_t key) {
+    const float d = __uint_as_float((uint32_t)(key >> 32));
+    const int b = (int)((d - lo) * scale);
+    return b < 0 ? 0 : (b > nb - 1 ? nb - 1 : b);
+  };
+#pragma unroll
+  for (int r = 0; r < KPT; ++r)
+    if (tid + 256 * r < n) atomicAdd(&s_start[bucket_of(k[r])], 1u);
+  __syncthreads();
+  // ---- exclusive scan of the nb bucket counts (4 consecutive buckets per thread), in place ----
+  {
+    uint32_t c[4];
+    uint32_t sum = 0, worst = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int t = tid * 4 + q;
+      c[q] = t < nb ? s_start[t] : 0u;
+      sum += c[q];
+      worst = max(worst, c[q]);
+    }
+    if (worst > (uint32_t)kBucketFull) *s_full = 1u;   // (benign race: every writer stores 1)
+    uint32_t incl = sum;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const uint32_t u = __shfl_up(incl, off, 64);
+      if (lane >= off) incl += u;
+    }
+    __shared__ uint32_t s_wave[4];
+    if (lane == 63) s_wave[tid >> 6] = incl;
+    __syncthreads();
+    if (*s_full) return false;
+    uint32_t base = incl - sum;
+    for (int w = 0; w < (tid >> 6); ++w) base += s_wave[w];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int t = tid * 4 + q;
+      if (t < nb) s_start[t] = base;
+      base += c[q];
+    }
+  }
+  __syncthreads();
+  // ---- place the keys in bucket order: the bucket's start is its cursor; afterwards start[b] = END of bucket b ----
+#pragma unroll
+  for (int r = 0; r < KPT; ++r)
+    if (tid + 256 * r < n) s_bk[atomicAdd(&s_start[bucket_of(k[r])], 1u)] = k[r];
+  __syncthreads();
+  // ---- rank inside the bucket: the number of smaller keys there (ids are distinct: no equal keys) ----
+#pragma unroll
+  for (int r = 0; r < KPT; ++r) {
+    if (tid + 256 * r < n) {
+      const int b = bucket_of(k[r]);
+      const int p0 = b ? (int)s_start[b - 1] : 0, p1 = (int)s_start[b];
+      int rank = 0;
+      for (int p = p0; p < p1; ++p) rank += s_bk[p] < k[r] ? 1 : 0;
+      out[p0 + rank] = (int32_t)(uint32_t)k[r];
+    }
+  }
+  return true;
+}
+
+
+// pass 4a: one workgroup per tile; lists of up to kSmallN entries are sorted here (20 KB of LDS, 93 registers),
+// longer ones are queued for the queue kernel below (16+ keys per lane: 256 registers).  The queues live in the tile-count buffer, which is free once the scan has consumed it:
+//   q[0] = number of mid lists (ids at q[2 + i]), q[1] = number of big lists (ids at q[T - 1 - i]); scan_kernel zeroes
+//   both; each queue owns half of the T - 2 slots, a list that finds its queue full is sorted in place in global memory.
+constexpr int kSmallN = 2048, kMidN = 2048;   // (a middle class of its own -- 1024 < n <= 2048 queued -- measured slower)
+
+__device__ __forceinline__ int queue_cap(int T, int big) {
+  const int total = T > 2 ? T - 2 : 0;
+  return big ? total - total / 2 : total / 2;
+}
+
+__device__ __forceinline__ bool tile_range(int T, int64_t capacity, int32_t* __restrict__ tile_bins, int b, int t, int tid,
+                                           bool clamp, int& start, int& n) {
+  int2* binp = reinterpret_cast<int2*>(tile_bins) + (size_t)b * T + t;
+  const int2 bin = *binp;
+  start = bin.x;
+  int end = bin.y;
+  if (clamp) {
+    __syncthreads();  // everyone has read the bin before thread 0 may clamp it
+    // clamp to capacity (overflow is reported through n_isect; keep the bins self-consistent)
+    if (start > capacity) start = (int)capacity;
+    if (end > capacity) end = (int)capacity;
+    if (tid == 0 && (start != bin.x || end != bin.y)) *binp = make_int2(start, end);
+  }
+  n = end - start;
+  return n > 0;
+}
+
 __global__ __launch_bounds__(256) void sort_kernel(int T, int64_t capacity, int32_t* __restrict__ tile_bins,
                                                    uint64_t* __restrict__ isect_keys,
-                                                   int32_t* __restrict__ sorted_ids) {
-  __shared__ uint64_t lds_keys[kSortLds];
+                                                   int32_t* __restrict__ sorted_ids, int32_t* __restrict__ queue) {
+  __shared__ uint64_t lds_keys[kSmallN + kBucketMaxB / 2 + 8];
   const int b = blockIdx.y, t = blockIdx.x, tid = threadIdx.x;
-  int2* binp = reinterpret_cast<int2*>(tile_bins) + (size_t)b * T + t;
-  int2 bin = *binp;
-  __syncthreads();  // everyone has read the bin before thread 0 may clamp it
-  // clamp to capacity (overflow is reported through n_isect; keep the bins self-consistent)
-  int start = bin.x, end = bin.y;
-  if (start > capacity) start = (int)capacity;
-  if (end > capacity) end = (int)capacity;
-  if (tid == 0 && (start != bin.x || end != bin.y)) *binp = make_int2(start, end);
-  const int n = end - start;
-  if (n <= 0) return;
+  int start, n;
+  if (!tile_range(T, capacity, tile_bins, b, t, tid, true, start, n)) return;
   uint64_t* keys = isect_keys + (size_t)b * capacity + start;
   int32_t* out = sorted_ids + (size_t)b * capacity + start;
   if (n == 1) {
     if (tid == 0) out[0] = (int32_t)(uint32_t)keys[0];
     return;
+  }
+  if (n > kSmallN) {
+    __shared__ int32_t s_ok;
+    const int big = n > kMidN ? 1 : 0;
+    if (tid == 0) {
+      int32_t* q = queue + (size_t)b * T;
+      const int cap = queue_cap(T, big);
+      const int slot = cap > 0 ? atomicAdd(q + big, 1) : 0;
+      if (slot < cap) q[big ? T - 1 - slot : 2 + slot] = t;
+      s_ok = slot < cap;
+    }
+    __syncthreads();
+    if (s_ok) return;
+    // queue full (nearly every tile of the view is long): sort in place in global memory
+    bitonic_sort(keys, n, tid, 256);
+    for (int i = tid; i < n; i += 256) out[i] = (int32_t)(uint32_t)keys[i];
+    return;
+  }
+  if (n > 64) {
+    if (bucket_sort_tile<kSmallN>(keys, out, n, lds_keys, tid)) return;
+    __syncthreads();  // too clustered for buckets: the network below re-reads the keys from global memory
   }
   if (n <= 256) {
     sort_tile_regs<1>(keys, out, n, lds_keys, tid);
@@ -424,21 +604,44 @@ __global__ __launch_bounds__(256) void sort_kernel(int T, int64_t capacity, int3
     sort_tile_regs<2>(keys, out, n, lds_keys, tid);
   } else if (n <= 1024) {
     sort_tile_regs<4>(keys, out, n, lds_keys, tid);
-  } else if (n <= 2048) {
-    sort_tile_regs<8>(keys, out, n, lds_keys, tid);
-  } else if (n <= 4096) {
-    sort_tile_regs<16>(keys, out, n, lds_keys, tid);
-  } else if (n <= kSortLds) {
-    for (int i = tid; i < n; i += 256) lds_keys[i] = keys[i];
-    __syncthreads();
-    bitonic_sort(lds_keys, n, tid, 256);
-    for (int i = tid; i < n; i += 256) out[i] = (int32_t)(uint32_t)lds_keys[i];
   } else {
-    // rare: a tile covered by > 4096 Gaussians; same network straight on global memory
-    // (one workgroup = one CU, so __syncthreads() orders its own global stores and loads)
-    __syncthreads();
-    bitonic_sort(keys, n, tid, 256);
-    for (int i = tid; i < n; i += 256) out[i] = (int32_t)(uint32_t)keys[i];
+    sort_tile_regs<8>(keys, out, n, lds_keys, tid);
+  }
+}
+
+// pass 4b / 4c: the queued lists (a fixed grid of workgroups per view walks its queue).  BIG = false: kSmallN < n <=
+// kMidN; BIG = true: everything longer.
+template <bool BIG>
+__global__ __launch_bounds__(256) void sort_queue_kernel(int T, int64_t capacity, int32_t* __restrict__ tile_bins,
+                                                         uint64_t* __restrict__ isect_keys,
+                                                         int32_t* __restrict__ sorted_ids,
+                                                         const int32_t* __restrict__ queue) {
+  constexpr int MAXN = BIG ? kSortLds : kMidN;
+  __shared__ uint64_t lds_keys[MAXN + kBucketMaxB / 2 + 8];   // the keys + the bucket offsets
+  const int b = blockIdx.y, tid = threadIdx.x;
+  const int32_t* q = queue + (size_t)b * T;
+  const int count = min(q[BIG ? 1 : 0], queue_cap(T, BIG ? 1 : 0));
+  for (int w = blockIdx.x; w < count; w += gridDim.x) {
+    const int t = q[BIG ? T - 1 - w : 2 + w];
+    int start, n;
+    __syncthreads();  // the previous list is done with the LDS
+    if (!tile_range(T, capacity, tile_bins, b, t, tid, false, start, n)) continue;
+    uint64_t* keys = isect_keys + (size_t)b * capacity + start;
+    int32_t* out = sorted_ids + (size_t)b * capacity + start;
+    if (n <= MAXN) {
+      if (bucket_sort_tile<MAXN>(keys, out, n, lds_keys, tid)) continue;
+      __syncthreads();
+    }
+    if (!BIG) {
+      sort_tile_regs<8>(keys, out, n, lds_keys, tid);
+    } else if (n <= 4096) {
+      sort_tile_regs<16>(keys, out, n, lds_keys, tid);
+    } else {
+      // rare: a tile covered by > 4096 Gaussians; the network straight on global memory
+      // (one workgroup = one CU, so __syncthreads() orders its own global stores and loads)
+      bitonic_sort(keys, n, tid, 256);
+      for (int i = tid; i < n; i += 256) out[i] = (int32_t)(uint32_t)keys[i];
+    }
   }
 }
 
@@ -486,10 +689,10 @@ extern "C" int gol_bin_sort(int B, int N, const float* xys, const float* depths,
   int per_view = gol_cdiv(512, B);
   a.chunk = N > 0 ? gol_cdiv(N, per_view) : 1;
   if (a.chunk < 1024) a.chunk = 1024;
-  if (a.chunk > 32768) a.chunk = 32768;  // scatter_lds_kernel keeps per-workgroup tile counts in 16 bits
+  if (a.chunk > 1024 * kMaskPerLane) a.chunk = 1024 * kMaskPerLane;  // scatter_lds_kernel: test masks in registers, 16-bit counts
   const int nblk = N > 0 ? gol_cdiv(N, a.chunk) : 1;
   const bool lds_path = (size_t)T * 8 <= 128 * 1024;
-  a.reach = (lds_path && conics) ? reach_scratch : nullptr;
+  (void)reach_scratch;  // (rounds 1-2: mask buffer between the count and the scatter pass; the masks live in registers now)
   if (hipMemsetAsync(tile_count, 0, sizeof(int32_t) * (size_t)B * T, s) != hipSuccess) {
     gol_set_error("gol_bin_sort: hipMemsetAsync failed");
     return GOL_ERR_LAUNCH;
@@ -516,7 +719,8 @@ extern "C" int gol_bin_sort(int B, int N, const float* xys, const float* depths,
     } else {
       scatter_kernel<<<dim3(gol_cdiv(N, 256), B), 256, 0, s>>>(a, capacity, tile_bins, isect_keys);
     }
-    sort_kernel<<<dim3(T, B), 256, 0, s>>>(T, capacity, tile_bins, isect_keys, sorted_ids);
+    sort_kernel<<<dim3(T, B), 256, 0, s>>>(T, capacity, tile_bins, isect_keys, sorted_ids, tile_count);
+    sort_queue_kernel<true><<<dim3(256, B), 256, 0, s>>>(T, capacity, tile_bins, isect_keys, sorted_ids, tile_count);
   }
   GOL_CHECK_LAUNCH();
   return GOL_OK;
