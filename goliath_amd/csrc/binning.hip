@@ -23,6 +23,7 @@
 //     depth clustering (a bucket of more than 48 entries) and lists of more than 2048 entries fall back to the network.
 // Traffic: 8 B written + 8 B read + 4 B written per intersection, everything else stays in LDS.
 #include <atomic>
+#include <cstdlib>
 
 #include "gol_common.h"
 
@@ -685,12 +686,23 @@ extern "C" int gol_bin_sort(int B, int N, const float* xys, const float* depths,
   a.block = (float)block;
   a.xys = xys; a.depths = depths; a.radii = radii; a.conics = conics; a.opacities = opacities;
   const int T = a.tiles_x * a.tiles_y;
-  // chunk of Gaussians per 1024-thread workgroup: ~512 workgroups over all views, >= 1024 each
-  int per_view = gol_cdiv(512, B);
-  a.chunk = N > 0 ? gol_cdiv(N, per_view) : 1;
-  if (a.chunk < 1024) a.chunk = 1024;
-  if (a.chunk > 1024 * kMaskPerLane) a.chunk = 1024 * kMaskPerLane;  // scatter_lds_kernel: test masks in registers, 16-bit counts
-  const int nblk = N > 0 ? gol_cdiv(N, a.chunk) : 1;
+  // chunk of Gaussians per 1024-thread workgroup.  Count pass: ~512 workgroups over all views (its cost is the zeroing /
+  // flushing of the LDS table: fewer, longer workgroups); scatter pass: ~2048 (it is bound by its barriers: a lane with
+  // a 49-tile Gaussian holds up its workgroup -- short chunks bound the damage and let the CUs rebalance; measured per 8
+  // views: 512 workgroups 0.247 ms, 1024 0.217, 2048 0.192).  >= 1024 Gaussians each; the scatter keeps its test masks
+  // in registers and its counts in 16 bits: <= 1024 * kMaskPerLane.
+  static const int kWgsCount = getenv("GOL_BIN_WGS") ? atoi(getenv("GOL_BIN_WGS")) : 512;
+  static const int kWgsScatter = getenv("GOL_BIN_WGS2") ? atoi(getenv("GOL_BIN_WGS2")) : 2048;
+  auto chunk_for = [&](int wgs) {
+    int c = N > 0 ? gol_cdiv(N, gol_cdiv(wgs, B)) : 1;
+    if (c < 1024) c = 1024;
+    if (c > 1024 * kMaskPerLane) c = 1024 * kMaskPerLane;
+    return c;
+  };
+  a.chunk = chunk_for(kWgsCount);
+  BinArgs a2 = a;
+  a2.chunk = chunk_for(kWgsScatter);
+  const int nblk = N > 0 ? gol_cdiv(N, a.chunk) : 1, nblk2 = N > 0 ? gol_cdiv(N, a2.chunk) : 1;
   const bool lds_path = (size_t)T * 8 <= 128 * 1024;
   (void)reach_scratch;  // (rounds 1-2: mask buffer between the count and the scatter pass; the masks live in registers now)
   if (hipMemsetAsync(tile_count, 0, sizeof(int32_t) * (size_t)B * T, s) != hipSuccess) {
@@ -715,7 +727,7 @@ extern "C" int gol_bin_sort(int B, int N, const float* xys, const float* depths,
       const size_t lds = sizeof(int32_t) * ((size_t)((T + 1) >> 1) + (size_t)T);
       if (lds_limit_needs_raise(1, lds))
         hipFuncSetAttribute((const void*)scatter_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      scatter_lds_kernel<<<dim3(nblk, B), 1024, lds, s>>>(a, capacity, tile_bins, isect_keys);
+      scatter_lds_kernel<<<dim3(nblk2, B), 1024, lds, s>>>(a2, capacity, tile_bins, isect_keys);
     } else {
       scatter_kernel<<<dim3(gol_cdiv(N, 256), B), 256, 0, s>>>(a, capacity, tile_bins, isect_keys);
     }
