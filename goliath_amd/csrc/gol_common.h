@@ -135,5 +135,38 @@ __device__ __forceinline__ float gol_min_sigma_rect(float gx, float gy, float a,
   return m;
 }
 
+// ---- packed per-Gaussian raster record (GOL_SPLAT_RECORD floats = 64 bytes = one HBM sector) ------------------------
+// Everything the rasterizer stages for a list entry, written once per (view, Gaussian) by the projection (or by
+// gol_splat_pack for the gsplat-compatible operators) and fetched with four 16-byte loads from ONE aligned 64-byte line
+// -- the five separate attribute arrays of rounds 1-2 cost up to five sectors per entry (PMC: 109 B fetched for 40 B
+// used).  The conic is stored the way the pixel loops want it: pre-multiplied by log2(e) (alpha = opacity * 2^-sigma' is
+// one v_exp_f32) and the diagonal terms by the 1/2 of sigma = (a dx^2 + c dy^2) / 2 + b dx dy as well; GOL_UN_A / GOL_UN_B
+// bring the true conic back.  The exact-math test build stores it unscaled.
+//   [0] x  [1] y  [2] a'  [3] b' | [4] c'  [5] opacity  [6] r  [7] g | [8] b  [9] extra (depth)  [10] tau  [11] 1/a |
+//   [12] 1/c  [13] exact (1 = the ellipse tests are valid, 0 = degenerate conic: "reaches everything")  [14-15] pad
+// tau = gol_alpha_tau(opacity) (< 0: alpha < 1/255 everywhere), 1/a and 1/c of the TRUE conic: the per-entry part of the
+// alpha >= 1/255 reach test, hoisted out of the staging loops of both raster passes.
+#ifndef GOL_EXACT_MATH
+#define GOL_SC_A (0.5f * 1.4426950408889634f)
+#define GOL_SC_B 1.4426950408889634f
+#define GOL_UN_A (2.f * 0.6931471805599453f)
+#define GOL_UN_B 0.6931471805599453f
+#else
+#define GOL_SC_A 1.f
+#define GOL_SC_B 1.f
+#define GOL_UN_A 1.f
+#define GOL_UN_B 1.f
+#endif
+
+__device__ __forceinline__ void gol_record_write(float* __restrict__ rec, float x, float y, float ca, float cb, float cc,
+                                                 float op, float r, float g, float b, float extra) {
+  const bool exact = (ca * cc - cb * cb > 0.f) && ca > 0.f && cc > 0.f;
+  float4* R = reinterpret_cast<float4*>(rec);
+  R[0] = make_float4(x, y, ca * GOL_SC_A, cb * GOL_SC_B);
+  R[1] = make_float4(cc * GOL_SC_A, op, r, g);
+  R[2] = make_float4(b, extra, gol_alpha_tau(op), exact ? 1.f / ca : 0.f);
+  R[3] = make_float4(exact ? 1.f / cc : 0.f, exact ? 1.f : 0.f, 0.f, 0.f);
+}
+
 __device__ __forceinline__ float gol_fast_exp(float x) { return __expf(x); }
 __device__ __forceinline__ float gol_rcp(float x) { return __frcp_rn(x); }

@@ -52,7 +52,7 @@ __global__ __launch_bounds__(256) void project_fwd_kernel(
     float* __restrict__ cov3d, float* __restrict__ xys, float* __restrict__ depths,
     int32_t* __restrict__ radii, float* __restrict__ conics, float* __restrict__ compensation,
     int32_t* __restrict__ num_tiles_hit, const float* __restrict__ opacities,
-    float* __restrict__ opac_eff) {
+    float* __restrict__ opac_eff, const float* __restrict__ colors, float* __restrict__ records) {
   const int b = blockIdx.y;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= N) return;
@@ -121,7 +121,13 @@ __global__ __launch_bounds__(256) void project_fwd_kernel(
   conics[3 * e] = o_con[0]; conics[3 * e + 1] = o_con[1]; conics[3 * e + 2] = o_con[2];
   compensation[e] = o_comp;
   num_tiles_hit[e] = o_tiles;
-  if (opac_eff) opac_eff[e] = opacities[e] * o_comp;
+  const float op_eff = opacities ? opacities[e] * o_comp : 0.f;
+  if (opac_eff) opac_eff[e] = op_eff;
+  // the rasterizer's 64-byte record of this Gaussian (gol_common.h): screen position, scaled conic, effective opacity,
+  // colour, depth as the 4th channel, and the per-Gaussian part of the alpha >= 1/255 reach test
+  if (records)
+    gol_record_write(records + e * GOL_SPLAT_RECORD, o_xy[0], o_xy[1], o_con[0], o_con[1], o_con[2], op_eff,
+                     colors[3 * e], colors[3 * e + 1], colors[3 * e + 2], o_depth);
 }
 
 __global__ __launch_bounds__(256) void project_bwd_kernel(
@@ -247,7 +253,8 @@ extern "C" int gol_project_fwd(int B, int N, const float* means3d, const float* 
                                const float* quats, const float* viewmats, const float* intrins, int img_h,
                                int img_w, int block, float clip_thresh, float* cov3d, float* xys,
                                float* depths, int32_t* radii, float* conics, float* compensation,
-                               int32_t* num_tiles_hit, const float* opacities, float* opac_eff, void* stream) {
+                               int32_t* num_tiles_hit, const float* opacities, float* opac_eff, const float* colors,
+                               float* records, void* stream) {
   GOL_REQUIRE(B >= 0 && N >= 0, "negative size");
   GOL_REQUIRE(block > 1 && block <= 16, "block_width must be between 2 and 16");
   GOL_REQUIRE(img_h > 0 && img_w > 0, "empty image");
@@ -255,11 +262,12 @@ extern "C" int gol_project_fwd(int B, int N, const float* means3d, const float* 
   GOL_REQUIRE(means3d && scales && quats && viewmats && intrins, "null input");
   GOL_REQUIRE(cov3d && xys && depths && radii && conics && compensation && num_tiles_hit, "null output");
   GOL_REQUIRE((opac_eff == nullptr) || (opacities != nullptr), "opac_eff needs opacities");
+  GOL_REQUIRE((records == nullptr) || (opacities != nullptr && colors != nullptr), "records need opacities and colors");
   GOL_REQUIRE(B <= 65535, "B > 65535");
   dim3 grid(gol_cdiv(N, 256), B);
   project_fwd_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(
       N, means3d, scales, glob_scale, quats, viewmats, intrins, img_h, img_w, block, clip_thresh, cov3d, xys,
-      depths, radii, conics, compensation, num_tiles_hit, opacities, opac_eff);
+      depths, radii, conics, compensation, num_tiles_hit, opacities, opac_eff, colors, records);
   GOL_CHECK_LAUNCH();
   return GOL_OK;
 }

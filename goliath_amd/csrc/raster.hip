@@ -29,16 +29,13 @@ constexpr int kBatch = 256;
 // conics are staged in LDS pre-multiplied by log2(e) -- alpha = opacity * 2^(-sigma') is one v_exp_f32 with a negated
 // operand instead of a multiply + exp per pixel -- and the diagonal terms by the 1/2 of sigma = (a dx^2 + c dy^2) / 2 +
 // b dx dy as well; kUnA / kUnB bring the true conic back where the backward needs it
-constexpr float kLog2e = 1.4426950408889634f, kLn2 = 0.6931471805599453f;
-#ifndef GOL_EXACT_MATH
-constexpr float kScA = 0.5f * kLog2e, kScB = kLog2e, kUnA = 2.f * kLn2, kUnB = kLn2;
-#else
+constexpr float kScA = GOL_SC_A, kScB = GOL_SC_B, kUnA = GOL_UN_A, kUnB = GOL_UN_B;
+#ifdef GOL_EXACT_MATH
 // TEST-ONLY exact-math twin (goliath_amd/build.py, variant "exact"): the conic is staged unscaled, sigma is evaluated in
 // the order the CPU oracle (and gsplat) writes it -- 0.5 (a dx^2 + c dy^2) + b dx dy, every product and sum rounded
 // separately -- exp goes through double precision (correctly rounded to fp32) and the transmittance recurrence is
 // T (1 - alpha) instead of T - alpha T.  With bit-identical inputs the alpha >= 1/255 and T <= 1e-4 decisions then
 // coincide with the oracle's: what remains between the two is rounding noise, no threshold flips.
-constexpr float kScA = 1.f, kScB = 1.f, kUnA = 1.f, kUnB = 1.f;
 __device__ __forceinline__ float exact_sigma(float a, float b, float c, float dx, float dy) {
 #pragma clang fp contract(off)
   const float t1 = (a * dx) * dx, t2 = (c * dy) * dy, t3 = (b * dx) * dy;
@@ -77,15 +74,13 @@ typedef int i2 __attribute__((ext_vector_type(2)));
 
 // 2-bit mask of the 16x8 halves (bit h = rows 8h..8h+7) that the alpha >= 1/255 region of a Gaussian can reach:
 // exact ellipse-vs-rectangle test (minimum of sigma over the half's pixel centres against ln(255*opacity)),
-// conservative only by a rounding margin; degenerate conics -> both.
-__device__ __forceinline__ int half_mask(float gx, float gy, float ca, float cb, float cc, float op, float tile_x0,
-                                         float tile_y0) {
-  const float tau = gol_alpha_tau(op);
+// conservative only by a rounding margin; degenerate conics -> both.  tau, 1/a, 1/c and the validity flag come from the
+// record (gol_common.h: computed once per Gaussian by the projection).
+__device__ __forceinline__ int half_mask(float gx, float gy, float ca, float cb, float cc, float tau, float ia, float ic,
+                                         float exact, float tile_x0, float tile_y0) {
   if (!(tau >= 0.f)) return 0;  // alpha < 1/255 everywhere (also NaN opacity: skipped by gsplat too)
-  const float det = ca * cc - cb * cb;
-  if (!(det > 0.f) || !(ca > 0.f) || !(cc > 0.f)) return 0x3;
+  if (exact == 0.f) return 0x3;
   int m = 0;
-  const float ia = 1.f / ca, ic = 1.f / cc;
 #pragma unroll
   for (int q = 0; q < 2; ++q) {
     const float x0 = tile_x0 + 0.5f, y0 = tile_y0 + (float)(q * 8) + 0.5f;
@@ -95,15 +90,27 @@ __device__ __forceinline__ int half_mask(float gx, float gy, float ca, float cb,
   return m;
 }
 
+// stage one list entry: four 16-byte loads from the Gaussian's 64-byte record
+struct Staged { float4 a, b; float2 c; int mask; };
+__device__ __forceinline__ Staged stage_entry(const float* __restrict__ records, size_t g, float tile_x0, float tile_y0) {
+  const float4* R = reinterpret_cast<const float4*>(records + g * GOL_SPLAT_RECORD);
+  const float4 q0 = R[0], q1 = R[1], q2 = R[2], q3 = R[3];
+  Staged s;
+  s.a = q0;                              // x, y, a', b'
+  s.b = q1;                              // c', opacity, r, g
+  s.c = make_float2(q2.x, q2.y);         // b, extra
+  s.mask = half_mask(q0.x, q0.y, q0.z * kUnA, q0.w * kUnB, q1.x * kUnA, q2.z, q2.w, q3.x, q3.y, tile_x0, tile_y0);
+  return s;
+}
+
 // Forward.  128-thread workgroup per 16x16 tile: wave w owns the 16x8 half (rows 8w..8w+7) and every lane two
 // vertically adjacent pixels, so the per-pixel recurrence runs on 2-vectors = packed fp32 VALU ops
 // (v_pk_fma/mul/add_f32), half the instructions per pixel of a one-pixel-per-lane loop.
 template <bool EXTRA>
 __global__ __launch_bounds__(128) void raster_fwd_kernel(
     int N, int img_h, int img_w, int planar, int tiles_x, int tiles_y, const int2* __restrict__ tile_bins,
-    const int32_t* __restrict__ sorted_ids, int64_t capacity, const float* __restrict__ xys,
-    const float* __restrict__ conics, const float* __restrict__ colors, const float* __restrict__ extra,
-    const float* __restrict__ opacities, const float* __restrict__ background, float* __restrict__ out_img,
+    const int32_t* __restrict__ sorted_ids, int64_t capacity, const float* __restrict__ records,
+    const float* __restrict__ background, float* __restrict__ out_img,
     float* __restrict__ out_extra, float* __restrict__ final_Ts, int32_t* __restrict__ final_idx,
     float* __restrict__ out_alpha, float* __restrict__ out_extra_norm, float norm_lo,
     const float* __restrict__ l1_target, const float* __restrict__ l1_mask, int l1_mask_c,
@@ -143,16 +150,8 @@ __global__ __launch_bounds__(128) void raster_fwd_kernel(
     for (int k = tid; k < kBatch; k += 128) {
       const int idx = batch_start + k;
       if (idx < range.y) {
-        const size_t g = goff + (size_t)ids[idx];
-        const float2 xy = *reinterpret_cast<const float2*>(xys + 2 * g);
-        const float ca = conics[3 * g], cb = conics[3 * g + 1], cc = conics[3 * g + 2];
-        const float op = opacities[g];
-        const float r = colors[3 * g], gg = colors[3 * g + 1], bl = colors[3 * g + 2];
-        const float ex = EXTRA ? extra[g] : 0.f;
-        s_a[k] = make_float4(xy.x, xy.y, ca * kScA, cb * kScB);
-        s_b[k] = make_float4(cc * kScA, op, r, gg);
-        s_c[k] = make_float2(bl, ex);
-        s_mask[k] = half_mask(xy.x, xy.y, ca, cb, cc, op, (float)(tc.tx * 16), (float)(tc.ty * 16));
+        const Staged st = stage_entry(records, goff + (size_t)ids[idx], (float)(tc.tx * 16), (float)(tc.ty * 16));
+        s_a[k] = st.a; s_b[k] = st.b; s_c[k] = st.c; s_mask[k] = st.mask;
       } else {
         s_mask[k] = 0;
       }
@@ -291,9 +290,8 @@ static_assert(kBatchB == 64, "raster_bwd_kernel ballots one 64-entry chunk per b
 template <bool EXTRA, bool PACKED>
 __global__ __launch_bounds__(128) void raster_bwd_kernel(
     int N, int img_h, int img_w, int planar, int tiles_x, int tiles_y, const int2* __restrict__ tile_bins,
-    const int32_t* __restrict__ sorted_ids, int64_t capacity, const float* __restrict__ xys,
-    const float* __restrict__ conics, const float* __restrict__ colors, const float* __restrict__ extra,
-    const float* __restrict__ opacities, const float* __restrict__ background,
+    const int32_t* __restrict__ sorted_ids, int64_t capacity, const float* __restrict__ records,
+    const float* __restrict__ background,
     const float* __restrict__ final_Ts, const int32_t* __restrict__ final_idx,
     const float* __restrict__ v_out_img, const float* __restrict__ v_out_extra,
     const float* __restrict__ v_out_alpha, float* __restrict__ v_xy, float* __restrict__ v_conic,
@@ -377,16 +375,8 @@ __global__ __launch_bounds__(128) void raster_bwd_kernel(
     if (tid < kBatchB) {
       if (tid < batch_size) {
         const int gid = ids[batch_end - tid];
-        const size_t g = goff + (size_t)gid;
-        const float2 xy = *reinterpret_cast<const float2*>(xys + 2 * g);
-        const float ca = conics[3 * g], cb = conics[3 * g + 1], cc = conics[3 * g + 2];
-        const float op = opacities[g];
-        const float r = colors[3 * g], gg = colors[3 * g + 1], bl = colors[3 * g + 2];
-        const float ex = EXTRA ? extra[g] : 0.f;
-        s_a[tid] = make_float4(xy.x, xy.y, ca * kScA, cb * kScB);
-        s_b[tid] = make_float4(cc * kScA, op, r, gg);
-        s_c[tid] = make_float2(bl, ex);
-        s_mask[tid] = half_mask(xy.x, xy.y, ca, cb, cc, op, (float)(tc.tx * 16), (float)(tc.ty * 16));
+        const Staged st = stage_entry(records, goff + (size_t)gid, (float)(tc.tx * 16), (float)(tc.ty * 16));
+        s_a[tid] = st.a; s_b[tid] = st.b; s_c[tid] = st.c; s_mask[tid] = st.mask;
         s_id[tid] = gid;
       } else {
         s_mask[tid] = 0;
@@ -525,12 +515,38 @@ __global__ __launch_bounds__(128) void raster_bwd_kernel(
   }
 }
 
+// gsplat-compatible operators hand over separate attribute arrays: pack them into records (the fused path's projection
+// writes the records itself)
+__global__ __launch_bounds__(256) void splat_pack_kernel(size_t n, const float* __restrict__ xys,
+                                                         const float* __restrict__ conics,
+                                                         const float* __restrict__ colors,
+                                                         const float* __restrict__ extra,
+                                                         const float* __restrict__ opacities,
+                                                         float* __restrict__ records) {
+  const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= n) return;
+  gol_record_write(records + e * GOL_SPLAT_RECORD, xys[2 * e], xys[2 * e + 1], conics[3 * e], conics[3 * e + 1],
+                   conics[3 * e + 2], opacities[e], colors[3 * e], colors[3 * e + 1], colors[3 * e + 2],
+                   extra ? extra[e] : 0.f);
+}
+
 }  // namespace
 
+extern "C" int gol_splat_pack(int B, int N, const float* xys, const float* conics, const float* colors,
+                              const float* extra, const float* opacities, float* records, void* stream) {
+  GOL_REQUIRE(B >= 0 && N >= 0, "negative size");
+  if (B == 0 || N == 0) return GOL_OK;
+  GOL_REQUIRE(xys && conics && colors && opacities && records, "null pointer");
+  const size_t n = (size_t)B * N;
+  splat_pack_kernel<<<gol_cdiv((long long)n, 256), 256, 0, (hipStream_t)stream>>>(n, xys, conics, colors, extra, opacities,
+                                                                                 records);
+  GOL_CHECK_LAUNCH();
+  return GOL_OK;
+}
+
 extern "C" int gol_rasterize_fwd(int B, int N, int img_h, int img_w, int block, int planar, const int32_t* tile_bins,
-                                 const int32_t* sorted_ids, int64_t capacity, const float* xys,
-                                 const float* conics, const float* colors, const float* extra,
-                                 const float* opacities, const float* background, float* out_img,
+                                 const int32_t* sorted_ids, int64_t capacity, const float* records, int with_extra,
+                                 const float* background, float* out_img,
                                  float* out_extra, float* final_Ts, int32_t* final_idx, float* out_alpha,
                                  float* out_extra_norm, float norm_lo, const float* l1_target, const float* l1_mask,
                                  int l1_mask_c, uint8_t* l1_sign, float* l1_partial, void* stream) {
@@ -542,33 +558,31 @@ extern "C" int gol_rasterize_fwd(int B, int N, int img_h, int img_w, int block, 
   GOL_REQUIRE(tile_bins && background && out_img && final_Ts && final_idx, "null pointer");
   GOL_REQUIRE((uint64_t)img_h * (uint64_t)img_w * 12ull < (1ull << 32), "image too large (32-bit byte offsets inside a view)");
   GOL_REQUIRE(capacity == 0 || sorted_ids, "null sorted_ids");
-  GOL_REQUIRE(N == 0 || (xys && conics && colors && opacities), "null Gaussian attribute");
-  GOL_REQUIRE((!out_extra && !out_extra_norm) || extra || N == 0, "out_extra / out_extra_norm need the extra channel");
-  GOL_REQUIRE(!extra || out_extra || out_extra_norm, "extra without an output for it");
+  GOL_REQUIRE(N == 0 || records, "null Gaussian records");
+  GOL_REQUIRE((!out_extra && !out_extra_norm) || with_extra || N == 0, "out_extra / out_extra_norm need the extra channel");
+  GOL_REQUIRE(!with_extra || out_extra || out_extra_norm, "extra without an output for it");
   GOL_REQUIRE(!l1_target || (planar && l1_sign && l1_partial), "the fused L1 needs planar images, l1_sign and l1_partial");
   GOL_REQUIRE(!l1_mask || (l1_target && (l1_mask_c == 1 || l1_mask_c == 3)), "l1_mask: 1 or 3 channels, with l1_target");
-  const int tiles_x = (img_w + 15) / 16, tiles_y = (img_h + 15) / 16, T = tiles_x * tiles_y;
+  const int tiles_x = (img_w + 15) / 16, tiles_y = (img_h + 15) / 16;
   dim3 grid(8 * ((tiles_y + 7) / 8) * tiles_x, B);
   const int2* bins = reinterpret_cast<const int2*>(tile_bins);
   hipStream_t s = (hipStream_t)stream;
   if (out_extra || out_extra_norm)
-    raster_fwd_kernel<true><<<grid, 128, 0, s>>>(N, img_h, img_w, planar, tiles_x, tiles_y, bins, sorted_ids, capacity, xys,
-                                                  conics, colors, extra, opacities, background, out_img, out_extra,
-                                                  final_Ts, final_idx, out_alpha, out_extra_norm, norm_lo, l1_target,
-                                                  l1_mask, l1_mask_c, l1_sign, l1_partial);
+    raster_fwd_kernel<true><<<grid, 128, 0, s>>>(N, img_h, img_w, planar, tiles_x, tiles_y, bins, sorted_ids, capacity,
+                                                  records, background, out_img, out_extra, final_Ts, final_idx, out_alpha,
+                                                  out_extra_norm, norm_lo, l1_target, l1_mask, l1_mask_c, l1_sign,
+                                                  l1_partial);
   else
-    raster_fwd_kernel<false><<<grid, 128, 0, s>>>(N, img_h, img_w, planar, tiles_x, tiles_y, bins, sorted_ids, capacity, xys,
-                                                   conics, colors, extra, opacities, background, out_img, out_extra,
-                                                   final_Ts, final_idx, out_alpha, nullptr, norm_lo, l1_target,
-                                                   l1_mask, l1_mask_c, l1_sign, l1_partial);
+    raster_fwd_kernel<false><<<grid, 128, 0, s>>>(N, img_h, img_w, planar, tiles_x, tiles_y, bins, sorted_ids, capacity,
+                                                   records, background, out_img, out_extra, final_Ts, final_idx, out_alpha,
+                                                   nullptr, norm_lo, l1_target, l1_mask, l1_mask_c, l1_sign, l1_partial);
   GOL_CHECK_LAUNCH();
   return GOL_OK;
 }
 
 extern "C" int gol_rasterize_bwd(int B, int N, int img_h, int img_w, int block, int planar, const int32_t* tile_bins,
-                                 const int32_t* sorted_ids, int64_t capacity, const float* xys,
-                                 const float* conics, const float* colors, const float* extra,
-                                 const float* opacities, const float* background, const float* final_Ts,
+                                 const int32_t* sorted_ids, int64_t capacity, const float* records, int with_extra,
+                                 const float* background, const float* final_Ts,
                                  const int32_t* final_idx, const float* v_out_img, const float* v_out_extra,
                                  const float* v_out_alpha, float* v_xy, float* v_conic, float* v_colors,
                                  float* v_extra, float* v_opacity, int grad_stride, const uint8_t* v_sign,
@@ -582,9 +596,9 @@ extern "C" int gol_rasterize_bwd(int B, int N, int img_h, int img_w, int block, 
   GOL_REQUIRE(v_out_img || v_sign, "no upstream image gradient (v_out_img or v_sign)");
   GOL_REQUIRE(!v_sign || planar, "the sign image of the fused L1 goes with planar images");
   GOL_REQUIRE(!v_sign_mask || (v_sign && (v_sign_mask_c == 1 || v_sign_mask_c == 3)), "v_sign_mask: 1 or 3 channels, with v_sign");
-  GOL_REQUIRE(xys && conics && colors && opacities, "null Gaussian attribute");
+  GOL_REQUIRE(records, "null Gaussian records");
   GOL_REQUIRE(v_xy && v_conic && v_colors && v_opacity, "null gradient output");
-  GOL_REQUIRE(!(v_out_extra || v_extra) || extra, "extra-channel gradients need extra");
+  GOL_REQUIRE(!(v_out_extra || v_extra) || with_extra, "extra-channel gradients need the extra channel");
   GOL_REQUIRE(grad_stride == 0 || grad_stride == GOL_GRAD_RECORD, "grad_stride must be 0 (dense arrays) or 16 (records)");
   const bool packed = grad_stride == GOL_GRAD_RECORD;
   if (packed)
@@ -595,10 +609,10 @@ extern "C" int gol_rasterize_bwd(int B, int N, int img_h, int img_w, int block, 
   dim3 grid(8 * ((tiles_y + 7) / 8) * tiles_x, B);
   const int2* bins = reinterpret_cast<const int2*>(tile_bins);
   hipStream_t s = (hipStream_t)stream;
-  const bool ex = extra && (v_out_extra || v_extra);
+  const bool ex = with_extra && (v_out_extra || v_extra);
 #define GOL_LAUNCH_BWD(EX, PK)                                                                                      \
   raster_bwd_kernel<EX, PK><<<grid, 128, 0, s>>>(N, img_h, img_w, planar, tiles_x, tiles_y, bins, sorted_ids, capacity, \
-                                                 xys, conics, colors, EX ? extra : nullptr, opacities, background,    \
+                                                 records, background,                                                 \
                                                  final_Ts, final_idx, v_out_img, EX ? v_out_extra : nullptr,          \
                                                  v_out_alpha, v_xy, v_conic, v_colors, EX ? v_extra : nullptr, v_opacity, \
                                                  v_sign, v_sign_mask, v_sign_mask_c, v_img_scale)

@@ -22,6 +22,7 @@ from ._lib import c_float, c_i64, c_int, fptr, iptr, ptr, stream_ptr
 
 BLOCK = 16  # tile width; the reference's only value (render_gsplat.py:28)
 GRAD_RECORD = 16  # include/goliath_hip.h: GOL_GRAD_RECORD
+SPLAT_RECORD = 16  # include/goliath_hip.h: GOL_SPLAT_RECORD (the rasterizer's packed per-Gaussian record, 64 bytes)
 
 
 def _tiles(img_h, img_w, block=BLOCK):
@@ -158,9 +159,11 @@ def _bin_sort(B, N, xys, depths, radii, img_h, img_w, ws, conics=None, opacities
 
 
 def _project_fwd(B, N, means, scales, glob_scale, quats, viewmats, intrins, img_h, img_w, clip,
-                 opacities=None):
+                 opacities=None, colors=None):
+    """colors (with opacities) given: also returns the rasterizer's packed records[B,N,16] (depth as the 4th channel)."""
     dev = means.device
     f = dict(dtype=torch.float32, device=dev)
+    records = torch.empty(B, N, SPLAT_RECORD, **f) if colors is not None else None
     cov3d = torch.empty(B, N, 6, **f)
     xys = torch.empty(B, N, 2, **f)
     depths = torch.empty(B, N, **f)
@@ -173,8 +176,18 @@ def _project_fwd(B, N, means, scales, glob_scale, quats, viewmats, intrins, img_
               c_float(glob_scale), fptr(quats, "quats"), fptr(viewmats, "viewmat"), fptr(intrins, "intrins"),
               c_int(img_h), c_int(img_w), c_int(BLOCK), c_float(clip), fptr(cov3d), fptr(xys), fptr(depths),
               iptr(radii), fptr(conics), fptr(comp), iptr(nth), fptr(opacities, "opacity"), fptr(opac_eff),
-              stream_ptr())
+              fptr(colors, "colors"), fptr(records), stream_ptr())
+    if colors is not None:
+        return cov3d, xys, depths, radii, conics, comp, nth, opac_eff, records
     return cov3d, xys, depths, radii, conics, comp, nth, opac_eff
+
+
+def _pack_records(B, N, xys, conics, colors, extra, opacities):
+    """gol_splat_pack: the rasterizer's packed records from gsplat-style attribute arrays."""
+    records = torch.empty(B, N, SPLAT_RECORD, dtype=torch.float32, device=xys.device)
+    _lib.call("gol_splat_pack", c_int(B), c_int(N), fptr(xys), fptr(conics), fptr(colors), fptr(extra), fptr(opacities),
+              fptr(records), stream_ptr())
+    return records
 
 
 def _f32c(t):
@@ -263,13 +276,14 @@ class _RasterizeGaussians(torch.autograd.Function):
             final_idx = torch.empty(1, img_height, img_width, dtype=torch.int32, device=dev)
             with _lib.device_guard(dev):
                 _bin_sort(1, N, xys, depths, radii, img_height, img_width, ws, conics, opacity)
+                records = _pack_records(1, N, xys, conics, colors, None, opacity)
                 _lib.call("gol_rasterize_fwd", c_int(1), c_int(N), c_int(img_height), c_int(img_width),
-                          c_int(BLOCK), c_int(0), iptr(ws.tile_bins), iptr(ws.sorted_ids), c_i64(ws.capacity), fptr(xys),
-                          fptr(conics), fptr(colors), fptr(None), fptr(opacity), fptr(background),
+                          c_int(BLOCK), c_int(0), iptr(ws.tile_bins), iptr(ws.sorted_ids), c_i64(ws.capacity),
+                          fptr(records), c_int(0), fptr(background),
                           fptr(out_img), fptr(None), fptr(final_Ts), iptr(final_idx), fptr(None), fptr(None),
                           c_float(0.0), fptr(None), fptr(None), c_int(0), fptr(None), fptr(None), stream_ptr())
             ctx.ws = ws
-            ctx.save_for_backward(xys, conics, colors, opacity, background, final_Ts, final_idx)
+            ctx.save_for_backward(xys, conics, colors, opacity, background, final_Ts, final_idx, records)
             out_img, final_Ts = out_img[0], final_Ts[0]
         if return_alpha:
             return out_img, 1 - final_Ts
@@ -285,15 +299,15 @@ class _RasterizeGaussians(torch.autograd.Function):
         v_colors = torch.zeros_like(colors)
         v_opacity = torch.zeros(N, device=xys.device)
         if ctx.n_isect >= 1 and v_out_img is not None:
-            final_Ts, final_idx = saved[5], saved[6]
+            final_Ts, final_idx, records = saved[5], saved[6], saved[7]
             H, W = ctx.dims
             ws = ctx.ws
             va = None if v_out_alpha is None else _f32c(v_out_alpha)
             vo = _f32c(v_out_img)
             with _lib.device_guard(xys.device):
                 _lib.call("gol_rasterize_bwd", c_int(1), c_int(N), c_int(H), c_int(W), c_int(BLOCK), c_int(0),
-                          iptr(ws.tile_bins), iptr(ws.sorted_ids), c_i64(ws.capacity), fptr(xys), fptr(conics),
-                          fptr(colors), fptr(None), fptr(opacity), fptr(background), fptr(final_Ts),
+                          iptr(ws.tile_bins), iptr(ws.sorted_ids), c_i64(ws.capacity), fptr(records), c_int(0),
+                          fptr(background), fptr(final_Ts),
                           iptr(final_idx), fptr(vo), fptr(None), fptr(va), fptr(v_xy),
                           fptr(v_conic), fptr(v_colors), fptr(None), fptr(v_opacity), c_int(0), fptr(None), fptr(None),
                           c_int(0), fptr(None), stream_ptr())
@@ -341,9 +355,9 @@ class _RenderViews(torch.autograd.Function):
         dev = means.device
         T = _tiles(img_h, img_w)
         with _lib.device_guard(dev):
-            cov3d, xys, depths, radii, conics, comp, nth, opac_eff = _project_fwd(
+            cov3d, xys, depths, radii, conics, comp, nth, opac_eff, records = _project_fwd(
                 B, N, means, scales, glob_scale, quats, viewmats, intrins, img_h, img_w, clip_thresh,
-                opacities=opacity)
+                opacities=opacity, colors=colors)
             out_img = torch.empty(B, 3, img_h, img_w, device=dev)  # planar, as the model consumes it
             out_depth = torch.empty(B, img_h, img_w, device=dev) if with_depth and raw_depth else None
             final_Ts = torch.empty(B, img_h, img_w, device=dev)
@@ -362,8 +376,8 @@ class _RenderViews(torch.autograd.Function):
                 _bin_sort(B, N, xys, depths, radii, img_h, img_w, ws, conics, opac_eff)
                 pending = PLANNER.fetch(ws.n_isect) if plan_key is not None and B > 0 else None
                 _lib.call("gol_rasterize_fwd", c_int(B), c_int(N), c_int(img_h), c_int(img_w), c_int(BLOCK), c_int(1),
-                          iptr(ws.tile_bins), iptr(ws.sorted_ids), c_i64(ws.capacity), fptr(xys), fptr(conics),
-                          fptr(colors), fptr(depths if with_depth else None), fptr(opac_eff), fptr(background),
+                          iptr(ws.tile_bins), iptr(ws.sorted_ids), c_i64(ws.capacity), fptr(records),
+                          c_int(1 if with_depth else 0), fptr(background),
                           fptr(out_img), fptr(out_depth), fptr(final_Ts), iptr(final_idx), fptr(alpha),
                           fptr(depth_norm), c_float(depth_norm_lo), fptr(l1_target), fptr(l1_mask), c_int(l1_mask_c),
                           ptr(l1_sign, torch.uint8), fptr(l1_partial), stream_ptr())
@@ -387,7 +401,7 @@ class _RenderViews(torch.autograd.Function):
         ctx.l1_inv_n = 1.0 / max(B * 3 * img_h * img_w, 1)
         l1 = l1_partial.sum() * ctx.l1_inv_n if l1_target is not None else None  # == mean(|(rgb - target) * mask|)
         ctx.save_for_backward(means, scales, quats, opacity, colors, viewmats, intrins, background, cov3d, xys,
-                              depths, radii, conics, comp, opac_eff, final_Ts, final_idx, l1_sign, l1_mask)
+                              depths, radii, conics, comp, opac_eff, final_Ts, final_idx, l1_sign, l1_mask, records)
         ctx.mark_non_differentiable(radii, ws.n_isect, final_Ts, final_idx, ws.sorted_ids, ws.tile_bins)
         ctx.set_materialize_grads(False)
         return (out_img, alpha, out_depth, depth_norm, l1, radii, ws.n_isect, final_Ts, final_idx, ws.sorted_ids,
@@ -396,7 +410,7 @@ class _RenderViews(torch.autograd.Function):
     @staticmethod
     def backward(ctx, v_img, v_alpha, v_depth, v_depth_norm, v_l1, *_non_differentiable):
         (means, scales, quats, opacity, colors, viewmats, intrins, background, cov3d, xys, depths, radii,
-         conics, comp, opac_eff, final_Ts, final_idx, l1_sign, l1_mask) = ctx.saved_tensors
+         conics, comp, opac_eff, final_Ts, final_idx, l1_sign, l1_mask, records) = ctx.saved_tensors
         img_h, img_w, glob_scale, with_depth, depth_norm_lo = ctx.cfg
         B, N = means.shape[:2]
         dev = means.device
@@ -432,8 +446,8 @@ class _RenderViews(torch.autograd.Function):
         v_opacity = torch.empty_like(opacity)
         with _lib.device_guard(dev):
             _lib.call("gol_rasterize_bwd", c_int(B), c_int(N), c_int(img_h), c_int(img_w), c_int(BLOCK), c_int(1),
-                      iptr(ws.tile_bins), iptr(ws.sorted_ids), c_i64(ws.capacity), fptr(xys), fptr(conics),
-                      fptr(colors), fptr(depths if use_depth else None), fptr(opac_eff), fptr(background),
+                      iptr(ws.tile_bins), iptr(ws.sorted_ids), c_i64(ws.capacity), fptr(records),
+                      c_int(1 if use_depth else 0), fptr(background),
                       fptr(final_Ts), iptr(final_idx), fptr(v_img_c), fptr(v_depth_c), fptr(v_alpha_c),
                       field(4), field(6), field(0),
                       field(9) if use_depth else fptr(None), field(3), c_int(GRAD_RECORD), ptr(v_sign, torch.uint8),

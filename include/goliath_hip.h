@@ -65,14 +65,17 @@ int gol_sg_eval_bwd(int N, int D, int L, const float* lobe_dirs, const float* lo
  * Batched over B views: viewmats[B,12] (row-major 3x4 world->camera), intrins[B,4]=(fx,fy,cx,cy)
  * live on the device so no host sync is needed to read K (cf. rgca.py:123-126 .item() x4).
  * Outputs for culled Gaussians are zero (radii = num_tiles_hit = 0).
- * Optional fused extra (pass NULL to skip):
+ * Optional fused extras (pass NULL to skip):
  *   opacities[B,N] -> opac_eff[B,N] = opacity * compensation   (render_gsplat.py:72)
+ *   colors[B,N,3] (+ opacities) -> records[B,N,GOL_SPLAT_RECORD]: the rasterizer's packed per-Gaussian records
+ *   (see gol_rasterize_fwd) with the depth as the 4th channel -- the fused path never assembles them separately.
  * ---------------------------------------------------------------------------------------- */
 int gol_project_fwd(int B, int N, const float* means3d, const float* scales, float glob_scale,
                     const float* quats, const float* viewmats, const float* intrins, int img_h,
                     int img_w, int block, float clip_thresh, float* cov3d, float* xys,
                     float* depths, int32_t* radii, float* conics, float* compensation,
-                    int32_t* num_tiles_hit, const float* opacities, float* opac_eff, void* stream);
+                    int32_t* num_tiles_hit, const float* opacities, float* opac_eff, const float* colors,
+                    float* records, void* stream);
 /* v_* inputs may be NULL (treated as zero).  If opacities != NULL the op also differentiates
  * opac_eff = opacity*compensation: v_opac_eff[B,N] in, v_opacity[B,N] out.
  * grad_stride = 0: v_xy[B,N,2], v_depth[B,N], v_conic[B,N,3], v_opac_eff[B,N] are dense arrays;
@@ -99,10 +102,11 @@ int gol_project_bwd(int B, int N, const float* means3d, const float* scales, flo
  *   tile_bins[B,T,2] out: [start,end) into the view's segment of sorted_ids
  *   isect_keys[B,capacity] uint64 scratch
  *   sorted_ids[B,capacity] out: Gaussian ids, tile by tile, front to back
- *   n_isect[B] out: number of intersections found (> capacity means overflow: the excess
- *                   intersections were dropped and the render is incomplete)
- *   reach_scratch[B,N] optional scratch (NULL = off): the counting pass leaves each Gaussian's exact
- *                   tile-reach bit mask there so the scatter pass does not repeat the ellipse tests
+ *   n_isect[B] out: number of list slots the view needs (> capacity means overflow: the excess
+ *                   intersections were dropped and the render is incomplete).  Without conics this is gsplat's exact
+ *                   intersection count; with conics it is an upper bound (the tight tile boxes, ~1.2x the pruned
+ *                   lists: the count pass reserves, the scatter pass tests) and a view's lists have slack between them
+ *   reach_scratch   unused since round 3 (pass NULL; kept for ABI stability)
  * ---------------------------------------------------------------------------------------- */
 int gol_bin_sort(int B, int N, const float* xys, const float* depths, const int32_t* radii,
                  const float* conics, const float* opacities, int img_h, int img_w, int block,
@@ -112,7 +116,13 @@ int gol_bin_sort(int B, int N, const float* xys, const float* depths, const int3
 /* ------------------------------------------------------------------------------------------
  * Tile rasterizer.  Replaces gsplat: rasterize_forward / rasterize_backward, 3-channel
  * specialisation (call sites render_gsplat.py:65-78, 91-104; semantics SURVEY.md A.3, A.4).
- * One launch composites colours[B,N,3] and, when extra != NULL, a 4th channel extra[B,N]
+ * Gaussian attributes come as PACKED RECORDS records[B,N,GOL_SPLAT_RECORD] (64 bytes = one HBM sector per Gaussian):
+ *   [0] x [1] y [2] a' [3] b' | [4] c' [5] opacity [6] r [7] g | [8] b [9] extra [10] tau [11] 1/a | [12] 1/c [13] exact [14-15] pad
+ *   (a', b', c' = the conic scaled for the pixel loops, tau / 1/a / 1/c / exact = the per-Gaussian part of the
+ *   alpha >= 1/255 reach test; goliath_amd/csrc/gol_common.h) written by gol_project_fwd (fused path) or by
+ *   gol_splat_pack from xys[B,N,2], conics[B,N,3], colors[B,N,3], extra[B,N] (NULL = 0), opacities[B,N] (the
+ *   gsplat-compatible operators): a list entry costs one aligned 64-byte fetch instead of up to five sectors of five arrays.
+ * One launch composites the colour and, with with_extra != 0, the 4th channel "extra" of the records
  * (the depth pass of render_gsplat.py:91-104 fused into the colour pass; its background is 0).
  *   planar = 0: out_img / v_out_img are [B,H,W,3] (gsplat); planar = 1: [B,3,H,W] (what
  *   AutoEncoder.render stacks, rgca.py:139 -- saves the permute copy in the backward).
@@ -138,17 +148,18 @@ int gol_bin_sort(int B, int N, const float* xys, const float* depths, const int3
  *   loss without the two extra passes over the image a separate loss kernel needs; at least one of v_out_img / v_sign.
  * ---------------------------------------------------------------------------------------- */
 #define GOL_GRAD_RECORD 16
+#define GOL_SPLAT_RECORD 16
+int gol_splat_pack(int B, int N, const float* xys, const float* conics, const float* colors, const float* extra,
+                   const float* opacities, float* records, void* stream);
 int gol_rasterize_fwd(int B, int N, int img_h, int img_w, int block, int planar, const int32_t* tile_bins,
-                      const int32_t* sorted_ids, int64_t capacity, const float* xys,
-                      const float* conics, const float* colors, const float* extra,
-                      const float* opacities, const float* background, float* out_img,
+                      const int32_t* sorted_ids, int64_t capacity, const float* records, int with_extra,
+                      const float* background, float* out_img,
                       float* out_extra, float* final_Ts, int32_t* final_idx, float* out_alpha,
                       float* out_extra_norm, float norm_lo, const float* l1_target, const float* l1_mask, int l1_mask_c,
                       uint8_t* l1_sign, float* l1_partial, void* stream);
 int gol_rasterize_bwd(int B, int N, int img_h, int img_w, int block, int planar, const int32_t* tile_bins,
-                      const int32_t* sorted_ids, int64_t capacity, const float* xys,
-                      const float* conics, const float* colors, const float* extra,
-                      const float* opacities, const float* background, const float* final_Ts,
+                      const int32_t* sorted_ids, int64_t capacity, const float* records, int with_extra,
+                      const float* background, const float* final_Ts,
                       const int32_t* final_idx, const float* v_out_img, const float* v_out_extra,
                       const float* v_out_alpha, float* v_xy, float* v_conic, float* v_colors,
                       float* v_extra, float* v_opacity, int grad_stride, const uint8_t* v_sign, const float* v_sign_mask,

@@ -78,17 +78,18 @@ def main(n_views):
             dnorm = torch.empty(1, H, W, device=dev)
             sign = torch.empty(1, H, W, dtype=torch.uint8, device=dev)
             part = torch.empty(1, T, device=dev)
+            records = splat._pack_records(1, N, d_xy, d_con, d_col, d_dep, d_op)
             _lib.call("gol_rasterize_fwd", c_int(1), c_int(N), c_int(H), c_int(W), c_int(16), c_int(1),
-                      iptr(ws.tile_bins), iptr(ws.sorted_ids), c_i64(ws.capacity), fptr(d_xy), fptr(d_con), fptr(d_col),
-                      fptr(d_dep), fptr(d_op), fptr(bgd), fptr(out_img), fptr(None), fptr(fT), iptr(fidx), fptr(alpha),
+                      iptr(ws.tile_bins), iptr(ws.sorted_ids), c_i64(ws.capacity), fptr(records), c_int(1),
+                      fptr(bgd), fptr(out_img), fptr(None), fptr(fT), iptr(fidx), fptr(alpha),
                       fptr(dnorm), c_float(0.05), fptr(d_tgt), fptr(None), c_int(0), ptr(sign, torch.uint8), fptr(part),
                       stream_ptr())
             rec = torch.zeros(1, N, 16, device=dev)
             field = lambda k: ctypes.c_void_p(rec.data_ptr() + 4 * k)
             vsc = torch.full((1,), scale, device=dev)
             _lib.call("gol_rasterize_bwd", c_int(1), c_int(N), c_int(H), c_int(W), c_int(16), c_int(1),
-                      iptr(ws.tile_bins), iptr(ws.sorted_ids), c_i64(ws.capacity), fptr(d_xy), fptr(d_con), fptr(d_col),
-                      fptr(None), fptr(d_op), fptr(bgd), fptr(fT), iptr(fidx), fptr(None), fptr(None), fptr(None),
+                      iptr(ws.tile_bins), iptr(ws.sorted_ids), c_i64(ws.capacity), fptr(records), c_int(0),
+                      fptr(bgd), fptr(fT), iptr(fidx), fptr(None), fptr(None), fptr(None),
                       field(4), field(6), field(0), fptr(None), field(3), c_int(16), ptr(sign, torch.uint8), fptr(None),
                       c_int(0), fptr(vsc), stream_ptr())
             torch.cuda.synchronize()
