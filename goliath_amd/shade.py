@@ -52,14 +52,36 @@ def _p(t, dtype=torch.float32):
     return _lib.ptr(t, dtype).value if t is not None else None
 
 
+_PACKED = {}   # (data_ptr, shape, _version) -> (the level tensor, packed copy): the pyramid is static across frames
+
+
 def pack_envmap(mips):
-    """[B,3,h,w] mip levels -> [B,h,w,4] texel-interleaved copies for 16-byte gathers."""
+    """[B,3,h,w] mip levels -> [B,h,w,4] texel-interleaved copies for 16-byte gathers.  The reference builds the
+    SG-prefiltered pyramid once per environment (light_decorator.py:18-164) and only rotates it per frame (`lightrot`),
+    so the packed copy of a level is cached on the tensor's memory and in-place version counter: a level that was
+    neither replaced nor written since the last call is not packed again (4 launches per step in rounds 1-2).  The cache
+    keeps the source tensor alive (at most 16 levels), so its address cannot be handed to another tensor meanwhile."""
     out = []
     for m in mips:
+        key = (m.data_ptr(), tuple(m.shape), m._version, m.device.index)
+        hit = _PACKED.get(key)
+        if hit is not None:
+            if hit[2] is not None:          # packed on another stream and possibly still in flight: order after it
+                if hit[2].query():
+                    _PACKED[key] = (hit[0], hit[1], None)
+                else:
+                    torch.cuda.current_stream(m.device).wait_event(hit[2])
+            out.append(hit[1])
+            continue
         B, _, h, w = m.shape
         p = torch.empty(B, h, w, 4, device=m.device)
         _lib.call("gol_envmap_pack", _lib.c_int(B), _lib.c_int(h), _lib.c_int(w), _lib.fptr(m), _lib.fptr(p),
                   stream_ptr())
+        while len(_PACKED) >= 16:
+            _PACKED.pop(next(iter(_PACKED)))   # oldest entry
+        ev = torch.cuda.Event()
+        ev.record()
+        _PACKED[key] = (m, p, ev)
         out.append(p)
     return out
 

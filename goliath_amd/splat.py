@@ -33,14 +33,20 @@ def _tiles(img_h, img_w, block=BLOCK):
 # Intersection-capacity planning (replaces gsplat's host sync on the intersection count).
 # --------------------------------------------------------------------------------------------
 class CapacityPlanner:
-    """Per-shape capacity (max Gaussian/tile intersections per view) of the batched render path.
+    """Per-shape capacity (max Gaussian/tile list slots per view) of the batched render path.
 
-    mode "verify" (default): every render_views call launches the whole forward at the planned
-        capacity, then waits on an event recorded right after binning (the true counts land in a
-        pre-allocated pinned buffer).  The wait is normally free -- the raster kernels are still
-        queued behind it -- and if a view overflowed, binning + raster are re-run at a grown
-        capacity INSIDE the same call, in stream order, before any consumer can read the image.
-        No exception ever reaches the caller (ca_code/utils/train.py:170-214 knows none of ours).
+    mode "adaptive" (default): a call BLOCKS on its own counts only while that can matter -- the shape is new, or the
+        last observed count came within 1.5x of the capacity.  Blocking means: the whole forward is launched at the
+        planned capacity, then the host waits on an event recorded right after binning (the true counts land in a
+        pre-allocated pinned buffer; the raster kernels are still queued behind the wait) and, if a view overflowed,
+        binning + raster are re-run at a grown capacity INSIDE the same call, in stream order, before any consumer
+        can read the image.  With 2x head-room in the plan the steady state of a training run never blocks: the counts
+        are read back when their copy has landed (next call) and only move the plan.  Should the lists then still
+        outgrow a 1.5x margin within ONE step, that step rendered with truncated lists (the deepest entries of the
+        fullest tiles dropped): a RuntimeWarning says so, `truncated` counts it, the capacity is raised, and the next
+        call is a blocking one again.  No exception reaches the caller (ca_code/utils/train.py:170-214 knows none of ours).
+    mode "verify": every call blocks and repairs in place (rounds 1-2 default): nothing is ever truncated, and an
+        eager loop can never run ahead of the GPU (measured: 1.35 ms of host wait per 8-view step).
     mode "async": nothing waits; the counts are inspected at the NEXT call and an overflow raises
         (after growing the capacity) -- for benchmark loops that must not block the host.
     frozen: while a HIP graph is captured / replayed: no host copies; check_frozen() afterwards.
@@ -49,11 +55,13 @@ class CapacityPlanner:
 
     def __init__(self):
         self.capacity = {}
-        self.mode = os.environ.get("GOLIATH_CAPACITY_MODE", "verify")
-        self.pending = []        # async mode: (event, pinned counts, capacity, key)
+        self.mode = os.environ.get("GOLIATH_CAPACITY_MODE", "adaptive")
+        self.pending = []        # deferred checks: (event, pinned counts, capacity, key)
         self.frozen = False      # True while a HIP graph is captured / replayed: no polling, no host copies
         self.frozen_log = []     # (n_isect tensor, capacity) of the calls made while frozen -> check_frozen()
-        self.reruns = 0          # verify mode: forwards that had to be re-run at a grown capacity
+        self.reruns = 0          # blocking calls whose forward had to be re-run at a grown capacity
+        self.truncated = 0       # adaptive mode: steps found (after the fact) to have rendered with truncated lists
+        self.last_worst = {}     # key -> most recent observed count
         self._pinned = {}        # B -> free list of pinned int32[B] buffers (allocated once, recycled)
 
     def check_frozen(self):
@@ -64,8 +72,14 @@ class CapacityPlanner:
                 raise _lib.GoliathHipError(f"a captured render_views call overflowed its intersection capacity "
                                            f"({worst} > {capacity}): re-capture with a larger capacity")
 
-    def verify(self):
-        return self.mode != "async" or os.environ.get("GOLIATH_STRICT_CAPACITY", "0") == "1"
+    def must_block(self, key):
+        """Does this call have to wait for its own counts?"""
+        if self.mode == "verify" or os.environ.get("GOLIATH_STRICT_CAPACITY", "0") == "1":
+            return True
+        if self.mode == "async":
+            return False
+        seen, cap = self.last_worst.get(key), self.capacity.get(key)
+        return seen is None or cap is None or seen * 1.5 > cap
 
     def get(self, key):
         return self.capacity.get(key)
@@ -82,6 +96,7 @@ class CapacityPlanner:
 
     def observe(self, key, worst, capacity):
         """Grow early, before it overflows."""
+        self.last_worst[key] = worst
         if key not in self.capacity or worst * 1.5 > capacity:
             self.set(key, worst)
 
@@ -118,6 +133,7 @@ class CapacityPlanner:
                 worst = int(host.max()) if host.numel() else 0
                 self._pinned[host.numel()].append(host)
                 if worst > capacity:
+                    self.last_worst[key] = worst
                     self.set(key, worst)
                     overflow = (worst, capacity, key)
                 else:
@@ -127,10 +143,16 @@ class CapacityPlanner:
         self.pending = still
         if overflow is not None:
             worst, capacity, key = overflow
-            raise _lib.GoliathHipError(
-                f"a previous render_views call overflowed its intersection capacity ({worst} > {capacity}); "
-                f"its image is incomplete. Capacity was raised to {self.capacity[key]} -- re-run the step "
-                f"(GOLIATH_CAPACITY_MODE=verify, the default, recovers inside the call instead).")
+            msg = (f"a previous render_views call overflowed its intersection capacity ({worst} > {capacity}): its tile "
+                   f"lists were truncated. Capacity was raised to {self.capacity[key]}")
+            if self.mode == "async":
+                raise _lib.GoliathHipError(msg + " -- re-run the step (GOLIATH_CAPACITY_MODE=verify repairs inside the "
+                                                 "call instead).")
+            import warnings
+
+            self.truncated += 1
+            warnings.warn(msg + "; the next call checks its own counts before returning "
+                                "(GOLIATH_CAPACITY_MODE=verify checks every call).", RuntimeWarning, stacklevel=3)
 
 
 PLANNER = CapacityPlanner()
@@ -346,7 +368,80 @@ def rasterize_gaussians(xys, depths, radii, conics, num_tiles_hit, colors, opaci
 # --------------------------------------------------------------------------------------------
 # Fused, batched, sync-free path
 # --------------------------------------------------------------------------------------------
+class RenderLayout(ctypes.Structure):
+    """include/goliath_hip.h: gol_render_ws -- byte offsets of the sub-buffers of a render workspace."""
+    _fields_ = [(n, ctypes.c_int64) for n in (
+        "cov3d", "xys", "depths", "radii", "conics", "comp", "nth", "opac_eff", "records", "tile_count", "tile_bins",
+        "keys", "sorted_ids", "n_isect", "final_T", "final_idx", "l1_sign", "total")]
+
+
+_LAYOUTS = {}
+
+
+def _layout(B, N, img_h, img_w, capacity, with_l1):
+    key = (B, N, img_h, img_w, capacity, with_l1)
+    L = _LAYOUTS.get(key)
+    if L is None:
+        L = RenderLayout()
+        _lib.call("gol_render_layout", c_int(B), c_int(N), c_int(img_h), c_int(img_w), c_i64(capacity), c_int(with_l1),
+                  ctypes.byref(L))
+        if len(_LAYOUTS) > 256:
+            _LAYOUTS.clear()
+        _LAYOUTS[key] = L
+    return L
+
+
+def _ws_view(ws, off, dtype, shape):
+    """Typed view of a workspace sub-buffer (no copy)."""
+    n = 1
+    for d in shape:
+        n *= d
+    return ws[off:off + n * torch.empty(0, dtype=dtype).element_size()].view(dtype).view(shape)
+
+
+def _render_fwd_stages(B, N, img_h, img_w, glob_scale, clip, means, scales, quats, opacity, colors, viewmats, intrins,
+                       background, with_depth, norm_lo, cap, ws, L, out_img, out_depth, alpha, depth_norm, l1_target,
+                       l1_mask, l1_mask_c, l1_partial):
+    """gol_render_fwd, stage by stage (what csrc/render.hip composes), for per-stage event timing."""
+    p = lambda off: ctypes.c_void_p(ws.data_ptr() + off) if off >= 0 else ctypes.c_void_p(0)
+    _lib.call("gol_project_fwd", c_int(B), c_int(N), fptr(means), fptr(scales), c_float(glob_scale), fptr(quats),
+              fptr(viewmats), fptr(intrins), c_int(img_h), c_int(img_w), c_int(BLOCK), c_float(clip), p(L.cov3d),
+              p(L.xys), p(L.depths), p(L.radii), p(L.conics), p(L.comp), p(L.nth), fptr(opacity), p(L.opac_eff),
+              fptr(colors), p(L.records), stream_ptr())
+    _lib.call("gol_bin_sort", c_int(B), c_int(N), p(L.xys), p(L.depths), p(L.radii), p(L.conics), p(L.opac_eff),
+              c_int(img_h), c_int(img_w), c_int(BLOCK), c_i64(cap), p(L.tile_count), p(L.tile_bins), p(L.keys),
+              p(L.sorted_ids), p(L.n_isect), ctypes.c_void_p(0), stream_ptr())
+    _lib.call("gol_rasterize_fwd", c_int(B), c_int(N), c_int(img_h), c_int(img_w), c_int(BLOCK), c_int(1),
+              p(L.tile_bins), p(L.sorted_ids), c_i64(cap), p(L.records), c_int(1 if with_depth else 0), fptr(background),
+              fptr(out_img), fptr(out_depth), p(L.final_T), p(L.final_idx), fptr(alpha), fptr(depth_norm),
+              c_float(norm_lo), fptr(l1_target), fptr(l1_mask), c_int(l1_mask_c),
+              p(L.l1_sign) if l1_target is not None else ctypes.c_void_p(0), fptr(l1_partial), stream_ptr())
+
+
+def _render_bwd_stages(B, N, img_h, img_w, glob_scale, means, scales, quats, opacity, viewmats, intrins, background, cap,
+                       ws, L, v_img, v_depth, v_alpha, use_l1, l1_mask, v_scale, rec, v_mean, v_scale_g, v_quat, v_opacity):
+    """gol_render_bwd, stage by stage, for per-stage event timing."""
+    p = lambda off: ctypes.c_void_p(ws.data_ptr() + off) if off >= 0 else ctypes.c_void_p(0)
+    field = lambda k: ctypes.c_void_p(rec.data_ptr() + 4 * k)
+    null = ctypes.c_void_p(0)
+    use_depth = v_depth is not None
+    rec.zero_()
+    _lib.call("gol_rasterize_bwd", c_int(B), c_int(N), c_int(img_h), c_int(img_w), c_int(BLOCK), c_int(1),
+              p(L.tile_bins), p(L.sorted_ids), c_i64(cap), p(L.records), c_int(1 if use_depth else 0), fptr(background),
+              p(L.final_T), p(L.final_idx), fptr(v_img), fptr(v_depth), fptr(v_alpha), field(4), field(6), field(0),
+              field(9) if use_depth else null, field(3), c_int(GRAD_RECORD), p(L.l1_sign) if use_l1 else null,
+              fptr(l1_mask) if use_l1 else null, c_int(0 if (l1_mask is None or not use_l1) else l1_mask.shape[1]),
+              fptr(v_scale), stream_ptr())
+    _lib.call("gol_project_bwd", c_int(B), c_int(N), fptr(means), fptr(scales), c_float(glob_scale), fptr(quats),
+              fptr(viewmats), fptr(intrins), p(L.cov3d), p(L.radii), p(L.conics), p(L.comp), field(4),
+              field(9) if use_depth else null, field(6), null, fptr(opacity), field(3), c_int(GRAD_RECORD), fptr(v_mean),
+              fptr(v_scale_g), fptr(v_quat), fptr(v_opacity), stream_ptr())
+
+
 class _RenderViews(torch.autograd.Function):
+    """The fused path: ONE C-ABI call per direction (gol_render_fwd / gol_render_bwd, csrc/render.hip) out of one
+    workspace allocation; the host work of a direction is that call plus the allocation of its outputs."""
+
     @staticmethod
     def forward(ctx, means, scales, quats, opacity, colors, viewmats, intrins, background, img_h, img_w,
                 glob_scale, clip_thresh, with_depth, capacity, depth_norm_lo, plan_key, l1_target, l1_mask,
@@ -354,113 +449,139 @@ class _RenderViews(torch.autograd.Function):
         B, N = means.shape[:2]
         dev = means.device
         T = _tiles(img_h, img_w)
+        with_l1 = 1 if l1_target is not None else 0
+        f = dict(dtype=torch.float32, device=dev)
+        out_img = torch.empty(B, 3, img_h, img_w, **f)   # planar, as the model consumes it
+        out_depth = torch.empty(B, img_h, img_w, **f) if with_depth and raw_depth else None
+        # alpha = 1 - T and depth / clamp(alpha, lo, 1) come out of the raster epilogue (rgca.py:137,144-145)
+        alpha = torch.empty(B, img_h, img_w, **f)
+        depth_norm = torch.empty(B, img_h, img_w, **f) if with_depth else None
+        # optional fused L1 against a target image: per-tile sums here, the sign codes (the loss gradient up to mask x
+        # scalar; one byte per pixel) in the workspace
+        l1_partial = torch.empty(B, T, **f) if with_l1 else None
+        l1_mask_c = 0 if l1_mask is None else l1_mask.shape[1]
+
+        def run(cap):
+            L = _layout(B, N, img_h, img_w, cap, with_l1)
+            ws = torch.empty(max(L.total, 1), dtype=torch.uint8, device=dev)
+            if _lib.TIMING is not None:
+                # instrumented pass (bench.py): the same work as three ABI calls, so that events bracket each stage
+                _render_fwd_stages(B, N, img_h, img_w, glob_scale, clip_thresh, means, scales, quats, opacity, colors,
+                                   viewmats, intrins, background, with_depth, depth_norm_lo, cap, ws, L, out_img,
+                                   out_depth, alpha, depth_norm, l1_target, l1_mask, l1_mask_c, l1_partial)
+            else:
+                _lib.call("gol_render_fwd", c_int(B), c_int(N), c_int(img_h), c_int(img_w), c_float(glob_scale),
+                          c_float(clip_thresh), fptr(means), fptr(scales), fptr(quats), fptr(opacity), fptr(colors),
+                          fptr(viewmats), fptr(intrins), fptr(background), c_int(1 if with_depth else 0),
+                          c_float(depth_norm_lo), c_i64(cap), ctypes.c_void_p(ws.data_ptr()), ctypes.byref(L),
+                          fptr(out_img), fptr(out_depth), fptr(alpha), fptr(depth_norm), fptr(l1_target), fptr(l1_mask),
+                          c_int(l1_mask_c), fptr(l1_partial), stream_ptr())
+            n_isect = _ws_view(ws, L.n_isect, torch.int32, (B,))
+            pending = PLANNER.fetch(n_isect) if plan_key is not None and B > 0 else None
+            return ws, L, n_isect, pending
+
         with _lib.device_guard(dev):
-            cov3d, xys, depths, radii, conics, comp, nth, opac_eff, records = _project_fwd(
-                B, N, means, scales, glob_scale, quats, viewmats, intrins, img_h, img_w, clip_thresh,
-                opacities=opacity, colors=colors)
-            out_img = torch.empty(B, 3, img_h, img_w, device=dev)  # planar, as the model consumes it
-            out_depth = torch.empty(B, img_h, img_w, device=dev) if with_depth and raw_depth else None
-            final_Ts = torch.empty(B, img_h, img_w, device=dev)
-            final_idx = torch.empty(B, img_h, img_w, dtype=torch.int32, device=dev)
-            # alpha = 1 - T and depth / clamp(alpha, lo, 1) come out of the raster epilogue (rgca.py:137,144-145)
-            alpha = torch.empty(B, img_h, img_w, device=dev)
-            depth_norm = torch.empty(B, img_h, img_w, device=dev) if with_depth else None
-            # optional fused L1 against a target image: sign codes (the loss gradient up to mask x scalar; one byte per
-            # pixel) + per-tile sums
-            l1_sign = torch.empty(B, img_h, img_w, dtype=torch.uint8, device=dev) if l1_target is not None else None
-            l1_partial = torch.empty(B, T, device=dev) if l1_target is not None else None
-            l1_mask_c = 0 if l1_mask is None else l1_mask.shape[1]
-
-            def bin_and_raster(cap):
-                ws = _Workspace(B, N, T, cap, dev)
-                _bin_sort(B, N, xys, depths, radii, img_h, img_w, ws, conics, opac_eff)
-                pending = PLANNER.fetch(ws.n_isect) if plan_key is not None and B > 0 else None
-                _lib.call("gol_rasterize_fwd", c_int(B), c_int(N), c_int(img_h), c_int(img_w), c_int(BLOCK), c_int(1),
-                          iptr(ws.tile_bins), iptr(ws.sorted_ids), c_i64(ws.capacity), fptr(records),
-                          c_int(1 if with_depth else 0), fptr(background),
-                          fptr(out_img), fptr(out_depth), fptr(final_Ts), iptr(final_idx), fptr(alpha),
-                          fptr(depth_norm), c_float(depth_norm_lo), fptr(l1_target), fptr(l1_mask), c_int(l1_mask_c),
-                          ptr(l1_sign, torch.uint8), fptr(l1_partial), stream_ptr())
-                return ws, pending
-
-            ws, pending = bin_and_raster(capacity)
+            ws, L, n_isect, pending = run(capacity)
             if pending is not None:
                 # the counts were final after the tile scan; the raster is still queued behind this wait
                 worst = PLANNER.finish(*pending)
                 if worst > capacity:
-                    # some lists were truncated: grow and redo binning + raster into the SAME output buffers, in
-                    # stream order, before anything downstream can read them
+                    # some lists were truncated: grow and redo the call into the SAME output buffers, in stream
+                    # order, before anything downstream can read them
                     capacity = PLANNER.set(plan_key, worst)
+                    PLANNER.last_worst[plan_key] = worst
                     PLANNER.reruns += 1
-                    ws, pending = bin_and_raster(capacity)
+                    ws, L, n_isect, pending = run(capacity)
                     PLANNER.finish(*pending)
                 else:
                     PLANNER.observe(plan_key, worst, capacity)
-        ctx.ws = ws
-        ctx.cfg = (img_h, img_w, glob_scale, with_depth, depth_norm_lo)
+        ctx.L, ctx.capacity = L, capacity
+        ctx.cfg = (img_h, img_w, glob_scale, with_depth, depth_norm_lo, with_l1)
         ctx.l1_inv_n = 1.0 / max(B * 3 * img_h * img_w, 1)
-        l1 = l1_partial.sum() * ctx.l1_inv_n if l1_target is not None else None  # == mean(|(rgb - target) * mask|)
-        ctx.save_for_backward(means, scales, quats, opacity, colors, viewmats, intrins, background, cov3d, xys,
-                              depths, radii, conics, comp, opac_eff, final_Ts, final_idx, l1_sign, l1_mask, records)
-        ctx.mark_non_differentiable(radii, ws.n_isect, final_Ts, final_idx, ws.sorted_ids, ws.tile_bins)
+        l1 = l1_partial.sum() * ctx.l1_inv_n if with_l1 else None  # == mean(|(rgb - target) * mask|)
+        ctx.save_for_backward(means, scales, quats, opacity, viewmats, intrins, background, ws, l1_mask)
+        ctx.mark_non_differentiable(ws, n_isect)
         ctx.set_materialize_grads(False)
-        return (out_img, alpha, out_depth, depth_norm, l1, radii, ws.n_isect, final_Ts, final_idx, ws.sorted_ids,
-                ws.tile_bins)
+        return out_img, alpha, out_depth, depth_norm, l1, ws, n_isect
 
     @staticmethod
     def backward(ctx, v_img, v_alpha, v_depth, v_depth_norm, v_l1, *_non_differentiable):
-        (means, scales, quats, opacity, colors, viewmats, intrins, background, cov3d, xys, depths, radii,
-         conics, comp, opac_eff, final_Ts, final_idx, l1_sign, l1_mask, records) = ctx.saved_tensors
-        img_h, img_w, glob_scale, with_depth, depth_norm_lo = ctx.cfg
+        means, scales, quats, opacity, viewmats, intrins, background, ws, l1_mask = ctx.saved_tensors
+        img_h, img_w, glob_scale, with_depth, depth_norm_lo, with_l1 = ctx.cfg
         B, N = means.shape[:2]
         dev = means.device
-        ws = ctx.ws
+        L = ctx.L
         if v_depth_norm is not None:  # depth_norm = depth / clamp(alpha.detach(), lo, 1), alpha = 1 - final_T
+            final_Ts = _ws_view(ws, L.final_T, torch.float32, (B, img_h, img_w))
             g = v_depth_norm / (1.0 - final_Ts).clamp(depth_norm_lo, 1.0)
             v_depth = g if v_depth is None else v_depth + g
-        if l1_sign is None:
+        if not with_l1:
             v_l1 = None
         if v_img is None and v_alpha is None and v_depth is None and v_l1 is None:
             return (None,) * 19
         # fused L1: d loss / d rgb = (sign code - 1) * mask * (v_l1 / n).  The raster backward decodes the sign bytes itself
         # and adds the term to v_img (if the image has another consumer); the scalar goes in as a device value: no sync,
         # no pass over the image
-        v_scale, v_sign, v_sign_mask = None, None, None
+        v_scale = None
         if v_l1 is not None:
             v_scale = (v_l1.to(torch.float32) * ctx.l1_inv_n).reshape(1).contiguous()
-            v_sign, v_sign_mask = l1_sign, l1_mask
-        if v_img is None and v_sign is None:
+        if v_img is None and v_l1 is None:
             v_img = torch.zeros(B, 3, img_h, img_w, device=dev)
         use_depth = with_depth and v_depth is not None
         # converted upstream gradients stay bound to locals until the launches below are issued
         v_img_c = None if v_img is None else _f32c(v_img)
         v_depth_c = _f32c(v_depth) if use_depth else None
         v_alpha_c = None if v_alpha is None else _f32c(v_alpha)
-        # one zeroed buffer of 64-byte gradient records per Gaussian (include/goliath_hip.h: GOL_GRAD_RECORD):
-        # a Gaussian's float atomics hit one cache line and are issued by 16 adjacent lanes
-        rec = torch.zeros(B, N, GRAD_RECORD, device=dev)
-        field = lambda k: ctypes.c_void_p(rec.data_ptr() + 4 * k)
+        # 64-byte gradient records per Gaussian (include/goliath_hip.h: GOL_GRAD_RECORD), zeroed by the call: a Gaussian's
+        # float atomics hit one cache line and are issued by 16 adjacent lanes
+        rec = torch.empty(B, N, GRAD_RECORD, device=dev)
         v_mean = torch.empty_like(means)
         v_scale_g = torch.empty_like(scales)
         v_quat = torch.empty_like(quats)
         v_opacity = torch.empty_like(opacity)
+        use_mask = l1_mask if v_l1 is not None else None
+        if _lib.TIMING is not None:
+            with _lib.device_guard(dev):
+                _render_bwd_stages(B, N, img_h, img_w, glob_scale, means, scales, quats, opacity, viewmats, intrins,
+                                   background, ctx.capacity, ws, L, v_img_c, v_depth_c, v_alpha_c, v_l1 is not None,
+                                   use_mask, v_scale, rec, v_mean, v_scale_g, v_quat, v_opacity)
+            return (v_mean, v_scale_g, v_quat, v_opacity, rec[..., :3]) + (None,) * 14
         with _lib.device_guard(dev):
-            _lib.call("gol_rasterize_bwd", c_int(B), c_int(N), c_int(img_h), c_int(img_w), c_int(BLOCK), c_int(1),
-                      iptr(ws.tile_bins), iptr(ws.sorted_ids), c_i64(ws.capacity), fptr(records),
-                      c_int(1 if use_depth else 0), fptr(background),
-                      fptr(final_Ts), iptr(final_idx), fptr(v_img_c), fptr(v_depth_c), fptr(v_alpha_c),
-                      field(4), field(6), field(0),
-                      field(9) if use_depth else fptr(None), field(3), c_int(GRAD_RECORD), ptr(v_sign, torch.uint8),
-                      fptr(v_sign_mask), c_int(0 if v_sign_mask is None else v_sign_mask.shape[1]), fptr(v_scale),
-                      stream_ptr())
-            _lib.call("gol_project_bwd", c_int(B), c_int(N), fptr(means), fptr(scales), c_float(glob_scale),
-                      fptr(quats), fptr(viewmats), fptr(intrins), fptr(cov3d), iptr(radii), fptr(conics),
-                      fptr(comp), field(4), field(9) if use_depth else fptr(None), field(6), fptr(None), fptr(opacity),
-                      field(3), c_int(GRAD_RECORD), fptr(v_mean), fptr(v_scale_g), fptr(v_quat), fptr(v_opacity),
-                      stream_ptr())
-        # ctx.ws stays alive with the node (retain_graph / a second backward re-reads the tile lists; the result dict of
-        # render_views holds sorted_ids / tile_bins anyway)
+            _lib.call("gol_render_bwd", c_int(B), c_int(N), c_int(img_h), c_int(img_w), c_float(glob_scale), fptr(means),
+                      fptr(scales), fptr(quats), fptr(opacity), fptr(viewmats), fptr(intrins), fptr(background),
+                      c_i64(ctx.capacity), ctypes.c_void_p(ws.data_ptr()), ctypes.byref(L), fptr(v_img_c),
+                      fptr(v_depth_c), fptr(v_alpha_c), c_int(1 if v_l1 is not None else 0), fptr(use_mask),
+                      c_int(0 if use_mask is None else use_mask.shape[1]), fptr(v_scale), fptr(rec), fptr(v_mean),
+                      fptr(v_scale_g), fptr(v_quat), fptr(v_opacity), stream_ptr())
+        # (the workspace stays alive with the node: retain_graph / a second backward re-reads the tile lists)
         return (v_mean, v_scale_g, v_quat, v_opacity, rec[..., :3]) + (None,) * 14
+
+
+class _LazyRender(dict):
+    """Result of render_views: the images are plain entries; the diagnostics (typed views into the call's workspace:
+    radii, final_T, final_idx, sorted_ids, tile_bins) are created on first access."""
+
+    def __init__(self, ws, layout, dims, capacity):
+        super().__init__()
+        self._ws, self._L, self._dims, self._cap = ws, layout, dims, capacity
+
+    def __missing__(self, key):
+        B, N, H, W, T = self._dims
+        ws, L = self._ws, self._L
+        if key == "radii":
+            v = _ws_view(ws, L.radii, torch.int32, (B, N))
+        elif key == "final_T":
+            v = _ws_view(ws, L.final_T, torch.float32, (B, 1, H, W))
+        elif key == "final_idx":
+            v = _ws_view(ws, L.final_idx, torch.int32, (B, H, W))
+        elif key == "sorted_ids":
+            v = _ws_view(ws, L.sorted_ids, torch.int32, (B, max(self._cap, 1)))
+        elif key == "tile_bins":
+            v = _ws_view(ws, L.tile_bins, torch.int32, (B, T, 2))
+        else:
+            raise KeyError(key)
+        self[key] = v
+        return v
 
 
 def render_views(means, scales, quats, opacity, colors, viewmats, intrins, img_h, img_w,
@@ -501,12 +622,14 @@ def render_views(means, scales, quats, opacity, colors, viewmats, intrins, img_h
             if planned is None:
                 raise _lib.GoliathHipError("render_views inside a graph capture needs a calibrated capacity: run the "
                                            "same shapes once eagerly first")
-        elif planned is None or PLANNER.verify():
-            plan_key = key       # the forward waits for its own counts and repairs an overflow in place
         else:
-            PLANNER.poll()       # async mode: raises if an EARLIER call overflowed
-            planned = PLANNER.get(key)
-            deferred = True
+            if PLANNER.pending:
+                PLANNER.poll()   # counts of earlier calls that have landed meanwhile (async mode: raises on an overflow)
+                planned = PLANNER.get(key)
+            if planned is None or PLANNER.must_block(key):
+                plan_key = key   # the forward waits for its own counts and repairs an overflow in place
+            else:
+                deferred = True
         capacity = planned if planned is not None else PLANNER.initial(N, T)
     if l1_target is not None:
         l1_target = _f32c(l1_target.detach())
@@ -521,14 +644,18 @@ def render_views(means, scales, quats, opacity, colors, viewmats, intrins, img_h
     out = _RenderViews.apply(means, scales, quats, opacity, colors, viewmats, intrins, background, img_h,
                              img_w, float(glob_scale), float(clip_thresh), bool(with_depth), int(capacity),
                              float(depth_norm_lo), plan_key, l1_target, l1_mask, bool(raw_depth))
-    img, alpha, depth, depth_norm, l1, radii, n_isect, final_T, final_idx, sorted_ids, tile_bins = out
+    img, alpha, depth, depth_norm, l1, ws, n_isect = out
+    with_l1 = 1 if l1_target is not None else 0
+    if plan_key is not None and max(_layout(B, N, img_h, img_w, capacity, with_l1).total, 1) != ws.numel():
+        capacity = PLANNER.get(key)   # the checked call re-ran at a grown capacity: that is the workspace's layout
     if PLANNER.frozen:
         PLANNER.frozen_log.append((n_isect, capacity))
     elif deferred and B > 0:
         PLANNER.note(key, n_isect, capacity)
-    res = {"render": img, "alpha": alpha[:, None], "final_T": final_T[:, None], "radii": radii, "n_isect": n_isect,
-           # per-pixel index of the last contributor in its view's depth-sorted list, and that list (diagnostics)
-           "final_idx": final_idx, "sorted_ids": sorted_ids, "tile_bins": tile_bins}
+    res = _LazyRender(ws, _layout(B, N, img_h, img_w, capacity, with_l1), (B, N, img_h, img_w, T), capacity)
+    res["render"], res["alpha"], res["n_isect"] = img, alpha[:, None], n_isect
+    # per-pixel index of the last contributor in its view's depth-sorted list, and that list: res["final_idx"],
+    # res["sorted_ids"], res["tile_bins"], res["final_T"], res["radii"] (views into the call's workspace, made on access)
     if with_depth:
         if depth is not None:
             res["depth"] = depth[:, None]

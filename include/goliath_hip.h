@@ -166,6 +166,40 @@ int gol_rasterize_bwd(int B, int N, int img_h, int img_w, int block, int planar,
                       int v_sign_mask_c, const float* v_img_scale, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * One render direction of a batch of views as ONE call (csrc/render.hip): what AutoEncoder.render issues per view from
+ * Python -- project_gaussians -> rasterize_gaussians(colour) -> rasterize_gaussians(depth), ca_code/utils/render_gsplat.py:49-104,
+ * in the view loop of ca_code/models/rgca.py:112-151 -- becomes gol_render_fwd = gol_project_fwd (+ packed records) +
+ * gol_bin_sort + gol_rasterize_fwd (planar images, fused alpha / depth-normalisation / optional L1 epilogue) and
+ * gol_render_bwd = gol_rasterize_bwd (64-byte gradient records, zeroed here) + gol_project_bwd, enqueued on `stream` out
+ * of ONE caller-provided workspace.  gol_render_layout fills the byte offsets of the workspace's sub-buffers
+ * (all 256-byte aligned; `total` = bytes to allocate) -- the caller reads n_isect[B] (int32, overflow check as for
+ * gol_bin_sort), radii[B,N], final_T / final_idx[B,H,W], sorted_ids[B,capacity], tile_bins[B,T,2] there.
+ * The forward leaves everything the backward needs in the workspace: keep it (and the inputs) until gol_render_bwd.
+ *   out_img[B,3,H,W]; out_alpha[B,H,W] = 1 - final_T; with_depth: out_depth_norm[B,H,W] = depth / clamp(alpha, norm_lo, 1)
+ *   and optionally out_depth[B,H,W] (NULL = skip); l1_target / l1_mask / l1_partial[B,T] as for gol_rasterize_fwd.
+ *   bwd: v_img[B,3,H,W] / v_depth[B,H,W] (w.r.t. the UN-normalised depth image) / v_alpha[B,H,W] may be NULL;
+ *   use_l1_sign != 0 adds the fused L1's gradient (v_img_scale = device scalar d loss / d l1 / (B*3*H*W));
+ *   grad_records[B,N,GOL_GRAD_RECORD] scratch + output: d loss / d colour = its first three floats per Gaussian.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct gol_render_ws {
+  int64_t cov3d, xys, depths, radii, conics, comp, nth, opac_eff, records, tile_count, tile_bins, keys, sorted_ids,
+      n_isect, final_T, final_idx, l1_sign, total;
+} gol_render_ws;
+int gol_render_layout(int B, int N, int img_h, int img_w, int64_t capacity, int with_l1, gol_render_ws* layout);
+int gol_render_fwd(int B, int N, int img_h, int img_w, float glob_scale, float clip_thresh, const float* means,
+                   const float* scales, const float* quats, const float* opacity, const float* colors,
+                   const float* viewmats, const float* intrins, const float* background, int with_depth, float norm_lo,
+                   int64_t capacity, void* workspace, const gol_render_ws* layout, float* out_img, float* out_depth,
+                   float* out_alpha, float* out_depth_norm, const float* l1_target, const float* l1_mask, int l1_mask_c,
+                   float* l1_partial, void* stream);
+int gol_render_bwd(int B, int N, int img_h, int img_w, float glob_scale, const float* means, const float* scales,
+                   const float* quats, const float* opacity, const float* viewmats, const float* intrins,
+                   const float* background, int64_t capacity, void* workspace, const gol_render_ws* layout,
+                   const float* v_img, const float* v_depth, const float* v_alpha, int use_l1_sign, const float* l1_mask,
+                   int l1_mask_c, const float* v_img_scale, float* grad_records, float* v_mean, float* v_scale,
+                   float* v_quat, float* v_opacity, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Fused RGCA shading tail.  Replaces the chain of ATen kernels in PrimDecoder.forward after the
  * two transposed-conv decoders (ca_code/models/rgca.py:505-588, training extra :590-618), incl.
  * the specular term: point lights = evaluate_gaussian w_type 0 (extensions/sgutils/sg.cu:27-175,

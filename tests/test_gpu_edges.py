@@ -66,6 +66,7 @@ def test_capacity_overflow_is_detected_and_recovered():
     splat.PLANNER.set(key, 10)
     assert splat.PLANNER.capacity[key] == cap
     # async mode (benchmark loops): an overflowing call is reported (loudly) at the next poll
+    mode0 = splat.PLANNER.mode
     splat.PLANNER.mode = "async"
     try:
         splat.PLANNER.capacity[key] = need // 4
@@ -75,7 +76,7 @@ def test_capacity_overflow_is_detected_and_recovered():
             splat.PLANNER.poll(block=True)
         assert splat.PLANNER.capacity[key] >= need
     finally:
-        splat.PLANNER.mode = "verify"
+        splat.PLANNER.mode = mode0
 
 
 def test_growing_gaussians_never_raise_under_the_reference_loop_contract():
@@ -88,7 +89,17 @@ def test_growing_gaussians_never_raise_under_the_reference_loop_contract():
     H = W = 256
     s = head_scene(30000, H, W, seed=8)
     g, v = _views(s, B=2)
-    splat.PLANNER.capacity.pop((2, 30000, H, W, torch.cuda.current_device()), None)
+    key = (2, 30000, H, W, torch.cuda.current_device())
+    splat.PLANNER.capacity.pop(key, None)
+    splat.PLANNER.last_worst.pop(key, None)
+    mode0, splat.PLANNER.mode = splat.PLANNER.mode, "verify"   # the strict contract: every call checks its own counts
+    try:
+        _growing(splat, v, H, W)
+    finally:
+        splat.PLANNER.mode = mode0
+
+
+def _growing(splat, v, H, W):
     reruns0, grew = splat.PLANNER.reruns, []
     for it, f in enumerate([1.0, 1.1, 4.0, 4.4, 12.0, 13.0, 30.0]):
         vv = dict(v)
@@ -105,6 +116,49 @@ def test_growing_gaussians_never_raise_under_the_reference_loop_contract():
         grew.append(need)
     assert grew[-1] > 10 * grew[0], grew
     assert splat.PLANNER.reruns >= reruns0 + 2, (splat.PLANNER.reruns - reruns0, grew)
+
+
+def test_adaptive_capacity_mode_blocks_only_when_it_matters():
+    """Default mode: a call waits for its own counts only for a new shape or when the last count came within 1.5x of the
+    capacity; in the steady state nothing blocks (the counts are read back when they have landed).  A jump that outruns
+    the margin inside ONE step is reported after the fact (RuntimeWarning, `truncated`), never raised, the plan grows
+    and the next call is a checked one again -- complete image."""
+    import warnings
+
+    from goliath_amd import splat
+
+    H = W = 192
+    s = head_scene(20000, H, W, seed=11)
+    g, v = _views(s, B=2)
+    key = (2, 20000, H, W, torch.cuda.current_device())
+    splat.PLANNER.capacity.pop(key, None)
+    splat.PLANNER.last_worst.pop(key, None)
+    mode0, splat.PLANNER.mode = splat.PLANNER.mode, "adaptive"
+    try:
+        assert splat.PLANNER.must_block(key)                     # new shape: checked call
+        ref = splat.render_views(**v, img_h=H, img_w=W)
+        need = int(ref["n_isect"].max())
+        assert not splat.PLANNER.must_block(key)                 # 2x head-room: the steady state does not block
+        again = splat.render_views(**v, img_h=H, img_w=W)
+        assert torch.equal(again["render"], ref["render"])
+        assert splat.PLANNER.pending, "the unchecked call left its counts to be read back later"
+        torch.cuda.synchronize()
+        splat.PLANNER.poll()
+        assert not splat.PLANNER.pending and splat.PLANNER.last_worst[key] == need
+        # a 6x jump inside one step: not noticed by the call itself ...
+        big = dict(v, scales=v["scales"] * 6.0)
+        truncated0 = splat.PLANNER.truncated
+        splat.render_views(**big, img_h=H, img_w=W)
+        torch.cuda.synchronize()
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            out = splat.render_views(**big, img_h=H, img_w=W)     # ... but by the next one: warning, bigger plan, checked call
+        assert any(issubclass(x.category, RuntimeWarning) for x in w)
+        assert splat.PLANNER.truncated == truncated0 + 1
+        full = splat.render_views(**big, img_h=H, img_w=W, capacity=int(out["n_isect"].max()) + 16)
+        assert torch.equal(out["render"], full["render"])
+    finally:
+        splat.PLANNER.mode = mode0
 
 
 @pytest.mark.parametrize("H,W", [(17, 33), (16, 16), (1, 1), (250, 7)])
