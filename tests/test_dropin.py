@@ -74,5 +74,19 @@ def test_patch_losses_and_urhand_on_stand_in_modules():
     mod = reg.loss_registry["rgb_ssim"](None, src_key="rgb", tgt_key="image", mask_key="image_weight")
     assert isinstance(mod, FnLoss) and mod.fn is losses.rgb_ssim and mod.extra_args["src_key"] == "rgb"
     assert reg.loss_registry["rgb_l1"](None).fn is losses.rgb_l1 and reg.loss_registry["kl"] == "untouched"
-    ur = types.SimpleNamespace(get_shadow_map="reference")
+    from goliath_amd import meshraster, urhand
+
+    class ConvTeacherDecoder:  # stand-in for ca_code.models.urhand.ConvTeacherDecoder
+        def forward(self):
+            return "reference"
+
+    ur = types.SimpleNamespace(get_shadow_map="reference", RenderLayer="drtk", ConvTeacherDecoder=ConvTeacherDecoder)
     assert dropin.patch_urhand(ur).get_shadow_map is shadowmap.get_shadow_map
+    assert ur.RenderLayer is meshraster.RenderLayer and ConvTeacherDecoder.forward is urhand.conv_teacher_decoder_forward
+
+    class OLATRGBDecoder:  # stand-in for ca_code.models.hand_teacher_mvp.OLATRGBDecoder
+        def forward_rgb(self):
+            return "reference"
+
+    tm = types.SimpleNamespace(OLATRGBDecoder=OLATRGBDecoder)
+    assert dropin.patch_hand_teacher(tm) is tm and OLATRGBDecoder.forward_rgb is urhand.olat_rgb_decoder_forward_rgb
