@@ -106,7 +106,14 @@ __device__ __forceinline__ Staged stage_entry(const float* __restrict__ records,
 // Forward.  128-thread workgroup per 16x16 tile: wave w owns the 16x8 half (rows 8w..8w+7) and every lane two
 // vertically adjacent pixels, so the per-pixel recurrence runs on 2-vectors = packed fp32 VALU ops
 // (v_pk_fma/mul/add_f32), half the instructions per pixel of a one-pixel-per-lane loop.
-template <bool EXTRA>
+// LAZY (the fused path, planar images): everything that only changes when a pixel STOPS -- its liveness, the index the
+// backward may start from, the "is this half finished" test -- moves out of the per-visit instruction stream into a
+// wave-uniform branch taken only on visits where some pixel of the half stops (a pixel stops once; a visit costs 7 vector
+// instructions less).  final_idx then holds, per pixel, an UPPER BOUND of the index of its last contributor that excludes
+// the entry it stopped at: stop index - 1, or the end of the list for a pixel that never stopped.  The backward only needs
+// that (entries between the true last contributor and the bound fail its alpha >= 1/255 test again).  !LAZY (the
+// gsplat-compatible operator): gsplat's exact final_idx.
+template <bool EXTRA, bool LAZY>
 __global__ __launch_bounds__(128) void raster_fwd_kernel(
     int N, int img_h, int img_w, int planar, int tiles_x, int tiles_y, const int2* __restrict__ tile_bins,
     const int32_t* __restrict__ sorted_ids, int64_t capacity, const float* __restrict__ records,
@@ -162,8 +169,9 @@ __global__ __launch_bounds__(128) void raster_fwd_kernel(
     // 64 entries, then a scalar loop over the set bits (s_ff1) -- culled entries cost nothing.
     for (int chunk = 0; chunk < batch_size; chunk += 64) {
       unsigned long long bits = gol_ballot((s_mask[chunk + lane] >> wave) & 1);
+      if (LAZY && gol_ballot((__float_as_uint(live.x) | __float_as_uint(live.y)) != 0u) == 0ull) break;  // half finished
       while (bits) {
-        if (gol_ballot((__float_as_uint(live.x) | __float_as_uint(live.y)) != 0u) == 0ull) { chunk = batch_size; break; }  // this wave's half is finished
+        if (!LAZY && gol_ballot((__float_as_uint(live.x) | __float_as_uint(live.y)) != 0u) == 0ull) { chunk = batch_size; break; }  // this wave's half is finished
         const int t = chunk + __builtin_ctzll(bits);
         bits &= bits - 1;
         const float4 a4 = s_a[t];
@@ -196,9 +204,16 @@ __global__ __launch_bounds__(128) void raster_fwd_kernel(
         // stop / take as scalar lane-mask algebra: one compare per pixel (written with bools the compiler issues a second,
         // NaN-aware compare for the negation)
         const unsigned long long ms0 = gol_ballot(next_T.x <= GOL_T_STOP), ms1 = gol_ballot(next_T.y <= GOL_T_STOP);
-        const bool stop0 = __builtin_amdgcn_inverse_ballot_w64(mc0 & ms0), stop1 = __builtin_amdgcn_inverse_ballot_w64(mc1 & ms1);
         const bool take0 = __builtin_amdgcn_inverse_ballot_w64(mc0 & ~ms0), take1 = __builtin_amdgcn_inverse_ballot_w64(mc1 & ~ms1);
-        live.x = stop0 ? 0.f : live.x; live.y = stop1 ? 0.f : live.y;
+        bool half_done = false;
+        if (!LAZY || ((mc0 & ms0) | (mc1 & ms1)) != 0ull) {   // LAZY: wave-uniform and rare -- some pixel stops here
+          const bool stop0 = __builtin_amdgcn_inverse_ballot_w64(mc0 & ms0), stop1 = __builtin_amdgcn_inverse_ballot_w64(mc1 & ms1);
+          live.x = stop0 ? 0.f : live.x; live.y = stop1 ? 0.f : live.y;
+          if (LAZY) {
+            cur_idx.x = stop0 ? (batch_start + t - 1) : cur_idx.x; cur_idx.y = stop1 ? (batch_start + t - 1) : cur_idx.y;
+            half_done = gol_ballot((__float_as_uint(live.x) | __float_as_uint(live.y)) != 0u) == 0ull;
+          }
+        }
         vis.x = take0 ? vis.x : 0.f; vis.y = take1 ? vis.y : 0.f;
         acc0 += b4.z * vis; acc1 += b4.w * vis; acc2 += c2.x * vis;
         if (EXTRA) acc3 += c2.y * vis;
@@ -207,9 +222,13 @@ __global__ __launch_bounds__(128) void raster_fwd_kernel(
 #else
         T_cur.x = take0 ? next_T.x : T_cur.x; T_cur.y = take1 ? next_T.y : T_cur.y;
 #endif
-        cur_idx.x = take0 ? (batch_start + t) : cur_idx.x; cur_idx.y = take1 ? (batch_start + t) : cur_idx.y;
+        if (!LAZY) { cur_idx.x = take0 ? (batch_start + t) : cur_idx.x; cur_idx.y = take1 ? (batch_start + t) : cur_idx.y; }
+        if (LAZY && half_done) { chunk = batch_size; break; }
       }
     }
+  }
+  if (LAZY) {   // a pixel that never stopped may have taken entries up to the end of the list
+    cur_idx.x = live.x != 0.f ? range.y - 1 : cur_idx.x; cur_idx.y = live.y != 0.f ? range.y - 1 : cur_idx.y;
   }
 
   // planar: [B,3,H,W] (what the model consumes, rgca.py:139); else gsplat's [B,H,W,3].
@@ -567,15 +586,18 @@ extern "C" int gol_rasterize_fwd(int B, int N, int img_h, int img_w, int block, 
   dim3 grid(8 * ((tiles_y + 7) / 8) * tiles_x, B);
   const int2* bins = reinterpret_cast<const int2*>(tile_bins);
   hipStream_t s = (hipStream_t)stream;
-  if (out_extra || out_extra_norm)
-    raster_fwd_kernel<true><<<grid, 128, 0, s>>>(N, img_h, img_w, planar, tiles_x, tiles_y, bins, sorted_ids, capacity,
-                                                  records, background, out_img, out_extra, final_Ts, final_idx, out_alpha,
-                                                  out_extra_norm, norm_lo, l1_target, l1_mask, l1_mask_c, l1_sign,
-                                                  l1_partial);
-  else
-    raster_fwd_kernel<false><<<grid, 128, 0, s>>>(N, img_h, img_w, planar, tiles_x, tiles_y, bins, sorted_ids, capacity,
-                                                   records, background, out_img, out_extra, final_Ts, final_idx, out_alpha,
-                                                   nullptr, norm_lo, l1_target, l1_mask, l1_mask_c, l1_sign, l1_partial);
+#define GOL_LAUNCH_FWD(EX, LZ)                                                                                          \
+  raster_fwd_kernel<EX, LZ><<<grid, 128, 0, s>>>(N, img_h, img_w, planar, tiles_x, tiles_y, bins, sorted_ids, capacity, \
+                                                 records, background, out_img, out_extra, final_Ts, final_idx,         \
+                                                 out_alpha, EX ? out_extra_norm : nullptr, norm_lo, l1_target, l1_mask, \
+                                                 l1_mask_c, l1_sign, l1_partial)
+  const bool ex = out_extra || out_extra_norm;
+  // planar = the fused path: final_idx is the backward's start bound (see raster_fwd_kernel); gsplat's layout: exact
+  if (ex && planar) GOL_LAUNCH_FWD(true, true);
+  else if (ex) GOL_LAUNCH_FWD(true, false);
+  else if (planar) GOL_LAUNCH_FWD(false, true);
+  else GOL_LAUNCH_FWD(false, false);
+#undef GOL_LAUNCH_FWD
   GOL_CHECK_LAUNCH();
   return GOL_OK;
 }

@@ -126,8 +126,10 @@ int gol_bin_sort(int B, int N, const float* xys, const float* depths, const int3
  * (the depth pass of render_gsplat.py:91-104 fused into the colour pass; its background is 0).
  *   planar = 0: out_img / v_out_img are [B,H,W,3] (gsplat); planar = 1: [B,3,H,W] (what
  *   AutoEncoder.render stacks, rgca.py:139 -- saves the permute copy in the backward).
- *   background[3]; out_extra[B,H,W]; final_Ts[B,H,W]; final_idx[B,H,W] int32
- *   (index into the view's sorted_ids segment of the last contributing Gaussian, 0 if none).
+ *   background[3]; out_extra[B,H,W]; final_Ts[B,H,W]; final_idx[B,H,W] int32:
+ *   planar = 0: index into the view's sorted_ids segment of the last contributing Gaussian, 0 if none (gsplat's);
+ *   planar = 1: the index gol_rasterize_bwd starts the pixel's walk from -- an upper bound of the above that excludes
+ *   the entry the pixel stopped at (stop index - 1; end of the tile's list for a pixel that never reached T <= 1e-4).
  * fwd optional fused epilogue of AutoEncoder.render (rgca.py:137,144-145), NULL = off: out_alpha[B,H,W] = 1 - final_T and
  *   out_extra_norm[B,H,W] = extra image / clamp(1 - final_T, norm_lo, 1)  (the reference divides depth by alpha.clamp(0.05, 1));
  *   with out_extra_norm given, out_extra (the un-normalised image) may be NULL -- one image write less.

@@ -5,7 +5,7 @@ shade(env) -> project -> pruned bin/sort -> planar 2-px/lane colour+depth raster
 backward -> project backward -> shade backward -- is compared as a whole with the CPU oracle chain
 (oracle/chain.py): rgb / alpha / depth and EVERY input gradient (f_vnocond, f_vcond, postex, tn, albedo) on whole
 images (the OpenMP oracle needs ~2 s per view on the GPU box's cores, so no tile subsampling is necessary), plus the
-fraction of pixels whose contributing list differs (threshold flips at alpha = 1/255, T = 1e-4, sigma < 0)."""
+fraction of pixels whose contributing list differs (threshold flips at alpha = 1/255, T = 1e-4, sigma < 0; seen in T)."""
 import json
 import os
 import sys
@@ -130,14 +130,12 @@ def _gpu_step(mb, cfg):
         preds[k].retain_grad()
     loss.backward()
     mb["_stage"] = {k: preds[k].grad for k in STAGE}
-    # the lists of the same views (diagnostics only: last contributor per pixel)
+    # the transmittance images of the same views (diagnostics: which pixels composite a different list)
     with torch.no_grad():
         intr = torch.stack([mb["K"][:, 0, 0], mb["K"][:, 1, 1], mb["K"][:, 0, 2], mb["K"][:, 1, 2]], -1)
         d = splat.render_views(preds["primpos"], preds["primscale"], preds["primqvec"], preds["opacity"], preds["color"],
                                mb["Rt"], intr, cfg["height"], cfg["width"])
-        B = rgb.shape[0]
-        last = torch.gather(d["sorted_ids"], 1, d["final_idx"].reshape(B, -1).long()).reshape(d["final_idx"].shape)
-        last = torch.where(d["final_T"][:, 0] < 1.0, last, torch.full_like(last, -1))
+        last = None
     return rgb.detach(), alpha, depth.detach(), float(loss), last, d
 
 
@@ -184,9 +182,11 @@ def test_bench_step_matches_oracle_chain(name):
         worst["rgb"] = max(worst["rgb"], rel_l2(rgb[b], o["rgb"]))
         worst["alpha"] = max(worst["alpha"], rel_l2(alpha[b, 0], o["alpha"]))
         worst["depth"] = max(worst["depth"], rel_l2(depth[b, 0], o["depth_norm"]))
-        # flip pixels: the last contributor differs, or the transmittance differs by more than rounding
+        # flip pixels: the transmittance differs by more than rounding.  Any difference between the two composited lists
+        # shows there: an entry at the alpha = 1/255 cut taken by one side only moves T by >= 0.39 %, a pixel that stops
+        # (T <= 1e-4) at different entries ends with different products
         T_h, T_o = diag["final_T"][b, 0].cpu(), o["final_T"]
-        flip = (last[b].cpu() != o["last_id"]) | ((T_h - T_o).abs() > 1e-3 * T_o.clamp(min=1e-4))
+        flip = (T_h - T_o).abs() > 1e-3 * T_o.clamp(min=1e-4)
         flips += int(flip.sum())
         keep = ~flip
         worst["depth_without_flip_pixels"] = max(worst["depth_without_flip_pixels"],
