@@ -133,11 +133,12 @@ __device__ __forceinline__ Bilinear bilinear_border(const float* __restrict__ im
   const bool bx = x1 < w, by = y1 < h;
   float t00[3], t01[3], t10[3], t11[3];
   if constexpr (PACKED) {
-    // [h,w,4] texels: one 16-byte gather per tap, the two taps of a row are adjacent (32 B)
-    const float4* q = reinterpret_cast<const float4*>(img);
-    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-    const float4 a = q[y0 * w + x0], b2 = bx ? q[y0 * w + x1] : z;
-    const float4 c2 = by ? q[y1 * w + x0] : z, d2 = (bx && by) ? q[y1 * w + x1] : z;
+    // [h,w,16] FOOTPRINT records: record (y0, x0) holds the four taps of the bilinear footprint whose top-left texel
+    // it is (taps beyond the border already zero), 64 bytes on a 64-byte boundary -- a lookup is ONE sector, whatever
+    // its position.  ([h,w,4] texels cost 2.5 sectors per lookup on average: the footprint spans two rows, and the
+    // lookups of neighbouring Gaussians are unrelated, so nothing of the rest of a sector is ever used.)
+    const float4* q = reinterpret_cast<const float4*>(img) + (size_t)(y0 * w + x0) * 4;
+    const float4 a = q[0], b2 = q[1], c2 = q[2], d2 = q[3];
     t00[0] = a.x; t00[1] = a.y; t00[2] = a.z; t01[0] = b2.x; t01[1] = b2.y; t01[2] = b2.z;
     t10[0] = c2.x; t10[1] = c2.y; t10[2] = c2.z; t11[0] = d2.x; t11[1] = d2.y; t11[2] = d2.z;
   } else {
@@ -178,12 +179,12 @@ __device__ __forceinline__ EnvSample env_lookup(const gol_shade_in& in, int b, f
   }
   const int h0 = in.mip_h[d1], w0 = in.mip_w[d1];
   const bool packed = in.mips_packed[0] != nullptr;
-  const Bilinear s0 = packed ? bilinear_border<true>(in.mips_packed[d1] + (size_t)b * 4 * h0 * w0, h0, w0, u, v)
+  const Bilinear s0 = packed ? bilinear_border<true>(in.mips_packed[d1] + (size_t)b * 16 * h0 * w0, h0, w0, u, v)
                              : bilinear_border<false>(in.mips[d1] + (size_t)b * 3 * h0 * w0, h0, w0, u, v);
   if (q > 1) {
     const int d2 = min(d1 + 1, q - 1);
     const int h1 = in.mip_h[d2], w1 = in.mip_w[d2];
-    const Bilinear s1 = packed ? bilinear_border<true>(in.mips_packed[d2] + (size_t)b * 4 * h1 * w1, h1, w1, u, v)
+    const Bilinear s1 = packed ? bilinear_border<true>(in.mips_packed[d2] + (size_t)b * 16 * h1 * w1, h1, w1, u, v)
                                : bilinear_border<false>(in.mips[d2] + (size_t)b * 3 * h1 * w1, h1, w1, u, v);
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
@@ -656,13 +657,19 @@ __global__ __launch_bounds__(256) void shade_bwd_kernel(const gol_shade_in in, c
   }
 }
 
-// [B,3,h,w] planar -> [B,h,w,4] texel-interleaved (4th lane 0), one lane per texel
-__global__ __launch_bounds__(256) void envmap_pack_kernel(int hw, const float* __restrict__ src, float4* __restrict__ dst) {
-  const int b = blockIdx.y;
+// [B,3,h,w] planar -> [B,h,w,16] footprint records (see bilinear_border), one lane per record
+__global__ __launch_bounds__(256) void envmap_pack_kernel(int h, int w, const float* __restrict__ src, float4* __restrict__ dst) {
+  const int b = blockIdx.y, hw = h * w;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= hw) return;
+  const int y = i / w, x = i - y * w;
   const float* s = src + (size_t)b * 3 * hw;
-  dst[(size_t)b * hw + i] = make_float4(s[i], s[hw + i], s[2 * (size_t)hw + i], 0.f);
+  const bool bx = x + 1 < w, by = y + 1 < h;
+  auto tap = [&](int k, bool ok) {
+    return ok ? make_float4(s[k], s[hw + k], s[2 * (size_t)hw + k], 0.f) : make_float4(0.f, 0.f, 0.f, 0.f);
+  };
+  float4* d = dst + ((size_t)b * hw + i) * 4;
+  d[0] = tap(i, true); d[1] = tap(i + 1, bx); d[2] = tap(i + w, by); d[3] = tap(i + w + 1, bx && by);
 }
 
 int check_in(const gol_shade_in* in) {
@@ -695,7 +702,7 @@ extern "C" int gol_envmap_pack(int B, int h, int w, const float* src, float* dst
   GOL_REQUIRE(src && dst, "null pointer");
   GOL_REQUIRE(B <= 65535, "B > 65535");
   envmap_pack_kernel<<<dim3(gol_cdiv((long long)h * w, 256), B), 256, 0, (hipStream_t)stream>>>(
-      h * w, src, reinterpret_cast<float4*>(dst));
+      h, w, src, reinterpret_cast<float4*>(dst));
   GOL_CHECK_LAUNCH();
   return GOL_OK;
 }

@@ -56,7 +56,8 @@ _PACKED = {}   # (data_ptr, shape, _version) -> (the level tensor, packed copy):
 
 
 def pack_envmap(mips):
-    """[B,3,h,w] mip levels -> [B,h,w,4] texel-interleaved copies for 16-byte gathers.  The reference builds the
+    """[B,3,h,w] mip levels -> [B,h,w,16] footprint records (the four taps of the bilinear footprint whose top-left texel
+    is (y, x), 64 bytes: a lookup fetches one HBM sector instead of ~2.5).  The reference builds the
     SG-prefiltered pyramid once per environment (light_decorator.py:18-164) and only rotates it per frame (`lightrot`),
     so the packed copy of a level is cached on the tensor's memory and in-place version counter: a level that was
     neither replaced nor written since the last call is not packed again (4 launches per step in rounds 1-2).  The cache
@@ -74,7 +75,7 @@ def pack_envmap(mips):
             out.append(hit[1])
             continue
         B, _, h, w = m.shape
-        p = torch.empty(B, h, w, 4, device=m.device)
+        p = torch.empty(B, h, w, 16, device=m.device)
         _lib.call("gol_envmap_pack", _lib.c_int(B), _lib.c_int(h), _lib.c_int(w), _lib.fptr(m), _lib.fptr(p),
                   stream_ptr())
         while len(_PACKED) >= 16:

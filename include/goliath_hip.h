@@ -234,8 +234,8 @@ typedef struct {
   const float* mips[GOL_MAX_MIPS];  /* level i: [B, 3, mip_h[i], mip_w[i]] */
   int32_t mip_h[GOL_MAX_MIPS], mip_w[GOL_MAX_MIPS];
   const float* lightrot;        /* [B, 3, 3] */
-  /* optional: the same levels repacked by gol_envmap_pack to [B, h, w, 4] (one 16-byte gather per
-   * bilinear tap instead of three 4-byte ones); all levels or none (NULL) */
+  /* optional: the same levels repacked by gol_envmap_pack to [B, h, w, 16] footprint records (a bilinear lookup = one
+   * aligned 64-byte fetch); all levels or none (NULL) */
   const float* mips_packed[GOL_MAX_MIPS];
   float primscale_min, primscale_max; /* rgca.py:47 (0.1, 20) */
 } gol_shade_in;
@@ -274,7 +274,9 @@ typedef struct {  /* written in full */
 } gol_shade_in_grad;
 
 /* src[B,3,h,w] (the layout of EnvSpinDecorator's mip pyramid, light_decorator.py:100-140) ->
- * dst[B,h,w,4] texel-interleaved, 4th component 0. */
+ * dst[B,h,w,16]: record (y, x) = the four taps (y,x) (y,x+1) (y+1,x) (y+1,x+1) of the bilinear footprint whose top-left
+ * texel it is, each as (r, g, b, 0), taps beyond the border zero -- 64 bytes, one HBM sector per lookup (4x the memory
+ * of the map; packed once per environment, the host side caches it). */
 int gol_envmap_pack(int B, int h, int w, const float* src, float* dst, void* stream);
 int gol_shade_fwd(const gol_shade_in* in, const gol_shade_out* out, void* stream);
 /* `saved` = the gol_shade_out of the forward (reads color_rand, diff_sum, env_saved). */
