@@ -646,18 +646,25 @@ __global__ __launch_bounds__(256) void sort_queue_kernel(int T, int64_t capacity
   }
 }
 
-// Largest dynamic-LDS size already granted to kernel `which` on the CURRENT device (the attribute is per device and
-// per function).  The only process-wide state of the library besides the last-error string: a monotone cache,
-// updated with atomics, so concurrent callers at worst repeat an idempotent hipFuncSetAttribute.
-bool lds_limit_needs_raise(int which, size_t bytes) {
+// Dynamic-LDS limit of kernel `which` on the CURRENT device (the attribute is per device and per function): raise it to
+// `bytes` if a smaller size is on record.  The only process-wide state of the library besides the last-error string: a
+// monotone cache, published only AFTER hipFuncSetAttribute succeeded (compare-exchange max), so a concurrent caller
+// never sees a limit that is not in effect yet -- at worst it repeats the idempotent call.  Returns false on failure.
+bool ensure_lds_limit(int which, const void* fn, size_t bytes) {
   constexpr int kMaxDev = 64;
   static std::atomic<size_t> granted[2][kMaxDev];
   int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDev) return true;
-  size_t cur = granted[which][dev].load(std::memory_order_relaxed);
-  if (cur == 0) cur = 48 * 1024;  // the default limit
-  if (bytes <= cur) return false;
-  granted[which][dev].store(bytes, std::memory_order_relaxed);
+  const bool cached = hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < kMaxDev;
+  if (cached) {
+    size_t cur = granted[which][dev].load(std::memory_order_acquire);
+    if (cur == 0) cur = 48 * 1024;  // the default limit
+    if (bytes <= cur) return true;
+  }
+  if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) return false;
+  if (cached) {
+    size_t cur = granted[which][dev].load(std::memory_order_relaxed);
+    while (cur < bytes && !granted[which][dev].compare_exchange_weak(cur, bytes, std::memory_order_release)) {}
+  }
   return true;
 }
 
@@ -714,8 +721,7 @@ extern "C" int gol_bin_sort(int B, int N, const float* xys, const float* depths,
       const size_t lds = sizeof(int32_t) * (size_t)T;
       // raise the dynamic-LDS limit once per (device, size): not a stream operation, so it is kept out of the
       // steady state and the call sequence stays graph-capturable
-      if (lds_limit_needs_raise(0, lds))
-        hipFuncSetAttribute((const void*)count_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      GOL_REQUIRE(ensure_lds_limit(0, (const void*)count_lds_kernel, lds), "cannot raise the dynamic LDS limit");
       count_lds_kernel<<<dim3(nblk, B), 1024, lds, s>>>(a, tile_count);
     } else {
       count_kernel<<<dim3(gol_cdiv(N, 256), B), 256, 0, s>>>(a, tile_count);
@@ -725,8 +731,7 @@ extern "C" int gol_bin_sort(int B, int N, const float* xys, const float* depths,
   if (N > 0 && capacity > 0) {
     if (lds_path) {
       const size_t lds = sizeof(int32_t) * ((size_t)((T + 1) >> 1) + (size_t)T);
-      if (lds_limit_needs_raise(1, lds))
-        hipFuncSetAttribute((const void*)scatter_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      GOL_REQUIRE(ensure_lds_limit(1, (const void*)scatter_lds_kernel, lds), "cannot raise the dynamic LDS limit");
       scatter_lds_kernel<<<dim3(nblk2, B), 1024, lds, s>>>(a2, capacity, tile_bins, isect_keys);
     } else {
       scatter_kernel<<<dim3(gol_cdiv(N, 256), B), 256, 0, s>>>(a, capacity, tile_bins, isect_keys);

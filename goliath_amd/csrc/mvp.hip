@@ -251,17 +251,24 @@ __device__ __forceinline__ int build_hits(int K, const float* __restrict__ nodea
   // -> i in [floor((a - t)/step - m), ceil((b - t)/step + m)].  The margin m (in steps) covers what separates the exact
   // line used here from the marched position: t and pos are accumulated by repeated float additions (error <= n ulp
   // after n steps: 1.2e-7 |pos| n / step ~ 2e-5 n steps at the BASELINE step size) plus the rounding of box_hit itself;
-  // m = 0.05 + 1e-4 n leaves a factor > 4.  (A full step of margin on either side, as before, evaluated every box for
+  // m = 0.05 + drift n with drift >= 1e-4 scaled by the ray's own |pos| / stepsize (below) leaves a factor > 4.  (A full step of margin on either side, as before, evaluated every box for
   // ~2 of ~11 iterations in vain.)  Window of the wave = union over its lanes.
   const float inv_step = 1.f / stepsize;
   const V3 p0 = ray.pos - ray.dir * ray.t;  // ray origin again (positions are affine in t)
+  // drift per step, in steps: ray.pos and ray.t are accumulated by float additions, each off by <= ulp/2 of the LARGEST
+  // coordinate involved, i.e. <= 1.2e-7 max|pos| / stepsize steps per step (x4 for the three coordinates + t): 1e-4 at
+  // the BASELINE geometry (|pos| ~ 3, step 1/64), and growing with |pos| / stepsize -- world-space units, a small dt
+  const V3 pe = ray.pos + ray.dir * (ray.rt1 - ray.t);
+  const float pmax = fmaxf(fmaxf(fmaxf(fabsf(ray.pos.x), fabsf(ray.pos.y)), fmaxf(fabsf(ray.pos.z), fabsf(pe.x))),
+                           fmaxf(fmaxf(fabsf(pe.y), fabsf(pe.z)), fmaxf(fabsf(ray.t), fabsf(ray.rt1))));
+  const float drift = fmaxf(1e-4f, 4.8e-7f * pmax * inv_step);
   for (int s = 0; s < num; ++s) {
     const int k = __builtin_amdgcn_readfirstlane(s_list[s]);
     float a, b;
     int lo = 2147483647, hi = -2147483647;
     if (ray.live && box_hit(primpos, primrot, primscale, k, p0, ray.dir, a, b)) {
       const float xa = (a - ray.t) * inv_step, xb = (b - ray.t) * inv_step;
-      const float m = 0.05f + 1e-4f * fmaxf(fabsf(xa), fabsf(xb));
+      const float m = 0.05f + drift * fmaxf(fabsf(xa), fabsf(xb));
       const float fl = floorf(xa - m), fh = ceilf(xb + m);
       if (fl < 2.0e9f && fh > -2.0e9f) {
         lo = (int)fmaxf(fl, -2.0e9f);

@@ -110,6 +110,41 @@ def test_mvp_vs_oracle_with_shadow(N, H, W, K, T, fe):
         assert e < 3e-4, (k, e)
 
 
+def test_mvp_far_from_the_origin_with_a_small_step():
+    """|pos| / stepsize 150x the BASELINE ratio (the scene 60 units away from the origin, step 0.004): the accumulated
+    float error of the marched position grows with that ratio, and so must the margin of the per-box iteration windows
+    -- a sample the reference evaluates may not fall outside its window (the margin was calibrated for the
+    BASELINE ratio only).  Rays are given explicitly (the unit-cube clipping of compute_raydirs does not apply)."""
+    from goliath_amd import mvp
+    from oracle import cref
+
+    N, H, W, K, T = 1, 48, 40, 27, (4, 6, 6)
+    case = _random_case(N, H, W, K, T, seed=5, step=0.004)
+    off = torch.tensor([60.0, -45.0, 52.0])
+    c = lambda t: t.cuda().contiguous()
+    rp0, rd, tm = mvp.compute_raydirs(c(case["viewpos"]), c(case["viewrot"]), c(case["focal"]), c(case["princpt"]),
+                                      (W, H), 1.0)
+    rp = (rp0 + off.cuda()).contiguous()
+    primpos = (case["primpos"] + off).contiguous()
+    leaf = {"primpos": c(primpos).requires_grad_(True), "primrot": c(case["primrot"]).requires_grad_(True),
+            "primscale": c(case["primscale"]).requires_grad_(True), "template": c(case["template"]).requires_grad_(True)}
+    out = mvp.mvpraymarch(rp, rd, case["step"], tm, (leaf["primpos"], leaf["primrot"], leaf["primscale"]),
+                          leaf["template"], None, fadescale=6.5, fadeexp=8.0)
+    ref, raysat, _ = cref.mvp_forward(rp.cpu(), rd.cpu(), case["step"], tm.cpu(), primpos, case["primrot"],
+                                      case["primscale"], case["template"], 6.5, 8.0)
+    assert float(ref[..., 3].max()) > 0.2
+    # positions carry ~1e-5 of absolute rounding here (ulp of 60), i.e. ~3e-4 of a voxel: looser than at the origin
+    assert rel_l2(out, ref) < 2e-3, rel_l2(out, ref)
+    gen = torch.Generator().manual_seed(1)
+    go = torch.randn(out.shape, generator=gen)
+    out.backward(go.cuda())
+    gp, gr, gs, gt = cref.mvp_backward(rp.cpu(), rd.cpu(), case["step"], tm.cpu(), primpos, case["primrot"],
+                                       case["primscale"], case["template"], raysat, go, 6.5, 8.0)
+    for k, g in (("primscale", gs), ("template", gt)):
+        e = rel_l2(leaf[k].grad, g)
+        assert e < 5e-3, (k, e)
+
+
 def test_raymarcher_wrapper_and_errors():
     from goliath_amd import mvp
 
