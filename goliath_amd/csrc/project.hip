@@ -35,6 +35,19 @@ __device__ __forceinline__ M3 quat_to_rotmat(float qw, float qx, float qy, float
 
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return min(max(v, lo), hi); }
 
+// upper triangle of Sigma = M M^T, M = R(q) diag(glob_scale * scale)   
+__device__ __forceinline__ void cov3d_of(const float* __restrict__ quats, const float* __restrict__ scales,
+                                         float glob_scale, size_t e, float (&o_cov)[6]) {
+  const float4 q = *reinterpret_cast<const float4*>(quats + 4 * e);
+  const M3 R = quat_to_rotmat(q.x, q.y, q.z, q.w);
+  const float s0 = glob_scale * scales[3 * e], s1 = glob_scale * scales[3 * e + 1], s2 = glob_scale * scales[3 * e + 2];
+  M3 M;
+#pragma unroll
+  for (int r = 0; r < 3; ++r) { M.m[r * 3] = R.m[r * 3] * s0; M.m[r * 3 + 1] = R.m[r * 3 + 1] * s1; M.m[r * 3 + 2] = R.m[r * 3 + 2] * s2; }
+  const M3 S3 = mul(M, transpose(M));
+  o_cov[0] = S3.m[0]; o_cov[1] = S3.m[1]; o_cov[2] = S3.m[2]; o_cov[3] = S3.m[4]; o_cov[4] = S3.m[5]; o_cov[5] = S3.m[8];
+}
+
 // SURVEY A.1 tile bbox with C (int) truncation; [x0,x1) x [y0,y1) in tile units.
 __device__ __forceinline__ void tile_bbox(float cx, float cy, float radius, int tiles_x, int tiles_y,
                                           float inv_block, int& x0, int& x1, int& y0, int& y1) {
@@ -71,14 +84,7 @@ __global__ __launch_bounds__(256) void project_fwd_kernel(
   const float ty = V[4] * p0 + V[5] * p1 + V[6] * p2 + V[7];
   const float tz = V[8] * p0 + V[9] * p1 + V[10] * p2 + V[11];
   if (tz > clip_thresh) {
-    const float4 q = *reinterpret_cast<const float4*>(quats + 4 * e);
-    const M3 R = quat_to_rotmat(q.x, q.y, q.z, q.w);
-    const float s0 = glob_scale * scales[3 * e], s1 = glob_scale * scales[3 * e + 1], s2 = glob_scale * scales[3 * e + 2];
-    M3 M;
-#pragma unroll
-    for (int r = 0; r < 3; ++r) { M.m[r * 3] = R.m[r * 3] * s0; M.m[r * 3 + 1] = R.m[r * 3 + 1] * s1; M.m[r * 3 + 2] = R.m[r * 3 + 2] * s2; }
-    const M3 S3 = mul(M, transpose(M));
-    o_cov[0] = S3.m[0]; o_cov[1] = S3.m[1]; o_cov[2] = S3.m[2]; o_cov[3] = S3.m[4]; o_cov[4] = S3.m[5]; o_cov[5] = S3.m[8];
+    cov3d_of(quats, scales, glob_scale, e, o_cov);
 
     const float lim_x = GOL_FOV_CLAMP * (0.5f * (float)img_w / fx), lim_y = GOL_FOV_CLAMP * (0.5f * (float)img_h / fy);
     const float ex = tz * fminf(lim_x, fmaxf(-lim_x, tx / tz));
@@ -113,14 +119,16 @@ __global__ __launch_bounds__(256) void project_fwd_kernel(
     o_cov[0] = o_cov[1] = o_cov[2] = o_cov[3] = o_cov[4] = o_cov[5] = 0.f;
   }
 
+  if (cov3d) {   // (NULL in the fused path: the backward recomputes it from the scales and the quaternion it reads anyway)
 #pragma unroll
-  for (int k = 0; k < 6; ++k) cov3d[6 * e + k] = o_cov[k];
+    for (int k = 0; k < 6; ++k) cov3d[6 * e + k] = o_cov[k];
+  }
   *reinterpret_cast<float2*>(xys + 2 * e) = make_float2(o_xy[0], o_xy[1]);
   depths[e] = o_depth;
   radii[e] = o_rad;
   conics[3 * e] = o_con[0]; conics[3 * e + 1] = o_con[1]; conics[3 * e + 2] = o_con[2];
   compensation[e] = o_comp;
-  num_tiles_hit[e] = o_tiles;
+  if (num_tiles_hit) num_tiles_hit[e] = o_tiles;
   const float op_eff = opacities ? opacities[e] * o_comp : 0.f;
   if (opac_eff) opac_eff[e] = op_eff;
   // the rasterizer's 64-byte record of this Gaussian (gol_common.h): screen position, scaled conic, effective opacity,
@@ -192,7 +200,13 @@ __global__ __launch_bounds__(256) void project_bwd_kernel(
     const M3 J{{fx * rz, 0.f, -fx * tx * rz2, 0.f, fy * rz, -fy * ty * rz2, 0.f, 0.f, 0.f}};
     const M3 W{{V[0], V[1], V[2], V[4], V[5], V[6], V[8], V[9], V[10]}};
     const M3 T = mul(J, W);
-    const float* c3 = cov3d + 6 * e;
+    float c3[6];
+    if (cov3d) {
+#pragma unroll
+      for (int k = 0; k < 6; ++k) c3[k] = cov3d[6 * e + k];
+    } else {
+      cov3d_of(quats, scales, glob_scale, e, c3);   // the forward's own arithmetic: identical values
+    }
     const M3 Vc{{c3[0], c3[1], c3[2], c3[1], c3[3], c3[4], c3[2], c3[4], c3[5]}};
     const M3 Gc{{vc0, 0.5f * vc1, 0.f, 0.5f * vc1, vc2, 0.f, 0.f, 0.f, 0.f}};
     const M3 vV = mul(mul(transpose(T), Gc), T);
@@ -260,7 +274,7 @@ extern "C" int gol_project_fwd(int B, int N, const float* means3d, const float* 
   GOL_REQUIRE(img_h > 0 && img_w > 0, "empty image");
   if (B == 0 || N == 0) return GOL_OK;
   GOL_REQUIRE(means3d && scales && quats && viewmats && intrins, "null input");
-  GOL_REQUIRE(cov3d && xys && depths && radii && conics && compensation && num_tiles_hit, "null output");
+  GOL_REQUIRE(xys && depths && radii && conics && compensation, "null output");
   GOL_REQUIRE((opac_eff == nullptr) || (opacities != nullptr), "opac_eff needs opacities");
   GOL_REQUIRE((records == nullptr) || (opacities != nullptr && colors != nullptr), "records need opacities and colors");
   GOL_REQUIRE(B <= 65535, "B > 65535");
@@ -282,8 +296,7 @@ extern "C" int gol_project_bwd(int B, int N, const float* means3d, const float* 
   GOL_REQUIRE(B >= 0 && N >= 0, "negative size");
   GOL_REQUIRE(grad_stride >= 0, "negative grad_stride");
   if (B == 0 || N == 0) return GOL_OK;
-  GOL_REQUIRE(means3d && scales && quats && viewmats && intrins && cov3d && radii && conics && compensation,
-              "null input");
+  GOL_REQUIRE(means3d && scales && quats && viewmats && intrins && radii && conics && compensation, "null input");
   GOL_REQUIRE(v_mean3d && v_scale && v_quat, "null output");
   GOL_REQUIRE((v_opacity == nullptr) || (opacities != nullptr), "v_opacity needs opacities");
   GOL_REQUIRE(B <= 65535, "B > 65535");

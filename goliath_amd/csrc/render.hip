@@ -25,13 +25,13 @@ extern "C" int gol_render_layout(int B, int N, int img_h, int img_w, int64_t cap
   const int64_t BN = (int64_t)B * N, cap = capacity > 0 ? capacity : 1;
   int64_t o = 0;
   auto take = [&](int64_t bytes) { const int64_t at_ = o; o = align256(o + bytes); return at_; };
-  L->cov3d = take(BN * 6 * 4);
+  L->cov3d = -1;   // not stored: gol_project_bwd recomputes Sigma from the scales / quaternions (24 B per Gaussian less each way)
   L->xys = take(BN * 2 * 4);
   L->depths = take(BN * 4);
   L->radii = take(BN * 4);
   L->conics = take(BN * 3 * 4);
   L->comp = take(BN * 4);
-  L->nth = take(BN * 4);
+  L->nth = -1;     // gsplat's num_tiles_hit is not needed on this path
   L->opac_eff = take(BN * 4);
   L->records = take(BN * GOL_SPLAT_RECORD * 4);
   L->tile_count = take((int64_t)B * T * 4);
@@ -57,9 +57,9 @@ extern "C" int gol_render_fwd(int B, int N, int img_h, int img_w, float glob_sca
   if (B == 0) return GOL_OK;
   void* ws = workspace;
   int rc = gol_project_fwd(B, N, means, scales, glob_scale, quats, viewmats, intrins, img_h, img_w, 16, clip_thresh,
-                           at<float>(ws, L->cov3d), at<float>(ws, L->xys), at<float>(ws, L->depths),
+                           nullptr, at<float>(ws, L->xys), at<float>(ws, L->depths),
                            at<int32_t>(ws, L->radii), at<float>(ws, L->conics), at<float>(ws, L->comp),
-                           at<int32_t>(ws, L->nth), opacity, at<float>(ws, L->opac_eff), colors,
+                           nullptr, opacity, at<float>(ws, L->opac_eff), colors,
                            at<float>(ws, L->records), stream);
   if (rc != GOL_OK) return rc;
   rc = gol_bin_sort(B, N, at<float>(ws, L->xys), at<float>(ws, L->depths), at<int32_t>(ws, L->radii),
@@ -100,7 +100,7 @@ extern "C" int gol_render_bwd(int B, int N, int img_h, int img_w, float glob_sca
                              use_l1_sign ? at<uint8_t>(ws, L->l1_sign) : nullptr, use_l1_sign ? l1_mask : nullptr,
                              use_l1_sign ? l1_mask_c : 0, v_img_scale, stream);
   if (rc != GOL_OK) return rc;
-  return gol_project_bwd(B, N, means, scales, glob_scale, quats, viewmats, intrins, at<float>(ws, L->cov3d),
+  return gol_project_bwd(B, N, means, scales, glob_scale, quats, viewmats, intrins, nullptr,
                          at<int32_t>(ws, L->radii), at<float>(ws, L->conics), at<float>(ws, L->comp), g + 4,
                          use_depth ? g + 9 : nullptr, g + 6, nullptr, opacity, g + 3, GOL_GRAD_RECORD, v_mean, v_scale,
                          v_quat, v_opacity, stream);

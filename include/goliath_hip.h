@@ -64,7 +64,8 @@ int gol_sg_eval_bwd(int N, int D, int L, const float* lobe_dirs, const float* lo
  * (call site ca_code/utils/render_gsplat.py:49-63; semantics SURVEY.md A.1, A.5).
  * Batched over B views: viewmats[B,12] (row-major 3x4 world->camera), intrins[B,4]=(fx,fy,cx,cy)
  * live on the device so no host sync is needed to read K (cf. rgca.py:123-126 .item() x4).
- * Outputs for culled Gaussians are zero (radii = num_tiles_hit = 0).
+ * Outputs for culled Gaussians are zero (radii = num_tiles_hit = 0).  cov3d and num_tiles_hit may be NULL (not written);
+ * gol_project_bwd with cov3d == NULL recomputes Sigma from the scales and quaternions (the forward's own arithmetic).
  * Optional fused extras (pass NULL to skip):
  *   opacities[B,N] -> opac_eff[B,N] = opacity * compensation   (render_gsplat.py:72)
  *   colors[B,N,3] (+ opacities) -> records[B,N,GOL_SPLAT_RECORD]: the rasterizer's packed per-Gaussian records
