@@ -194,18 +194,25 @@ def make_step_inputs(cfg, device, rank, n_micro):
     return {"micro": micro, "albedo": albedo, "streams": [torch.cuda.Stream(device=device) for _ in range(n_micro)]}
 
 
-# algorithmic HBM bytes per view of each ABI call (DESIGN.md "Kernels and their rooflines").
+# algorithmic HBM bytes per view of each ABI call: what the call has to move given the data layout
+# -- every input read once, every output written once, a list entry = its 4-byte id + the 64-byte record it gathers.
 def algorithmic_bytes(name, N, I, P, n_mips_bytes):
     return {
         "gol_shade_fwd": (129 * 4 + 24 + 12) * N + 148 * N,
         "gol_shade_bwd": (16 * 4 + 24 + 12 + 12) * N + 56 * N + (129 * 4 + 24 + 12) * N,
-        "gol_project_fwd": 44 * N + 92 * N,
-        "gol_project_bwd": (44 + 24 + 16 + 4 + 4) * N + 36 * N + 44 * N,
-        "gol_bin_sort": 16 * N + 8 * I + 8 * I + 4 * I,
-        # rgb 12 + depth 4 + T 4 + idx 4 + alpha 4 + depth_norm 4 out; fused L1: target 12 in, sign image 12 out
-        # per pixel: final_T, final_idx, rgb, alpha, depth_norm written (28 B) + fused L1: target read, sign byte written
-        "gol_rasterize_fwd": 4 * I + 44 * I + 28 * P + 13 * P,
-        "gol_rasterize_bwd": 4 * I + 44 * I + 9 * P + 36 * N,   # per pixel: final_T, final_idx, sign byte
+        # in: means 12, scales 12, quats 16, opacity 4, colour 12; out: xy 8, depth 4, radius 4, conic 12, compensation 4,
+        # effective opacity 4, raster record 64
+        "gol_project_fwd": 56 * N + 100 * N,
+        # in: means / scales / quats / opacity 44, radius 4, conic 12, compensation 4, the Gaussian's gradient record 64;
+        # out: gradients of means / scales / quats / opacity 44
+        "gol_project_bwd": 128 * N + 44 * N,
+        # count pass 28 N (xy, radius, conic, opacity), scatter pass 2 x 28 N + depth 4 N; keys 8 I written + 8 I read, ids 4 I
+        "gol_bin_sort": 88 * N + 8 * I + 8 * I + 4 * I,
+        # per entry: id 4 + record 64; per pixel: final_T, final_idx, rgb, alpha, depth_norm written (28 B) + fused L1:
+        # target read 12, sign byte written
+        "gol_rasterize_fwd": 68 * I + 28 * P + 13 * P,
+        # per entry: id + record; per pixel: final_T, final_idx, sign byte; per Gaussian: 10 gradient floats accumulated
+        "gol_rasterize_bwd": 68 * I + 9 * P + 40 * N,
         "gol_l1_fwd": 24 * P,           # rendered + target image
         "gol_l1_bwd": 24 * P + 12 * P,  # ... and the image gradient
     }[name]

@@ -18,7 +18,8 @@ CALLS = {  # kernel-name prefix -> ABI call
     "shade_fwd_kernel": "gol_shade_fwd", "shade_bwd_kernel": "gol_shade_bwd", "project_fwd_kernel": "gol_project_fwd",
     "project_bwd_kernel": "gol_project_bwd", "count_lds_kernel": "gol_bin_sort", "count_kernel": "gol_bin_sort",
     "scan_kernel": "gol_bin_sort", "scatter_lds_kernel": "gol_bin_sort", "scatter_kernel": "gol_bin_sort",
-    "sort_kernel": "gol_bin_sort", "bin_": "gol_bin_sort", "raster_fwd_kernel": "gol_rasterize_fwd",
+    "sort_kernel": "gol_bin_sort", "sort_queue_kernel": "gol_bin_sort", "bin_": "gol_bin_sort",
+    "raster_fwd_kernel": "gol_rasterize_fwd", "splat_pack_kernel": "gol_splat_pack",
     "raster_bwd_kernel": "gol_rasterize_bwd", "l1_kernel<false>": "gol_l1_fwd", "l1_kernel<true>": "gol_l1_bwd",
 }
 
@@ -61,5 +62,35 @@ def main(tag):
     print("recorded", tag, "csrc", sha)
 
 
+def secondary(tag):
+    """gpurun_out/TAG/secondary_{workload}_pmc_sq.csv (tools/secondary_pmc.sh) -> profiles/valu_secondary.json:
+    {workload name: {kernel: counters per launch}}, stamped with the kernel-source digest."""
+    src = os.path.join(ROOT, "gpurun_out", tag)
+    dst = os.path.join(ROOT, "profiles")
+    sha = open(os.path.join(src, "csrc_sha16.txt")).read().strip()
+    names = {"mvp": "mvp_config5", "urhand": "urhand_config4_uvlight", "sg": "sgutils_native"}
+    out = {}
+    for w, cfg_name in names.items():
+        path = os.path.join(src, f"secondary_{w}_pmc_sq.csv")
+        if not os.path.exists(path):
+            continue
+        shutil.copy(path, os.path.join(dst, f"{tag}_{w}_pmc_sq.csv"))
+        rec = {}
+        for r in csv.DictReader(open(path)):
+            rec[r["kernel"]] = {k: float(v) for k, v in r.items() if k.startswith(("SQ_", "GRBM_")) and v not in ("", None)}
+        out[cfg_name] = rec
+        b = os.path.join(src, f"bench_{w}.json")
+        if os.path.exists(b):
+            shutil.copy(b, os.path.join(dst, f"{tag}_bench_{w}.json"))
+    out["_stamp"] = {"csrc_sha16": sha, "source": f"profiles/{tag}_*_pmc_sq.csv",
+                     "command": "rocprofv3 --pmc <counters> -- python bench.py --workload <w> --no-cpu-baseline --steps 2 "
+                                "--warmup 1 (two passes per workload; mean over the dispatches of a kernel)"}
+    json.dump(out, open(os.path.join(dst, "valu_secondary.json"), "w"), indent=1)
+    print("recorded secondary", tag, "csrc", sha, list(out))
+
+
 if __name__ == "__main__":
-    main(sys.argv[1])
+    if sys.argv[1] == "--secondary":
+        secondary(sys.argv[2])
+    else:
+        main(sys.argv[1])
