@@ -897,7 +897,10 @@ def main():
             intr = torch.stack([m0["K"][:, 0, 0], m0["K"][:, 1, 1], m0["K"][:, 0, 2], m0["K"][:, 1, 2]], -1)
             out = splat.render_views(preds["primpos"], preds["primscale"], preds["primqvec"], preds["opacity"],
                                      preds["color"], m0["Rt"], intr, cfg["height"], cfg["width"])
-            I = float(out["n_isect"].float().mean())
+            # list entries actually stored (n_isect is the RESERVED slot count since round 3: the tight tile boxes)
+            bins = out["tile_bins"]
+            I = float((bins[..., 1] - bins[..., 0]).sum(1).float().mean())
+            I_reserved = float(out["n_isect"].float().mean())
             mean_alpha = float(out["alpha"].mean())
         dom = max(kernels_ms, key=kernels_ms.get)
         mip_bytes = sum(m[0].numel() * 4 for m in t["micro"][0]["mips"])
@@ -927,7 +930,8 @@ def main():
                             "relight": "envmap_4mips",
                             "slab_layout": "uv-coherent" if args.coherent_uv else "random permutation",
                             "normal_offsets": "smooth (decoder-like)" if args.smooth_normals else "white noise (SURVEY 8d)",
-                            "intersections_per_view": I, "mean_alpha": mean_alpha}, **par),
+                            "intersections_per_view": I, "list_slots_reserved_per_view": I_reserved,
+                            "mean_alpha": mean_alpha}, **par),
             "windows": _window_stats(win_ms),
             "kernels_ms_per_call": kernels_ms,
             "roofline": roofline,
