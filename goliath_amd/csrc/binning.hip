@@ -154,10 +154,16 @@ __global__ __launch_bounds__(1024) void scatter_lds_kernel(BinArgs a, int64_t ca
                                                            uint64_t* __restrict__ isect_keys) {
   // LDS: per-tile counters packed two to a word (a workgroup sees at most `chunk` <= 4096 Gaussians, so 16 bits
   // hold any count) + per-tile 32-bit base offsets: 6 bytes per tile instead of 8, i.e. 64.5 KB at 2048x1334 -- two
-  // workgroups per CU instead of one.  The kernel is bound by its barriers (a lane with a 49-tile Gaussian holds up
-  // its 1024-thread workgroup; VALU-busy 35 %), not by instructions: measured and dropped in round 3 -- keeping the
-  // boxes and depths of the first walk in registers for the second (68 -> 102 VGPRs = one workgroup per CU: +8 %),
-  // the same under a 64-register cap (spills: +3 %), four reservation atomics in flight per lane (no change).
+  // workgroups per CU instead of one.  What bounds the kernel (0.20 ms per 8 views of 2 M stored entries each) is not its
+  // instruction count: its 8-byte key stores land in runs of ~2.7 entries per (workgroup, tile) -- 425 MB written for
+  // 126 MB of keys (PMC) -- behind two workgroups per CU that are phase-locked by their barriers.  Measured and dropped
+  // in round 3: keeping the boxes and depths of the first walk in registers for the second (68 -> 102 VGPRs = one
+  // workgroup per CU: +8 %), the same under a 64-register cap (spills: +3 %), four reservation atomics in flight per
+  // lane (no change); a PAIR-balanced walk (the wave numbers its (Gaussian, tile) pairs with a scan, every lane tests
+  // one pair per step: 100 M -> ~40 M vector instructions, bit-identical lists): 0.174 ms with 1024 Gaussians per
+  // workgroup, 0.21 / 0.24 with 2048 / 4096 (longer key runs, but fewer, longer workgroups), and 0.51 ms with one
+  // returning device atomic per pair instead of the LDS counters (profiles/r03g_global_atomic_probe.txt: device atomics
+  // top out at 26 G/s over >= 3000 addresses and fall to 1.3 G/s on 64) -- 12 % of one kernel for twice the code: not kept.
   extern __shared__ int32_t s_mem[];
   const int b = blockIdx.y, T = a.tiles_x * a.tiles_y, Tw = (T + 1) >> 1;
   uint32_t* s_cnt = reinterpret_cast<uint32_t*>(s_mem);
