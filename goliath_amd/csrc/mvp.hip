@@ -211,6 +211,54 @@ __device__ __forceinline__ void tri_setup(Tri& q, int D, int H, int W, V3 pos) {
   q.w[4] = w00 * q.fz; q.w[5] = w10 * q.fz; q.w[6] = w01 * q.fz; q.w[7] = w11 * q.fz;
 }
 
+// The same for an ARBITRARY position (warp fields, algo 1: the template is sampled at the warped position, which may
+// leave the box): every corner tested against all six bounds (utils.h:523-560).
+__device__ __forceinline__ void tri_setup_any(Tri& q, int D, int H, int W, V3 pos) {
+  const float ix = fmaxf(-100.f, fminf(100.f, (pos.x + 1.f) * 0.5f)) * (float)(W - 1);
+  const float iy = fmaxf(-100.f, fminf(100.f, (pos.y + 1.f) * 0.5f)) * (float)(H - 1);
+  const float iz = fmaxf(-100.f, fminf(100.f, (pos.z + 1.f) * 0.5f)) * (float)(D - 1);
+  const float fx0 = floorf(ix), fy0 = floorf(iy), fz0 = floorf(iz);
+  const int x0 = (int)fx0, y0 = (int)fy0, z0 = (int)fz0;
+  q.fx = ix - fx0; q.fy = iy - fy0; q.fz = iz - fz0; q.x0 = x0; q.y0 = y0; q.z0 = z0;
+  const bool vx[2] = {x0 >= 0 && x0 < W, x0 + 1 >= 0 && x0 + 1 < W};
+  const bool vy[2] = {y0 >= 0 && y0 < H, y0 + 1 >= 0 && y0 + 1 < H};
+  const bool vz[2] = {z0 >= 0 && z0 < D, z0 + 1 >= 0 && z0 + 1 < D};
+  const int sy = W, sz = H * W;
+  const int b = z0 * sz + y0 * sy + x0;
+  q.allv = true;
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    const bool v = vx[c & 1] && vy[(c >> 1) & 1] && vz[(c >> 2) & 1];
+    q.idx[c] = v ? b + (c & 1) + ((c >> 1) & 1) * sy + ((c >> 2) & 1) * sz : -1;
+    q.allv = q.allv && v;
+  }
+  const float gx = 1.f - q.fx, gy = 1.f - q.fy, gz = 1.f - q.fz;
+  const float w00 = gx * gy, w10 = q.fx * gy, w01 = gx * q.fy, w11 = q.fx * q.fy;
+  q.w[0] = w00 * gz; q.w[1] = w10 * gz; q.w[2] = w01 * gz; q.w[3] = w11 * gz;
+  q.w[4] = w00 * q.fz; q.w[5] = w10 * q.fz; q.w[6] = w01 * q.fz; q.w[7] = w11 * q.fz;
+}
+__device__ __forceinline__ bool tri_any(const Tri& q) {
+  bool v = false;
+#pragma unroll
+  for (int c = 0; c < 8; ++c) v = v || q.idx[c] >= 0;
+  return v;
+}
+
+// warped sample position y1 = trilinear(warp field of the box [WD,WH,WW,3], y0) for y0 strictly inside the box
+// (primsampler.h:53-56)
+__device__ __forceinline__ V3 warp_sample(const float* __restrict__ wp, int WD, int WH, int WW, V3 y0, Tri& qw) {
+  tri_setup(qw, WD, WH, WW, y0);
+  V3 r = v3(0.f, 0.f, 0.f);
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    if (qw.idx[c] >= 0) {
+      const float* v = gol_at(wp, (unsigned)qw.idx[c] * 12u);
+      r.x += v[0] * qw.w[c]; r.y += v[1] * qw.w[c]; r.z += v[2] * qw.w[c];
+    }
+  }
+  return r;
+}
+
 // Builds the wave's hit list (LDS) + per-box iteration windows, and positions the ray at its first
 // sample.  Returns the number of hit boxes (wave-uniform).
 __device__ __forceinline__ int build_hits(int K, const float* __restrict__ nodeaabb, const float* __restrict__ primpos,
@@ -290,6 +338,8 @@ struct MarchArgs {
   const float* primpos; const float* primrot; const float* primscale; const float* tplate;
   int group = 1;          // `group` consecutive ray images share one primitive set / template (light-batched shadow march)
   int alpha_only = 0;     // template has ONE channel (alpha); colour channels read as 0
+  const float* warp = nullptr;  // algo 1: per-box warp fields [N,K,WD,WH,WW,3] (kernels instantiated with WARP only)
+  int WD = 0, WH = 0, WW = 0;
 };
 
 __device__ __forceinline__ bool load_ray(const MarchArgs& a, int n, Ray& ray, float& tmin, float& tmax, size_t& r,
@@ -322,7 +372,7 @@ __device__ __forceinline__ float fade_pow_m1(float ax, float e, bool e8) {
   return fast_pow(ax, e - 1.f);
 }
 
-template <bool SHADOW>
+template <bool SHADOW, bool WARP>
 __global__ __launch_bounds__(256) void march_fwd_kernel(MarchArgs a, float* __restrict__ rayrgba,
                                                         float* __restrict__ raysat, float* __restrict__ shadow) {
   __shared__ int s_list[4][kMaxHits];
@@ -365,7 +415,14 @@ __global__ __launch_bounds__(256) void march_fwd_kernel(MarchArgs a, float* __re
       int sh_idx[SHADOW ? 8 : 1], sh_key = -1;
       float sh_w[SHADOW ? 8 : 1], sh_vis = 0.f;
       Tri q;  // (every lane; only evaluating lanes use theirs)
-      tri_setup(q, a.TD, a.TH, a.TW, y0);
+      if (WARP) {
+        V3 y1 = y0;
+        Tri qw;
+        if (ev) y1 = warp_sample(a.warp + ((size_t)pn * a.K + k) * (size_t)a.WD * a.WH * a.WW * 3, a.WD, a.WH, a.WW, y0, qw);
+        tri_setup_any(q, a.TD, a.TH, a.TW, y1);
+      } else {
+        tri_setup(q, a.TD, a.TH, a.TW, y0);
+      }
       const bool all_corners = gol_ballot(ev && !q.allv) == 0ull;
       if (ev) {
         const bool e8 = a.fadeexp == 8.f;
@@ -396,7 +453,7 @@ __global__ __launch_bounds__(256) void march_fwd_kernel(MarchArgs a, float* __re
           }
         }
         s3 *= fade;
-        if (SHADOW) {
+        if (SHADOW && (!WARP || tri_any(q))) {  // (a warped sample outside the template splats nothing: sh_key stays -1)
           sh_vis = 1.f - acc3;
           sh_key = ((q.z0 + 1) * (a.TH + 1) + (q.y0 + 1)) * (a.TW + 1) + (q.x0 + 1);
 #pragma unroll
@@ -416,7 +473,7 @@ __global__ __launch_bounds__(256) void march_fwd_kernel(MarchArgs a, float* __re
         // the backward: group the wave's lanes by voxel cell, reduce each group, and let lanes 15|31 (corner c) and 47|63
         // (corner c+1) issue ONE pair of atomics per (cell, corner) -- memory-side float atomics per lane are the cost.
         float* sp = shadow_n + (size_t)k * vox * 2;
-        unsigned long long todo = gol_ballot(ev);
+        unsigned long long todo = gol_ballot(WARP ? (ev && sh_key >= 0) : ev);
         while (todo) {
           const int leader = __builtin_ctzll(todo);
           const int key = __builtin_amdgcn_readlane(sh_key, leader);
@@ -445,12 +502,14 @@ __global__ __launch_bounds__(256) void march_fwd_kernel(MarchArgs a, float* __re
   }
 }
 
+template <bool WARP>
 __global__ __launch_bounds__(256) void march_bwd_kernel(MarchArgs a, const float* __restrict__ raysat_im,
                                                         const float* __restrict__ grad_rayrgba,
                                                         float* __restrict__ grad_primpos,
                                                         float* __restrict__ grad_primrot,
                                                         float* __restrict__ grad_primscale,
-                                                        float* __restrict__ grad_tplate) {
+                                                        float* __restrict__ grad_tplate,
+                                                        float* __restrict__ grad_warp) {
   __shared__ int s_list[4][kMaxHits];
   __shared__ int s_lo[4][kMaxHits];
   __shared__ int s_hi[4][kMaxHits];
@@ -500,7 +559,16 @@ __global__ __launch_bounds__(256) void march_bwd_kernel(MarchArgs a, const float
       // corner indices / weights of every lane (plain arithmetic; only lanes with `ev` use theirs): kept in `q` for the
       // scatter below instead of being copied out of the branch
       Tri q;
-      tri_setup(q, a.TD, a.TH, a.TW, y0);
+      Tri qw;  // WARP: the warp field's cell at y0
+      bool evs = ev;  // lanes taking part in the template-gradient scatter
+      if (WARP) {
+        V3 y1 = y0;
+        if (ev) y1 = warp_sample(a.warp + ((size_t)n * a.K + k) * (size_t)a.WD * a.WH * a.WW * 3, a.WD, a.WH, a.WW, y0, qw);
+        tri_setup_any(q, a.TD, a.TH, a.TW, y1);
+        evs = ev && tri_any(q);  // a warped sample outside the template has no corner to give a gradient to
+      } else {
+        tri_setup(q, a.TD, a.TH, a.TW, y0);
+      }
       const int cellkey = ((q.z0 + 1) * (a.TH + 1) + (q.y0 + 1)) * (a.TW + 1) + (q.x0 + 1);
       if (ev) {
         const float ax = fabsf(y0.x), ay = fabsf(y0.y), az = fabsf(y0.z);
@@ -541,7 +609,31 @@ __global__ __launch_bounds__(256) void march_bwd_kernel(MarchArgs a, const float
             giz += (dz ? dp : -dp) * wx * wy;
           }
         }
-        dLy = dLy + v3(gix * 0.5f * (float)(a.TW - 1), giy * 0.5f * (float)(a.TH - 1), giz * 0.5f * (float)(a.TD - 1));
+        V3 dLy1 = v3(gix * 0.5f * (float)(a.TW - 1), giy * 0.5f * (float)(a.TH - 1), giz * 0.5f * (float)(a.TD - 1));
+        if (WARP) {
+          // warp sampler backward at y0 (the chain of the reference's PyTorch fixture, mvpraymarch.py:621-626): the field's
+          // gradient (plain per-lane atomics: algo 1 has no caller in the reference's models, it is here for the fixture)
+          // and d y1 / d y0 applied to dLy1
+          const float* wp = a.warp + ((size_t)n * a.K + k) * (size_t)a.WD * a.WH * a.WW * 3;
+          float* gw = grad_warp + ((size_t)n * a.K + k) * (size_t)a.WD * a.WH * a.WW * 3;
+          float wix = 0.f, wiy = 0.f, wiz = 0.f;
+#pragma unroll
+          for (int c = 0; c < 8; ++c) {
+            if (qw.idx[c] >= 0) {
+              const float* v = gol_at(wp, (unsigned)qw.idx[c] * 12u);
+              float* g = gol_at(gw, (unsigned)qw.idx[c] * 12u);
+              atomicAdd(g, qw.w[c] * dLy1.x); atomicAdd(g + 1, qw.w[c] * dLy1.y); atomicAdd(g + 2, qw.w[c] * dLy1.z);
+              const float dp = v[0] * dLy1.x + v[1] * dLy1.y + v[2] * dLy1.z;
+              const int dx = c & 1, dy = (c >> 1) & 1, dz = (c >> 2) & 1;
+              const float wx = dx ? qw.fx : 1.f - qw.fx, wy = dy ? qw.fy : 1.f - qw.fy, wz = dz ? qw.fz : 1.f - qw.fz;
+              wix += (dx ? dp : -dp) * wy * wz;
+              wiy += (dy ? dp : -dp) * wx * wz;
+              wiz += (dz ? dp : -dp) * wx * wy;
+            }
+          }
+          dLy1 = v3(wix * 0.5f * (float)(a.WW - 1), wiy * 0.5f * (float)(a.WH - 1), wiz * 0.5f * (float)(a.WD - 1));
+        }
+        dLy = dLy + dLy1;
         sd0 = d0; sd1 = d1; sd2 = d2; sd3 = d3;
       }
       // Template-gradient scatter.  The 64 rays of a wave sample only a handful of distinct voxel cells
@@ -551,11 +643,11 @@ __global__ __launch_bounds__(256) void march_bwd_kernel(MarchArgs a, const float
       // instead of one per lane (mvpraymarch utils.h:83-113 issues one per lane).
       {
         float* gt = g_tplate + (size_t)k * vox * 4;
-        unsigned long long todo = gol_ballot(ev);
+        unsigned long long todo = gol_ballot(evs);
         while (todo) {
           const int leader = __builtin_ctzll(todo);
           const int key = __builtin_amdgcn_readlane(cellkey, leader);
-          const bool mine = ev && (cellkey == key);
+          const bool mine = evs && (cellkey == key);
           const unsigned long long grp = gol_ballot(mine);
           todo &= ~grp;
           // always reduce (even a one-lane group): memory-side atomics, not instructions, are the cost.  The two
@@ -665,8 +757,29 @@ extern "C" int gol_mvp_march_fwd(int N, int H, int W, int K, const float* raypos
   MarchArgs a{N, H, W, K, TD, TH, TW, stepsize, fadescale, fadeexp, raypos, raydir, tminmax, nodeaabb,
               primpos, primrot, primscale, tplate};
   dim3 grid(gol_cdiv(W, 16), gol_cdiv(H, 16), N);
-  if (shadow) march_fwd_kernel<true><<<grid, 256, 0, (hipStream_t)stream>>>(a, rayrgba, raysat, shadow);
-  else march_fwd_kernel<false><<<grid, 256, 0, (hipStream_t)stream>>>(a, rayrgba, raysat, shadow);
+  if (shadow) march_fwd_kernel<true, false><<<grid, 256, 0, (hipStream_t)stream>>>(a, rayrgba, raysat, shadow);
+  else march_fwd_kernel<false, false><<<grid, 256, 0, (hipStream_t)stream>>>(a, rayrgba, raysat, shadow);
+  GOL_CHECK_LAUNCH();
+  return GOL_OK;
+}
+
+extern "C" int gol_mvp_march_warp_fwd(int N, int H, int W, int K, const float* raypos, const float* raydir,
+                                      float stepsize, const float* tminmax, const float* nodeaabb, const float* primpos,
+                                      const float* primrot, const float* primscale, const float* tplate, int TD, int TH,
+                                      int TW, const float* warp, int WD, int WH, int WW, float fadescale, float fadeexp,
+                                      float* rayrgba, float* raysat, float* shadow, void* stream) {
+  int rc = check_march(N, H, W, K, TD, TH, TW, stepsize);
+  if (rc != GOL_OK) return rc;
+  GOL_REQUIRE(WD > 0 && WH > 0 && WW > 0, "bad warp field size");
+  if (N == 0 || H == 0 || W == 0) return GOL_OK;
+  GOL_REQUIRE(raypos && raydir && tminmax && nodeaabb && primpos && primrot && primscale && tplate && warp && rayrgba,
+              "null pointer");
+  MarchArgs a{N, H, W, K, TD, TH, TW, stepsize, fadescale, fadeexp, raypos, raydir, tminmax, nodeaabb,
+              primpos, primrot, primscale, tplate};
+  a.warp = warp; a.WD = WD; a.WH = WH; a.WW = WW;
+  dim3 grid(gol_cdiv(W, 16), gol_cdiv(H, 16), N);
+  if (shadow) march_fwd_kernel<true, true><<<grid, 256, 0, (hipStream_t)stream>>>(a, rayrgba, raysat, shadow);
+  else march_fwd_kernel<false, true><<<grid, 256, 0, (hipStream_t)stream>>>(a, rayrgba, raysat, shadow);
   GOL_CHECK_LAUNCH();
   return GOL_OK;
 }
@@ -685,7 +798,7 @@ extern "C" int gol_mvp_shadow_march(int N, int group, int H, int W, int K, const
   MarchArgs a{N, H, W, K, TD, TH, TW, stepsize, fadescale, fadeexp, raypos, raydir, tminmax, nodeaabb,
               primpos, primrot, primscale, tplate, group, alpha_only ? 1 : 0};
   dim3 grid(gol_cdiv(W, 16), gol_cdiv(H, 16), N);
-  march_fwd_kernel<true><<<grid, 256, 0, (hipStream_t)stream>>>(a, rayrgba, nullptr, shadow);
+  march_fwd_kernel<true, false><<<grid, 256, 0, (hipStream_t)stream>>>(a, rayrgba, nullptr, shadow);
   GOL_CHECK_LAUNCH();
   return GOL_OK;
 }
@@ -704,8 +817,32 @@ extern "C" int gol_mvp_march_bwd(int N, int H, int W, int K, const float* raypos
   MarchArgs a{N, H, W, K, TD, TH, TW, stepsize, fadescale, fadeexp, raypos, raydir, tminmax, nodeaabb,
               primpos, primrot, primscale, tplate};
   dim3 grid(gol_cdiv(W, 16), gol_cdiv(H, 16), N);
-  march_bwd_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(a, raysat, grad_rayrgba, grad_primpos, grad_primrot,
-                                                           grad_primscale, grad_tplate);
+  march_bwd_kernel<false><<<grid, 256, 0, (hipStream_t)stream>>>(a, raysat, grad_rayrgba, grad_primpos, grad_primrot,
+                                                                  grad_primscale, grad_tplate, nullptr);
+  GOL_CHECK_LAUNCH();
+  return GOL_OK;
+}
+
+extern "C" int gol_mvp_march_warp_bwd(int N, int H, int W, int K, const float* raypos, const float* raydir,
+                                      float stepsize, const float* tminmax, const float* nodeaabb, const float* primpos,
+                                      const float* primrot, const float* primscale, const float* tplate, int TD, int TH,
+                                      int TW, const float* warp, int WD, int WH, int WW, float fadescale, float fadeexp,
+                                      const float* raysat, const float* grad_rayrgba, float* grad_primpos,
+                                      float* grad_primrot, float* grad_primscale, float* grad_tplate, float* grad_warp,
+                                      void* stream) {
+  int rc = check_march(N, H, W, K, TD, TH, TW, stepsize);
+  if (rc != GOL_OK) return rc;
+  GOL_REQUIRE(WD > 0 && WH > 0 && WW > 0, "bad warp field size");
+  if (N == 0 || H == 0 || W == 0) return GOL_OK;
+  GOL_REQUIRE(raypos && raydir && tminmax && nodeaabb && primpos && primrot && primscale && tplate && warp, "null pointer");
+  GOL_REQUIRE(raysat && grad_rayrgba && grad_primpos && grad_primrot && grad_primscale && grad_tplate && grad_warp,
+              "null pointer");
+  MarchArgs a{N, H, W, K, TD, TH, TW, stepsize, fadescale, fadeexp, raypos, raydir, tminmax, nodeaabb,
+              primpos, primrot, primscale, tplate};
+  a.warp = warp; a.WD = WD; a.WH = WH; a.WW = WW;
+  dim3 grid(gol_cdiv(W, 16), gol_cdiv(H, 16), N);
+  march_bwd_kernel<true><<<grid, 256, 0, (hipStream_t)stream>>>(a, raysat, grad_rayrgba, grad_primpos, grad_primrot,
+                                                                 grad_primscale, grad_tplate, grad_warp);
   GOL_CHECK_LAUNCH();
   return GOL_OK;
 }

@@ -7,8 +7,9 @@ Drop-in for the reference operators (interfaces only; the work happens in libgol
   compute_raydirs(...), utilslib.compute_raydirs_forward
                                         <- extensions/utils/utils.py:26-54, utils.cpp:46-82
   Raymarcher                            <- ca_code/utils/render_raymarcher.py:18-71
-Supported configuration = the one every model in the reference uses: algo 0 without a
-warp field, usebvh="fixedorder", channels-last template, additive accumulation.  The options the
+Supported configuration = the one every model in the reference uses: algo 0, usebvh="fixedorder",
+channels-last template, additive accumulation -- plus algo 1 (a warp field per box, the second case of the reference's
+in-tree gradcheck, mvpraymarch.py:790-803).  The options the
 reference accepts but its kernels ignore (sortprims, maxhitboxes, synchitboxes, accum, termthresh,
 griddim, blocksize) are accepted and ignored here too.  Everything runs on the CURRENT stream with a
 device guard (the reference uses stream 0).
@@ -35,6 +36,20 @@ def _dims(template):
     return template.shape[1], template.shape[2], template.shape[3], template.shape[4]
 
 
+def _check_algo(algo, warp):
+    """algo 0 = no warp field, algo 1 = one warp field per box (mvpraymarch_kernel.cu:92-104); algo 2 (no softplus'd
+    template, experimental in the reference) is not built."""
+    if algo not in (0, 1) or (algo == 1) != (warp is not None):
+        raise NotImplementedError(f"algo={algo} with warp {'given' if warp is not None else 'absent'}: algo 0 takes no warp "
+                                  "field, algo 1 needs one; other algorithms are not implemented")
+
+
+def _warp_dims(warp, template):
+    if warp.dim() != 6 or warp.size(-1) != 3 or warp.shape[:2] != template.shape[:2]:
+        raise RuntimeError("warp must be channels-last [N, K, WD, WH, WW, 3] with the template's N, K")
+    return warp.shape[2], warp.shape[3], warp.shape[4]
+
+
 class _MvpLib:
     """Same entry points as the reference's compiled `mvpraymarchlib`."""
 
@@ -58,8 +73,7 @@ class _MvpLib:
                          primscale, template, warp, rayrgba, raysat, rayterm, shadow, algo=0, sortboxes=False,
                          maxhitboxes=512, synchitboxes=True, chlast=True, fadescale=8.0, fadeexp=8.0, accum=0,
                          termthresh=0.0, griddim=3, blocksizex=8, blocksizey=16):
-        if warp is not None or algo != 0:
-            raise NotImplementedError("warp fields (algo 1) have no caller in the reference and are not implemented")
+        _check_algo(algo, warp)
         if not chlast:
             raise NotImplementedError("only channels-last templates (chlast=True, the reference default)")
         if nodeaabb is None:
@@ -67,6 +81,16 @@ class _MvpLib:
         N, H, W = raypos.shape[:3]
         K, TD, TH, TW = _dims(template)
         _need_gpu(raypos, "raypos")
+        if warp is not None:
+            WD, WH, WW = _warp_dims(warp, template)
+            with _lib.device_guard(raypos.device):
+                _lib.call("gol_mvp_march_warp_fwd", c_int(N), c_int(H), c_int(W), c_int(K), fptr(raypos, "raypos"),
+                          fptr(raydir, "raydir"), c_float(stepsize), fptr(tminmax, "tminmax"), fptr(nodeaabb, "nodeaabb"),
+                          fptr(primpos, "primpos"), fptr(primrot, "primrot"), fptr(primscale, "primscale"),
+                          fptr(template, "template"), c_int(TD), c_int(TH), c_int(TW), fptr(warp, "warp"), c_int(WD),
+                          c_int(WH), c_int(WW), c_float(fadescale), c_float(fadeexp), fptr(rayrgba, "rayrgba"),
+                          fptr(raysat, "raysat"), fptr(shadow, "shadow"), stream_ptr())
+            return []
         with _lib.device_guard(raypos.device):
             _lib.call("gol_mvp_march_fwd", c_int(N), c_int(H), c_int(W), c_int(K), fptr(raypos, "raypos"),
                       fptr(raydir, "raydir"), c_float(stepsize), fptr(tminmax, "tminmax"), fptr(nodeaabb, "nodeaabb"),
@@ -82,11 +106,24 @@ class _MvpLib:
                           warp, grad_warp, rayrgba, grad_rayrgba, raysat, rayterm, algo=0, sortboxes=False,
                           maxhitboxes=512, synchitboxes=True, chlast=True, fadescale=8.0, fadeexp=8.0, accum=0,
                           termthresh=0.0, griddim=3, blocksizex=8, blocksizey=16):
-        if warp is not None or algo != 0 or not chlast:
-            raise NotImplementedError("only algo 0 / channels-last / no warp field")
+        _check_algo(algo, warp)
+        if not chlast:
+            raise NotImplementedError("only channels-last templates (chlast=True, the reference default)")
         N, H, W = raypos.shape[:3]
         K, TD, TH, TW = _dims(template)
         _need_gpu(raypos, "raypos")
+        if warp is not None:
+            WD, WH, WW = _warp_dims(warp, template)
+            if grad_warp is None or grad_warp.shape != warp.shape:
+                raise RuntimeError("grad_warp must have the shape of warp")
+            with _lib.device_guard(raypos.device):
+                _lib.call("gol_mvp_march_warp_bwd", c_int(N), c_int(H), c_int(W), c_int(K), fptr(raypos), fptr(raydir),
+                          c_float(stepsize), fptr(tminmax), fptr(nodeaabb), fptr(primpos), fptr(primrot),
+                          fptr(primscale), fptr(template), c_int(TD), c_int(TH), c_int(TW), fptr(warp, "warp"),
+                          c_int(WD), c_int(WH), c_int(WW), c_float(fadescale), c_float(fadeexp), fptr(raysat, "raysat"),
+                          fptr(grad_rayrgba, "grad_rayrgba"), fptr(grad_primpos), fptr(grad_primrot),
+                          fptr(grad_primscale), fptr(grad_template), fptr(grad_warp, "grad_warp"), stream_ptr())
+            return []
         with _lib.device_guard(raypos.device):
             _lib.call("gol_mvp_march_bwd", c_int(N), c_int(H), c_int(W), c_int(K), fptr(raypos), fptr(raydir),
                       c_float(stepsize), fptr(tminmax), fptr(nodeaabb), fptr(primpos), fptr(primrot), fptr(primscale),
@@ -120,21 +157,22 @@ def build_accel(primtransfin, algo=0, fixedorder=True):
 
 class MVPRaymarch(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, raypos, raydir, stepsize, tminmax, primpos, primrot, primscale, template, gradmode, opts):
+    def forward(ctx, raypos, raydir, stepsize, tminmax, primpos, primrot, primscale, template, gradmode, opts, warp=None):
         for name, t, last in (("raypos", raypos, 3), ("raydir", raydir, 3), ("tminmax", tminmax, 2)):
             assert t.is_contiguous() and t.size(3) == last, name
         for name, t in (("primpos", primpos), ("primrot", primrot), ("primscale", primscale)):
             assert t.is_contiguous() and t.size(2) == 3, name
         assert template.is_contiguous() and template.dim() == 6 and template.size(-1) == 4
+        assert warp is None or (warp.is_contiguous() and warp.size(-1) == 3)  # mvpraymarch.py:125
         _, _, nodeaabb = build_accel((primpos, primrot, primscale), opts["algo"], fixedorder=True)
         N, H, W = raypos.shape[:3]
         rayrgba = torch.empty(N, H, W, 4, device=raypos.device)
         raysat = torch.full((N, H, W, 3), -1.0, device=raypos.device) if gradmode else None
         shadow = torch.zeros(*template.shape[:5], 2, device=template.device) if opts["with_shadow"] else None
         mvpraymarchlib.raymarch_forward(raypos, raydir, stepsize, tminmax, None, None, nodeaabb, primpos, primrot,
-                                        primscale, template, None, rayrgba, raysat, None, shadow,
+                                        primscale, template, warp, rayrgba, raysat, None, shadow, algo=opts["algo"],
                                         fadescale=opts["fadescale"], fadeexp=opts["fadeexp"])
-        ctx.save_for_backward(raypos, raydir, tminmax, nodeaabb, primpos, primrot, primscale, template, raysat)
+        ctx.save_for_backward(raypos, raydir, tminmax, nodeaabb, primpos, primrot, primscale, template, raysat, warp)
         ctx.opts, ctx.stepsize = opts, stepsize
         if shadow is not None:
             ctx.mark_non_differentiable(shadow)
@@ -142,16 +180,17 @@ class MVPRaymarch(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, grad_rayrgba, _grad_shadow):
-        raypos, raydir, tminmax, nodeaabb, primpos, primrot, primscale, template, raysat = ctx.saved_tensors
+        raypos, raydir, tminmax, nodeaabb, primpos, primrot, primscale, template, raysat, warp = ctx.saved_tensors
         if raysat is None:
             raise RuntimeError("mvpraymarch was run with gradients disabled")
         g_pos, g_rot, g_scale = torch.zeros_like(primpos), torch.zeros_like(primrot), torch.zeros_like(primscale)
         g_tpl = torch.zeros_like(template)
+        g_warp = None if warp is None else torch.zeros_like(warp)
         mvpraymarchlib.raymarch_backward(raypos, raydir, ctx.stepsize, tminmax, None, None, nodeaabb, primpos, g_pos,
-                                         primrot, g_rot, primscale, g_scale, template, g_tpl, None, None, None,
-                                         grad_rayrgba.contiguous(), raysat, None, fadescale=ctx.opts["fadescale"],
-                                         fadeexp=ctx.opts["fadeexp"])
-        return None, None, None, None, g_pos, g_rot, g_scale, g_tpl, None, None
+                                         primrot, g_rot, primscale, g_scale, template, g_tpl, warp, g_warp, None,
+                                         grad_rayrgba.contiguous(), raysat, None, algo=ctx.opts["algo"],
+                                         fadescale=ctx.opts["fadescale"], fadeexp=ctx.opts["fadeexp"])
+        return None, None, None, None, g_pos, g_rot, g_scale, g_tpl, None, None, g_warp
 
 
 def mvpraymarch(raypos, raydir, stepsize, tminmax, primtransf, template, warp, rayterm=None, algo=0,
@@ -159,10 +198,9 @@ def mvpraymarch(raypos, raydir, stepsize, tminmax, primtransf, template, warp, r
                 chlast=True, fadescale=8.0, fadeexp=8.0, accum=2, termthresh=0.99, griddim=3, blocksize=(8, 16),
                 bwdblocksize=(8, 16), with_shadow=False):
     """raypos/raydir[N,H,W,3], tminmax[N,H,W,2], primtransf = (primpos[N,K,3], primrot[N,K,3,3],
-    primscale[N,K,3]) or the packed [N,K,5,3] tensor, template[N,K,TD,TH,TW,4] -> rayrgba[N,H,W,4]
-    (and the normalised shadow grid when with_shadow)."""
-    if warp is not None or algo != 0:
-        raise NotImplementedError("warp fields (algo 1) have no caller in the reference and are not implemented")
+    primscale[N,K,3]) or the packed [N,K,5,3] tensor, template[N,K,TD,TH,TW,4], warp = None (algo 0) or the warp fields
+    [N,K,WD,WH,WW,3] (algo 1) -> rayrgba[N,H,W,4] (and the normalised shadow grid when with_shadow)."""
+    _check_algo(algo, warp)
     if usebvh != "fixedorder" or randomorder or not chlast:
         raise NotImplementedError("only usebvh='fixedorder', randomorder=False, chlast=True")
     if isinstance(primtransf, tuple):
@@ -172,7 +210,7 @@ def mvpraymarch(raypos, raydir, stepsize, tminmax, primtransf, template, warp, r
                                        primtransf[:, :, 4, :].contiguous())
     opts = dict(algo=algo, fadescale=float(fadescale), fadeexp=float(fadeexp), with_shadow=bool(with_shadow))
     out, shadow = MVPRaymarch.apply(raypos, raydir, float(stepsize), tminmax, primpos, primrot, primscale, template,
-                                    torch.is_grad_enabled(), opts)
+                                    torch.is_grad_enabled(), opts, warp)
     if with_shadow:
         return out, shadow[..., 0:1] / (shadow[..., 1:] + 1e-5)
     return out

@@ -316,6 +316,26 @@ int gol_mvp_march_bwd(int N, int H, int W, int K, const float* raypos, const flo
                       float* grad_primpos, float* grad_primrot, float* grad_primscale, float* grad_tplate,
                       void* stream);
 
+/* algo 1 of the reference operator (mvpraymarch_kernel.cu:92-97, PrimSamplerTW<true>, primsampler.h:53-61, 83-87): every
+ * box carries a warp field warp[N,K,WD,WH,WW,3] (channels-last, the layout raymarch_forward receives with chlast = true,
+ * mvpraymarch.py:686); a sample at box position y0 reads its template at y1 = trilinear(warp_k, y0) -- y1 may leave the
+ * box: missing corners read 0 -- while the fade term stays a function of y0.  Backward: additionally grad_warp
+ * [N,K,WD,WH,WW,3] (ACCUMULATED, caller zeroes) and d y1 / d y0 in the chain to the box transform.  The gradient chain is
+ * the one of the reference's own PyTorch fixture (mvpraymarch.py:603-626, pinned by tests/golden/mvp_golden.npz set "w");
+ * the CUDA sampler hands the already warped position to its backward (primsampler.h:64 overwrites y0, :71-86 use it),
+ * which differs from that fixture as soon as the warp is not the identity.  No model of the reference emits a warp. */
+int gol_mvp_march_warp_fwd(int N, int H, int W, int K, const float* raypos, const float* raydir, float stepsize,
+                           const float* tminmax, const float* nodeaabb, const float* primpos,
+                           const float* primrot, const float* primscale, const float* tplate, int TD, int TH,
+                           int TW, const float* warp, int WD, int WH, int WW, float fadescale, float fadeexp,
+                           float* rayrgba, float* raysat, float* shadow, void* stream);
+int gol_mvp_march_warp_bwd(int N, int H, int W, int K, const float* raypos, const float* raydir, float stepsize,
+                           const float* tminmax, const float* nodeaabb, const float* primpos,
+                           const float* primrot, const float* primscale, const float* tplate, int TD, int TH,
+                           int TW, const float* warp, int WD, int WH, int WW, float fadescale, float fadeexp,
+                           const float* raysat, const float* grad_rayrgba, float* grad_primpos, float* grad_primrot,
+                           float* grad_primscale, float* grad_tplate, float* grad_warp, void* stream);
+
 /* Light-batched shadow march of the teacher model (ca_code/models/hand_teacher_mvp.py:271-358, no_grad): N = B*L ray
  * images (L = `group` lights per frame, consecutive), but the primitive transforms, the AABB tree and the template exist
  * once per FRAME: primpos/primrot/primscale [B,K,.], nodeaabb [B,2K-1,2,3], tplate [B,K,TD,TH,TW,4] -- or, with

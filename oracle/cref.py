@@ -213,9 +213,9 @@ def mvp_set_footprint(w=0, h=0, cap=0):
 
 
 def mvp_forward(raypos, raydir, stepsize, tminmax, primpos, primrot, primscale, template, fadescale=8.0,
-                fadeexp=8.0, want_raysat=True, with_shadow=False):
-    """mvpraymarchlib.raymarch_forward semantics (algo 0, chlast).  template[N,K,TD,TH,TW,4].
-    Returns rayrgba[N,H,W,4], raysat[N,H,W,3] (or None), shadow[N,K,TD,TH,TW,2] (or None)."""
+                fadeexp=8.0, want_raysat=True, with_shadow=False, warp=None):
+    """mvpraymarchlib.raymarch_forward semantics (algo 0, or algo 1 with warp[N,K,WD,WH,WW,3]; chlast).
+    template[N,K,TD,TH,TW,4].  Returns rayrgba[N,H,W,4], raysat[N,H,W,3] (or None), shadow[N,K,TD,TH,TW,2] (or None)."""
     raypos, raydir, tminmax, primpos, primrot, primscale, template = map(
         _f, (raypos, raydir, tminmax, primpos, primrot, primscale, template))
     N, H, W = raypos.shape[:3]
@@ -223,24 +223,33 @@ def mvp_forward(raypos, raydir, stepsize, tminmax, primpos, primrot, primscale, 
     out = torch.empty(N, H, W, 4)
     sat = torch.empty(N, H, W, 3) if want_raysat else None
     shadow = torch.zeros(N, K, TD, TH, TW, 2) if with_shadow else None
-    lib().orc_mvp_fwd(c_int(N), c_int(H), c_int(W), c_int(K), _p(raypos), _p(raydir), c_float(stepsize), _p(tminmax),
-                      _p(primpos), _p(primrot), _p(primscale), _p(template), c_int(TD), c_int(TH), c_int(TW),
-                      c_float(fadescale), c_float(fadeexp), _p(out), _p(sat), _p(shadow))
+    warp = None if warp is None else _f(warp)
+    WD, WH, WW = (0, 0, 0) if warp is None else warp.shape[2:5]
+    lib().orc_mvp_fwd_warp(c_int(N), c_int(H), c_int(W), c_int(K), _p(raypos), _p(raydir), c_float(stepsize), _p(tminmax),
+                           _p(primpos), _p(primrot), _p(primscale), _p(template), c_int(TD), c_int(TH), c_int(TW),
+                           _p(warp), c_int(WD), c_int(WH), c_int(WW),
+                           c_float(fadescale), c_float(fadeexp), _p(out), _p(sat), _p(shadow))
     return out, sat, shadow
 
 
 def mvp_backward(raypos, raydir, stepsize, tminmax, primpos, primrot, primscale, template, raysat, grad_rayrgba,
-                 fadescale=8.0, fadeexp=8.0):
-    """mvpraymarchlib.raymarch_backward semantics; returns grads (primpos, primrot, primscale, template)."""
+                 fadescale=8.0, fadeexp=8.0, warp=None):
+    """mvpraymarchlib.raymarch_backward semantics; returns grads (primpos, primrot, primscale, template) -- and the warp
+    field's as a fifth value when `warp` is given."""
     raypos, raydir, tminmax, primpos, primrot, primscale, template, raysat, grad_rayrgba = map(
         _f, (raypos, raydir, tminmax, primpos, primrot, primscale, template, raysat, grad_rayrgba))
     N, H, W = raypos.shape[:3]
     K, TD, TH, TW = template.shape[1:5]
     gp, gr, gs, gt = torch.zeros_like(primpos), torch.zeros_like(primrot), torch.zeros_like(primscale), torch.zeros_like(template)
-    lib().orc_mvp_bwd(c_int(N), c_int(H), c_int(W), c_int(K), _p(raypos), _p(raydir), c_float(stepsize), _p(tminmax),
-                      _p(primpos), _p(primrot), _p(primscale), _p(template), c_int(TD), c_int(TH), c_int(TW),
-                      c_float(fadescale), c_float(fadeexp), _p(raysat), _p(grad_rayrgba), _p(gp), _p(gr), _p(gs), _p(gt))
-    return gp, gr, gs, gt
+    warp = None if warp is None else _f(warp)
+    gw = None if warp is None else torch.zeros_like(warp)
+    WD, WH, WW = (0, 0, 0) if warp is None else warp.shape[2:5]
+    lib().orc_mvp_bwd_warp(c_int(N), c_int(H), c_int(W), c_int(K), _p(raypos), _p(raydir), c_float(stepsize), _p(tminmax),
+                           _p(primpos), _p(primrot), _p(primscale), _p(template), c_int(TD), c_int(TH), c_int(TW),
+                           _p(warp), c_int(WD), c_int(WH), c_int(WW),
+                           c_float(fadescale), c_float(fadeexp), _p(raysat), _p(grad_rayrgba), _p(gp), _p(gr), _p(gs), _p(gt),
+                           _p(gw))
+    return (gp, gr, gs, gt) if warp is None else (gp, gr, gs, gt, gw)
 
 
 def mvp_aabb(primpos, primrot, primscale):

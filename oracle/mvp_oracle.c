@@ -87,6 +87,17 @@ static void tri_setup(tri_t* q, int D, int H, int W, f3 pos) {
   }
 }
 
+/* 3-channel trilinear sample of a channels-last warp field at pos (same sampler as the template's, utils.h:523-617) */
+static f3 warp_sample(const float* wp, int D, int H, int W, f3 pos) {
+  tri_t q; tri_setup(&q, D, H, W, pos);
+  f3 r = f3_(0.f, 0.f, 0.f);
+  for (int c = 0; c < 8; ++c) if (q.i[c] >= 0) {
+    const float* v = wp + (size_t)q.i[c] * 3;
+    r.x += v[0] * q.w[c]; r.y += v[1] * q.w[c]; r.z += v[2] * q.w[c];
+  }
+  return r;
+}
+
 static int sat_floor_to_int(float v) {
   float f = floorf(v);
   if (f != f) return 0;
@@ -165,10 +176,12 @@ static int* build_block_lists(int N, int H, int W, int K, const int* order, cons
  * forward: rayrgba[N,H,W,4]; raysat[N,H,W,3] (may be NULL); shadow[N,K,TD,TH,TW,2] (may be NULL,
  * accumulated).  template[N,K,TD,TH,TW,4].
  * ---------------------------------------------------------------------------------------------- */
-void orc_mvp_fwd(int N, int H, int W, int K, const float* rayposim, const float* raydirim, float stepsize,
-                 const float* tminmaxim, const float* primpos_, const float* primrot_, const float* primscale_,
-                 const float* tplate_, int TD, int TH, int TW, float fadescale, float fadeexp, float* rayrgba,
-                 float* raysat, float* shadow_) {
+/* warp_ (optional, algo 1): [N,K,WD,WH,WW,3] channels-last warp fields; the template is sampled at the warped
+ * position y1 = trilinear(warp_k, y0) (primsampler.h:53-61), which may leave the box: zero padding per corner. */
+void orc_mvp_fwd_warp(int N, int H, int W, int K, const float* rayposim, const float* raydirim, float stepsize,
+                      const float* tminmaxim, const float* primpos_, const float* primrot_, const float* primscale_,
+                      const float* tplate_, int TD, int TH, int TW, const float* warp_, int WD, int WH, int WW,
+                      float fadescale, float fadeexp, float* rayrgba, float* raysat, float* shadow_) {
   int* order = (int*)malloc(sizeof(int) * K);
   dfs_leaf_order(K, order);
   const size_t vox = (size_t)TD * TH * TW;
@@ -207,7 +220,9 @@ void orc_mvp_fwd(int N, int H, int W, int K, const float* rayposim, const float*
           f3 y0 = xform_fwd(&xf, primpos, primrot, primscale, k, raypos);
           if (valid_pos(y0) && !sat && t < rt1 + 1e-5f) {
             float fade = expf(-fadescale * (powf(fabsf(y0.x), fadeexp) + powf(fabsf(y0.y), fadeexp) + powf(fabsf(y0.z), fadeexp)));
-            tri_t q; tri_setup(&q, TD, TH, TW, y0);
+            f3 y1 = y0;
+            if (warp_) y1 = warp_sample(warp_ + ((size_t)n * K + k) * (size_t)WD * WH * WW * 3, WD, WH, WW, y0);
+            tri_t q; tri_setup(&q, TD, TH, TW, y1);
             float smp[4] = {0, 0, 0, 0};
             const float* tp = tplate + (size_t)k * vox * 4;
             for (int c = 0; c < 8; ++c) if (q.i[c] >= 0) for (int ch = 0; ch < 4; ++ch) smp[ch] += tp[(size_t)q.i[c] * 4 + ch] * q.w[c];
@@ -240,15 +255,28 @@ void orc_mvp_fwd(int N, int H, int W, int K, const float* rayposim, const float*
   free(order); free(lists);
 }
 
+void orc_mvp_fwd(int N, int H, int W, int K, const float* rayposim, const float* raydirim, float stepsize,
+                 const float* tminmaxim, const float* primpos_, const float* primrot_, const float* primscale_,
+                 const float* tplate_, int TD, int TH, int TW, float fadescale, float fadeexp, float* rayrgba,
+                 float* raysat, float* shadow_) {
+  orc_mvp_fwd_warp(N, H, W, K, rayposim, raydirim, stepsize, tminmaxim, primpos_, primrot_, primscale_, tplate_, TD, TH, TW,
+                   NULL, 0, 0, 0, fadescale, fadeexp, rayrgba, raysat, shadow_);
+}
+
 /* ---------------------------------------------------------------------------------------------- *
  * backward (forward-direction replay, mvpraymarch_subset_kernel.h:114-228).  Gradients are summed in
  * double for an order-independent reference; grad_* are written (not accumulated).
  * ---------------------------------------------------------------------------------------------- */
-void orc_mvp_bwd(int N, int H, int W, int K, const float* rayposim, const float* raydirim, float stepsize,
-                 const float* tminmaxim, const float* primpos_, const float* primrot_, const float* primscale_,
-                 const float* tplate_, int TD, int TH, int TW, float fadescale, float fadeexp,
-                 const float* raysat_, const float* grad_rayrgba, float* grad_primpos, float* grad_primrot,
-                 float* grad_primscale, float* grad_tplate) {
+/* With a warp field the chain is the one of the reference's own PyTorch fixture (mvpraymarch.py:603-626): fade and its
+ * derivative at the box position y0, template gradient at y1, warp-field gradient and d y1 / d y0 at y0.  (The CUDA
+ * sampler hands the ALREADY WARPED position to its backward -- primsampler.h:64 overwrites y0, :71-86 use it -- which
+ * disagrees with that fixture whenever the warp is not the identity; no model of the reference emits a warp.) */
+void orc_mvp_bwd_warp(int N, int H, int W, int K, const float* rayposim, const float* raydirim, float stepsize,
+                      const float* tminmaxim, const float* primpos_, const float* primrot_, const float* primscale_,
+                      const float* tplate_, int TD, int TH, int TW, const float* warp_, int WD, int WH, int WW,
+                      float fadescale, float fadeexp, const float* raysat_, const float* grad_rayrgba,
+                      float* grad_primpos, float* grad_primrot, float* grad_primscale, float* grad_tplate,
+                      float* grad_warp) {
   int* order = (int*)malloc(sizeof(int) * K);
   dfs_leaf_order(K, order);
   const size_t vox = (size_t)TD * TH * TW;
@@ -256,6 +284,8 @@ void orc_mvp_bwd(int N, int H, int W, int K, const float* rayposim, const float*
   double* gP = (double*)calloc((size_t)N * K * 3, sizeof(double));
   double* gR = (double*)calloc((size_t)N * K * 9, sizeof(double));
   double* gS = (double*)calloc((size_t)N * K * 3, sizeof(double));
+  const size_t wvox = (size_t)WD * WH * WW;
+  double* gW = warp_ ? (double*)calloc((size_t)N * K * wvox * 3, sizeof(double)) : NULL;
   int nbx = 0, nby = 0;
   int* lists = build_block_lists(N, H, W, K, order, rayposim, raydirim, primpos_, primrot_, primscale_, &nbx, &nby);
 #pragma omp parallel
@@ -292,7 +322,10 @@ void orc_mvp_bwd(int N, int H, int W, int K, const float* rayposim, const float*
           if (!(valid_pos(y0) && !sat && t < rt1 + 1e-5f)) continue;
           float px = powf(fabsf(y0.x), fadeexp), py = powf(fabsf(y0.y), fadeexp), pz = powf(fabsf(y0.z), fadeexp);
           float fade = expf(-fadescale * (px + py + pz));
-          tri_t q; tri_setup(&q, TD, TH, TW, y0);
+          f3 y1 = y0;
+          const float* wp = warp_ ? warp_ + ((size_t)n * K + k) * wvox * 3 : NULL;
+          if (wp) y1 = warp_sample(wp, WD, WH, WW, y0);
+          tri_t q; tri_setup(&q, TD, TH, TW, y1);
           float smp[4] = {0, 0, 0, 0};
           const float* tp = tplate + (size_t)k * vox * 4;
           for (int c = 0; c < 8; ++c) if (q.i[c] >= 0) for (int ch = 0; ch < 4; ++ch) smp[ch] += tp[(size_t)q.i[c] * 4 + ch] * q.w[c];
@@ -335,7 +368,29 @@ void orc_mvp_bwd(int N, int H, int W, int K, const float* rayposim, const float*
             giy += (dy ? 1.f : -1.f) * wx * wz * dp;
             giz += (dz ? 1.f : -1.f) * wx * wy * dp;
           }
-          dLy = add(dLy, f3_(gix * (TW - 1.f) / 2, giy * (TH - 1.f) / 2, giz * (TD - 1.f) / 2));
+          f3 dLy1 = f3_(gix * (TW - 1.f) / 2, giy * (TH - 1.f) / 2, giz * (TD - 1.f) / 2);
+          if (wp) {  /* warp sampler backward at y0: field gradient + d y1 / d y0 */
+            tri_t qw; tri_setup(&qw, WD, WH, WW, y0);
+            double* gw = gW + ((size_t)n * K + k) * wvox * 3;
+            float wix = 0.f, wiy = 0.f, wiz = 0.f;
+            for (int c = 0; c < 8; ++c) if (qw.i[c] >= 0) {
+              const float* v = wp + (size_t)qw.i[c] * 3;
+              float comp[3] = {dLy1.x, dLy1.y, dLy1.z};
+              for (int ch = 0; ch < 3; ++ch) {
+#pragma omp atomic
+                gw[(size_t)qw.i[c] * 3 + ch] += (double)(qw.w[c] * comp[ch]);
+              }
+              float dp = v[0] * dLy1.x + v[1] * dLy1.y + v[2] * dLy1.z;
+              int dx = c & 1, dy = (c >> 1) & 1, dz = (c >> 2) & 1;
+              float wx = dx ? (qw.ix - qw.x0) : (qw.x0 + 1 - qw.ix), wy = dy ? (qw.iy - qw.y0) : (qw.y0 + 1 - qw.iy),
+                    wz = dz ? (qw.iz - qw.z0) : (qw.z0 + 1 - qw.iz);
+              wix += (dx ? 1.f : -1.f) * wy * wz * dp;
+              wiy += (dy ? 1.f : -1.f) * wx * wz * dp;
+              wiz += (dz ? 1.f : -1.f) * wx * wy * dp;
+            }
+            dLy1 = f3_(wix * (WW - 1.f) / 2, wiy * (WH - 1.f) / 2, wiz * (WD - 1.f) / 2);
+          }
+          dLy = add(dLy, dLy1);
           /* primtransf.h:155-179 */
           double* gs = gS + ((size_t)n * K + k) * 3; double* gr = gR + ((size_t)n * K + k) * 9;
           double* gp = gP + ((size_t)n * K + k) * 3;
@@ -358,7 +413,18 @@ void orc_mvp_bwd(int N, int H, int W, int K, const float* rayposim, const float*
   for (size_t i = 0; i < (size_t)N * K * vox * 4; ++i) grad_tplate[i] = (float)gT[i];
   for (size_t i = 0; i < (size_t)N * K * 3; ++i) { grad_primpos[i] = (float)gP[i]; grad_primscale[i] = (float)gS[i]; }
   for (size_t i = 0; i < (size_t)N * K * 9; ++i) grad_primrot[i] = (float)gR[i];
+  if (gW) { for (size_t i = 0; i < (size_t)N * K * wvox * 3; ++i) grad_warp[i] = (float)gW[i]; free(gW); }
   free(gT); free(gP); free(gR); free(gS); free(order); free(lists);
+}
+
+void orc_mvp_bwd(int N, int H, int W, int K, const float* rayposim, const float* raydirim, float stepsize,
+                 const float* tminmaxim, const float* primpos_, const float* primrot_, const float* primscale_,
+                 const float* tplate_, int TD, int TH, int TW, float fadescale, float fadeexp,
+                 const float* raysat_, const float* grad_rayrgba, float* grad_primpos, float* grad_primrot,
+                 float* grad_primscale, float* grad_tplate) {
+  orc_mvp_bwd_warp(N, H, W, K, rayposim, raydirim, stepsize, tminmaxim, primpos_, primrot_, primscale_, tplate_, TD, TH, TW,
+                   NULL, 0, 0, 0, fadescale, fadeexp, raysat_, grad_rayrgba, grad_primpos, grad_primrot, grad_primscale,
+                   grad_tplate, NULL);
 }
 
 /* primtransf.h:12-63 + bvh.cu:157-201, fixed-order tree (sortedobjid[k] = k, heap children 2i+1, 2i+2):

@@ -8,7 +8,8 @@ reference source text at run time, substitutes the device literal and the size c
 function where its CUDA half begins, and executes the reference's PyTorch half unchanged on CPU.
 Nothing from the reference is copied into the repository.  Recipe kept from the reference:
 torch.manual_seed(1112), coherent pinhole rays, coherent centres, Rodrigues rotations,
-usebvh="fixedorder", sortprims=False, chlast=True, fadescale=6.5, fadeexp=7.5, accum=0, algo=0.
+usebvh="fixedorder", sortprims=False, chlast=True, fadescale=6.5, fadeexp=7.5, accum=0, algo=0; set "w": the same recipe
+with dowarp=True, algo=1 (the second gradcheck of the reference's __main__, mvpraymarch.py:790-803).
 """
 import os
 import re
@@ -58,6 +59,20 @@ def mvp():
             f"{tag}/grad_primrot": g["primrot"], f"{tag}/grad_primscale": g["primscale"],
         })
         print(tag, "alpha range", float(L["sample0"][..., 3].min()), float(L["sample0"][..., 3].max()))
+    # warp fields (algo 1, mvpraymarch.py:777-803 second gradcheck): warp [N,K,3,M/2,M/2,M/2] = identity grid + noise
+    L = ns["gradcheck"](usebvh="fixedorder", sortprims=False, maxhitboxes=512, synchitboxes=True, dowarp=True,
+                        chlast=True, fadescale=6.5, fadeexp=7.5, accum=0, algo=1, griddim=3)
+    g = dict(zip(L["paramnames"], L["grads0"]))
+    out.update({
+        "w/raypos": L["_raypos"], "w/raydir": L["_raydir"], "w/tminmax": L["_tminmax"],
+        "w/stepsize": torch.tensor(L["_stepsize"]), "w/fade": torch.tensor([6.5, 7.5]),
+        "w/leaf_template": L["_template"].detach(), "w/leaf_warp": L["_warp"].detach(),
+        "w/leaf_primpos": L["_primpos"].detach(), "w/leaf_primrot": L["_primrot"].detach(),
+        "w/leaf_primscale": L["_primscale"].detach(), "w/rayrgba": L["sample0"].detach(),
+        "w/grad_template": g["template"], "w/grad_warp": g["warp"], "w/grad_primpos": g["primpos"],
+        "w/grad_primrot": g["primrot"], "w/grad_primscale": g["primscale"],
+    })
+    print("w alpha range", float(L["sample0"][..., 3].min()), float(L["sample0"][..., 3].max()))
     path = os.path.join(HERE, "mvp_golden.npz")
     np.savez_compressed(path, **{k: v.detach().cpu().numpy().astype(np.float32) for k, v in out.items()})
     print("wrote", path, os.path.getsize(path))

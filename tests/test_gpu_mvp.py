@@ -145,6 +145,60 @@ def test_mvp_far_from_the_origin_with_a_small_step():
         assert e < 5e-3, (k, e)
 
 
+def test_mvp_warp_fields_match_reference_golden():
+    """algo 1: the reference fixture with dowarp=True (mvpraymarch.py:790-803) -- image and all five leaf gradients."""
+    from goliath_amd import mvp
+
+    G = load("mvp_golden.npz")
+    leaf = {k: G[f"w/leaf_{k}"].cuda().requires_grad_(True) for k in ("template", "warp", "primpos", "primrot", "primscale")}
+    template = F.softplus(leaf["template"] * 1.5).permute(0, 1, 3, 4, 5, 2).contiguous()
+    warp = leaf["warp"].permute(0, 1, 3, 4, 5, 2).contiguous()
+    fs, fe = (float(v) for v in G["w/fade"])
+    out = mvp.mvpraymarch(G["w/raypos"].cuda(), G["w/raydir"].cuda(), float(G["w/stepsize"]), G["w/tminmax"].cuda(),
+                          (leaf["primpos"] * 0.3, leaf["primrot"].contiguous(), torch.exp(0.1 * leaf["primscale"])),
+                          template, warp, algo=1, fadescale=fs, fadeexp=fe, accum=0)
+    assert rel_l2(out, G["w/rayrgba"]) < 1e-4, rel_l2(out, G["w/rayrgba"])
+    out.backward(torch.ones_like(out))
+    for k in leaf:
+        e = rel_l2(leaf[k].grad, G[f"w/grad_{k}"])
+        assert e < 3e-4, (k, e)
+
+
+@pytest.mark.parametrize("N,H,W,K,T,WT,amp", [(2, 70, 50, 64, (4, 8, 8), (3, 4, 5), 0.05), (1, 33, 17, 27, (3, 5, 6), (2, 2, 2), 0.6)])
+def test_mvp_warp_fields_vs_oracle_with_shadow(N, H, W, K, T, WT, amp):
+    """Warp fields far from the identity (amp 0.6: warped positions leave the box, corners drop out one by one, some samples
+    have no corner at all), non-cubic warp grids, shadow splatting at the warped position."""
+    from goliath_amd import mvp
+    from oracle import cref
+
+    case = _random_case(N, H, W, K, T, seed=K + 7)
+    g = torch.Generator().manual_seed(99)
+    lin = [torch.linspace(-1, 1, n) for n in WT]
+    grid = torch.stack(torch.meshgrid(*lin, indexing="ij")[::-1], -1)  # [WD,WH,WW,3] = (x, y, z) of the cell
+    warp = (grid[None, None] + amp * torch.randn(N, K, *WT, 3, generator=g)).contiguous()
+    c = lambda t: t.cuda().contiguous()
+    rp, rd, tm = mvp.compute_raydirs(c(case["viewpos"]), c(case["viewrot"]), c(case["focal"]), c(case["princpt"]),
+                                     (W, H), 1.0)
+    leaf = {k: c(case[k]).requires_grad_(True) for k in ("primpos", "primrot", "primscale", "template")}
+    leaf["warp"] = c(warp).requires_grad_(True)
+    out, shadow = mvp.mvpraymarch(rp, rd, case["step"], tm, (leaf["primpos"], leaf["primrot"], leaf["primscale"]),
+                                  leaf["template"], leaf["warp"], algo=1, fadescale=6.5, fadeexp=7.5, with_shadow=True)
+    ref, raysat, ref_shadow = cref.mvp_forward(rp.cpu(), rd.cpu(), case["step"], tm.cpu(), case["primpos"],
+                                               case["primrot"], case["primscale"], case["template"], 6.5, 7.5,
+                                               with_shadow=True, warp=warp)
+    assert float(ref[..., 3].max()) > 0.2
+    assert rel_l2(out, ref) < 1e-4, rel_l2(out, ref)
+    ref_sh = ref_shadow[..., 0:1] / (ref_shadow[..., 1:] + 1e-5)
+    assert rel_l2(shadow, ref_sh) < 1e-3
+    go = torch.randn(out.shape, generator=torch.Generator().manual_seed(1))
+    out.backward(go.cuda())
+    gp, gr, gs, gt, gw = cref.mvp_backward(rp.cpu(), rd.cpu(), case["step"], tm.cpu(), case["primpos"], case["primrot"],
+                                           case["primscale"], case["template"], raysat, go, 6.5, 7.5, warp=warp)
+    for k, gref in (("primpos", gp), ("primrot", gr), ("primscale", gs), ("template", gt), ("warp", gw)):
+        e = rel_l2(leaf[k].grad, gref)
+        assert e < 3e-4, (k, e)
+
+
 def test_raymarcher_wrapper_and_errors():
     from goliath_amd import mvp
 
@@ -157,9 +211,11 @@ def test_raymarcher_wrapper_and_errors():
                primrgba=c(case["template"]), valid_prims=(torch.arange(8) % 2 == 0).cuda())
     rgb, alpha, rgba, shadow = rm(rp, rd, tm, dec, renderoptions={"fadescale": 6.5, "fadeexp": 7.5, "bogus": 1})
     assert rgb.shape == (1, 3, 32, 32) and alpha.shape == (1, 1, 32, 32) and shadow is None
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(NotImplementedError):  # a warp field needs algo=1 (and algo 1 a warp field)
         mvp.mvpraymarch(rp, rd, 0.05, tm, (dec["primpos"], dec["primrot"], dec["primscale"]), dec["primrgba"],
                         torch.zeros(1, 8, 2, 2, 2, 3).cuda())
+    with pytest.raises(NotImplementedError):
+        mvp.mvpraymarch(rp, rd, 0.05, tm, (dec["primpos"], dec["primrot"], dec["primscale"]), dec["primrgba"], None, algo=1)
     with pytest.raises(RuntimeError):  # CPU tensors
         mvp.mvpraymarch(rp.cpu(), rd.cpu(), 0.05, tm.cpu(), (case["primpos"], case["primrot"], case["primscale"]),
                         case["template"], None)

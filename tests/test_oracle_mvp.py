@@ -47,6 +47,32 @@ def test_mvp_oracle_reproduces_reference(tag):
         assert e < 2e-4, (k, e)
 
 
+def test_mvp_oracle_with_warp_field_reproduces_reference():
+    """algo 1 (mvpraymarch.py:790-803): the reference's PyTorch fixture with dowarp=True -- rgba and all five leaf gradients."""
+    G = load("mvp_golden.npz")
+    leaf, template, primpos, primrot, primscale = mvp_case(G, "w")
+    warp_leaf = G["w/leaf_warp"].clone().requires_grad_(True)
+    warp = warp_leaf.permute(0, 1, 3, 4, 5, 2).contiguous()  # chlast, mvpraymarch.py:686
+    fs, fe = (float(v) for v in G["w/fade"])
+    step = float(G["w/stepsize"])
+    rgba, raysat, _ = cref.mvp_forward(G["w/raypos"], G["w/raydir"], step, G["w/tminmax"], primpos, primrot, primscale,
+                                       template, fs, fe, warp=warp)
+    assert rel_l2(rgba, G["w/rayrgba"]) < 1e-5, rel_l2(rgba, G["w/rayrgba"])
+    # the warp matters: without it the image differs
+    rgba0, _, _ = cref.mvp_forward(G["w/raypos"], G["w/raydir"], step, G["w/tminmax"], primpos, primrot, primscale,
+                                   template, fs, fe)
+    assert rel_l2(rgba0, G["w/rayrgba"]) > 1e-4
+    gp, gr, gs, gt, gw = cref.mvp_backward(G["w/raypos"], G["w/raydir"], step, G["w/tminmax"], primpos, primrot, primscale,
+                                           template, raysat, torch.ones_like(rgba), fs, fe, warp=warp)
+    ((template * gt).sum() + (primpos * gp).sum() + (primrot * gr).sum() + (primscale * gs).sum()
+     + (warp * gw).sum()).backward()
+    for k in ("template", "primpos", "primrot", "primscale"):
+        e = rel_l2(leaf[k].grad, G[f"w/grad_{k}"])
+        assert e < 2e-4, (k, e)
+    e = rel_l2(warp_leaf.grad, G["w/grad_warp"])
+    assert e < 2e-4, ("warp", e)
+
+
 def test_raydirs_oracle_reproduces_reference():
     G = load("raydirs_golden.npz")
     rp, rd, tm = cref.compute_raydirs(G["viewpos"], G["viewrot"], G["focal"], G["princpt"], G["pixelcoords"], 1.0)
