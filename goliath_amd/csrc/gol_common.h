@@ -51,13 +51,32 @@ __device__ __forceinline__ float gol_dpp_mov0(float v) {
       float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, BANK_MASK, false));
 }
 
+// v + (v shifted right by 8 lanes inside its row of 16, 0 shifted in) as ONE v_add_f32_dpp.  Written as assembly: when
+// only lane 15 of a row consumes the result the compiler sinks the add into the consumer's branch and leaves a
+// v_mov 0 + v_mov_dpp + v_add triple behind (the DPP combiner works inside one basic block).  The s_nop covers the
+// two wait states a DPP read needs after a VALU write of its source (the hazard recognizer does not look into asm).
+__device__ __forceinline__ float gol_add_row_shr8(float v) {
+  float r;
+  asm("s_nop 1\n\tv_add_f32_dpp %0, %1, %1 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=v"(r) : "v"(v));
+  return r;
+}
+// rows 1 and 3 add lane 15 of the row before them / rows 2 and 3 add lane 31 (the last two steps of a 64-lane sum):
+// one v_add_f32_dpp each (masked-off rows keep their value) instead of v_mov 0 + v_mov_dpp + v_add
+__device__ __forceinline__ float gol_add_row_bcast15(float v) {
+  asm("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf" : "+v"(v));
+  return v;
+}
+__device__ __forceinline__ float gol_add_row_bcast31(float v) {
+  asm("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf" : "+v"(v));
+  return v;
+}
+
 // sums of the four 16-lane rows, valid in lanes 15, 31, 47, 63 (4 fused v_add_f32_dpp)
 __device__ __forceinline__ float gol_row_sum_to_lane15(float v) {
   v += gol_dpp_mov0<0x111>(v);  // row_shr:1
   v += gol_dpp_mov0<0x112>(v);  // row_shr:2
   v += gol_dpp_mov0<0x114>(v);  // row_shr:4
-  v += gol_dpp_mov0<0x118>(v);  // row_shr:8
-  return v;
+  return gol_add_row_shr8(v);   // row_shr:8
 }
 
 // Four wave-wide sums for the price of ~1.5: gfx950's v_permlane32_swap / v_permlane16_swap fold
@@ -98,10 +117,9 @@ __device__ __forceinline__ float gol_wave_sum_to_lane63(float v) {
   v += gol_dpp_mov0<0x111>(v);              // row_shr:1
   v += gol_dpp_mov0<0x112>(v);              // row_shr:2
   v += gol_dpp_mov0<0x114>(v);              // row_shr:4  (lanes 4..15 of a row now hold 8-sums..)
-  v += gol_dpp_mov0<0x118>(v);              // row_shr:8  -> lane 15 of each row = row sum
-  v += gol_dpp_mov0<0x142, 0xa>(v);         // row_bcast:15 into rows 1 and 3
-  v += gol_dpp_mov0<0x143, 0xc>(v);         // row_bcast:31 into rows 2 and 3
-  return v;
+  v = gol_add_row_shr8(v);                  // row_shr:8  -> lane 15 of each row = row sum
+  v = gol_add_row_bcast15(v);               // row_bcast:15 into rows 1 and 3
+  return gol_add_row_bcast31(v);            // row_bcast:31 into rows 2 and 3
 }
 
 __device__ __forceinline__ float gol_readlane63(float v) {

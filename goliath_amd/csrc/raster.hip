@@ -91,6 +91,9 @@ __device__ __forceinline__ int half_mask(float gx, float gy, float ca, float cb,
 }
 
 // stage one list entry: four 16-byte loads from the Gaussian's 64-byte record
+// LDS row of a staged list entry: a = (x, y, conic a', conic b'), b = (conic c', opacity, r, g), c = (b, extra)
+struct __attribute__((aligned(16))) StagedRow { float4 a, b; float2 c; float2 pad; };
+
 struct Staged { float4 a, b; float2 c; int mask; };
 __device__ __forceinline__ Staged stage_entry(const float* __restrict__ records, size_t g, float tile_x0, float tile_y0) {
   const float4* R = reinterpret_cast<const float4*>(records + g * GOL_SPLAT_RECORD);
@@ -123,6 +126,8 @@ __global__ __launch_bounds__(128) void raster_fwd_kernel(
     const float* __restrict__ l1_target, const float* __restrict__ l1_mask, int l1_mask_c,
     uint8_t* __restrict__ l1_sign, float* __restrict__ l1_partial) {
   __shared__ float s_l1[2];
+  // (separate arrays: the 48-byte rows of the backward kernel, which save it an address register move per visit, cost the
+  // forward 3-5 % -- measured side by side on one box, profiles/r03g_raster_ab.txt)
   __shared__ float4 s_a[kBatch];  // x, y, conic.a, conic.b
   __shared__ float4 s_b[kBatch];  // conic.c, opacity, r, g
   __shared__ float2 s_c[kBatch];  // b, extra
@@ -317,9 +322,7 @@ __global__ __launch_bounds__(128) void raster_bwd_kernel(
     float* __restrict__ v_colors, float* __restrict__ v_extra, float* __restrict__ v_opacity,
     const uint8_t* __restrict__ v_sign, const float* __restrict__ v_sign_mask, int v_sign_mask_c,
     const float* __restrict__ v_img_scale) {
-  __shared__ float4 s_a[kBatchB];
-  __shared__ float4 s_b[kBatchB];
-  __shared__ float2 s_c[kBatchB];
+  __shared__ StagedRow s_e[kBatchB];  // one 48-byte row per entry: the reads of a visit share their address register
   __shared__ int32_t s_mask[kBatchB];
   __shared__ int32_t s_id[kBatchB];
   __shared__ __attribute__((aligned(16))) float s_acc[2][kBatchB][kAcc];
@@ -395,7 +398,7 @@ __global__ __launch_bounds__(128) void raster_bwd_kernel(
       if (tid < batch_size) {
         const int gid = ids[batch_end - tid];
         const Staged st = stage_entry(records, goff + (size_t)gid, (float)(tc.tx * 16), (float)(tc.ty * 16));
-        s_a[tid] = st.a; s_b[tid] = st.b; s_c[tid] = st.c; s_mask[tid] = st.mask;
+        s_e[tid].a = st.a; s_e[tid].b = st.b; s_e[tid].c = st.c; s_mask[tid] = st.mask;
         s_id[tid] = gid;
       } else {
         s_mask[tid] = 0;
@@ -410,9 +413,9 @@ __global__ __launch_bounds__(128) void raster_bwd_kernel(
     while (bits) {
       const int t = __builtin_ctzll(bits);
       bits &= bits - 1;
-      const float4 a4 = s_a[t];
-      const float4 b4 = s_b[t];
-      const float2 c2 = s_c[t];
+      const float4 a4 = s_e[t].a;
+      const float4 b4 = s_e[t].b;
+      const float2 c2 = s_e[t].c;
       const int li = batch_end - t;
       const float dx = a4.x - px;
       const f2 dy = a4.y - py;
@@ -489,8 +492,8 @@ __global__ __launch_bounds__(128) void raster_bwd_kernel(
         if (!(t0w || t1w) || c > (EXTRA ? 9 : 8)) continue;
         // component c = w1 * S[k1] + w2 * S[k2] of the wave-summed slots S; slots 4..8 hold moments of gop:
         // v_sigma-sums = -opacity * moment (conic back from its log2e scaling with ln 2)
-        const float4 a4 = s_a[t];
-        const float4 b4 = s_b[t];
+        const float4 a4 = s_e[t].a;
+        const float4 b4 = s_e[t].b;
         const float nop = -b4.y, cc = b4.x;
         const int k1 = (c == 5) ? 4 : c, k2 = 5;
         const float w1 = (c == 4) ? nop * a4.z * kUnA : (c == 5) ? nop * a4.w * kUnB : (c == 6 || c == 8) ? 0.5f * nop
@@ -518,8 +521,8 @@ __global__ __launch_bounds__(128) void raster_bwd_kernel(
       }
       if (any) {
         const size_t g = goff + (size_t)s_id[tid];
-        const float4 a4 = s_a[tid];
-        const float4 b4 = s_b[tid];
+        const float4 a4 = s_e[tid].a;
+        const float4 b4 = s_e[tid].b;
         const float nop = -b4.y;  // slots 4..8 are moments of gop: v_sigma-sums = -opacity * moment
         const float ca = a4.z * kUnA, cb = a4.w * kUnB, cc = b4.x * kUnA;
         atomicAdd(v_colors + 3 * g, a[0]); atomicAdd(v_colors + 3 * g + 1, a[1]); atomicAdd(v_colors + 3 * g + 2, a[2]);
