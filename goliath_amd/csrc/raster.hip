@@ -130,7 +130,9 @@ __global__ __launch_bounds__(128) void raster_fwd_kernel(
   // forward 3-5 % -- measured side by side on one box, profiles/r03g_raster_ab.txt)
   __shared__ float4 s_a[kBatch];  // x, y, conic.a, conic.b
   __shared__ float4 s_b[kBatch];  // conic.c, opacity, r, g
-  __shared__ float2 s_c[kBatch];  // b, extra
+  __shared__ float2 s_c[kBatch];  // b, extra  (an 8-byte stride on purpose: with a 16-byte one the compiler issues all
+                                  // three reads of a visit at the loop top from one address register, and the forward
+                                  // runs 3-4 % slower -- profiles/r03g_raster_ab.txt)
   __shared__ int32_t s_mask[kBatch];  // half mask
   const int T = tiles_x * tiles_y;
   const TileCoord tc = tile_of_block(blockIdx.x, T, tiles_x);
@@ -389,6 +391,7 @@ __global__ __launch_bounds__(128) void raster_bwd_kernel(
   const int bmax = min(max(s_wmax[0], s_wmax[1]), range.y - 1);
   if (bmax < range.x) return;
 
+  float* acc_lane = &s_acc[wave][0][lane >> 4];  // this lane's column (lanes 15, 31, 47, 63 hold sums 0..3 / 4..7)
   const int n_batches = (bmax - range.x + kBatchB) / kBatchB;
   for (int bb = 0; bb < n_batches; ++bb) {
     __syncthreads();
@@ -453,12 +456,12 @@ __global__ __launch_bounds__(128) void raster_bwd_kernel(
       if (EXTRA) w += c2.y * vo3;
       const f2 v_alpha = T_new * w + ra * (tail - q);
       q += fac * w;
-      const f2 g0v = fac * vo0, g1v = fac * vo1, g2v = fac * vo2;
+      // colour gradients of the two pixels, summed: one multiply + one scalar FMA each (written on scalars: from the
+      // 2-vector form the compiler builds v_mul + v_pk_fma and throws the packed op's upper half away)
+      const float g0s = __builtin_fmaf(fac.x, vo0.x, fac.y * vo0.y), g1s = __builtin_fmaf(fac.x, vo1.x, fac.y * vo1.y),
+                  g2s = __builtin_fmaf(fac.x, vo2.x, fac.y * vo2.y);
       float g3 = 0.f;
-      if (EXTRA) {
-        const f2 g3v = fac * vo3;
-        g3 = g3v.x + g3v.y;
-      }
+      if (EXTRA) g3 = __builtin_fmaf(fac.x, vo3.x, fac.y * vo3.y);
       // d loss / d sigma per pixel is -opacity * gop; the (wave-uniform) factor -opacity is applied once per Gaussian in
       // the merge step: the lanes reduce the moments of gop itself, whose zeroth moment IS v_opacity
       f2 gop = vis * v_alpha;
@@ -469,15 +472,16 @@ __global__ __launch_bounds__(128) void raster_bwd_kernel(
       const f2 gyy = gy * dy;
       const float myy = gyy.x + gyy.y;
       const float mx = m0 * dx, mxx = mx * dx, mxy = my * dx;
-      const float r0 = gol_wave_sum4(g0v.x + g0v.y, g1v.x + g1v.y, g2v.x + g2v.y, m0);
+      const float r0 = gol_wave_sum4(g0s, g1s, g2s, m0);
       const float r1 = gol_wave_sum4(mx, my, mxx, mxy);
       // the 9th (and 10th) sum: a 6-instruction DPP ladder each (total in lane 63) instead of a third 4-way reduction
       const float r2 = gol_wave_sum_to_lane63(myy);
       const float r3 = EXTRA ? gol_wave_sum_to_lane63(g3) : 0.f;
       if ((lane & 15) == 15) {
-        float* a = &s_acc[wave][t][lane >> 4];
+        // slot row t of this wave + a 32-bit byte offset (plain pointer arithmetic on the int t becomes a v_mad_u64_u32)
+        float* a = gol_at(acc_lane, (unsigned)t * (unsigned)(kAcc * sizeof(float)));
         a[0] = r0; a[4] = r1;
-        if (lane == 63) { s_acc[wave][t][8] = r2; s_acc[wave][t][9] = r3; }
+        if (lane == 63) { a[8 - 3] = r2; a[9 - 3] = r3; }  // (lane 63's base points at slot 3)
         s_touched[wave][t] = 1;
       }
     }
