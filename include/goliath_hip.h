@@ -470,7 +470,9 @@ int gol_imgtail_bwd(int B, int H, int W, const float* rgb, const float* alpha, c
  *   bary_img[B,3,H,W] (may be NULL): perspective-correct barycentrics of the sample.
  * Conventions (drtk's source is not in the reference tree): sample at the pixel centre (j + 0.5, i + 0.5); coverage =
  * all edge functions >= 0, either winding; faces with a vertex at z <= 0 are skipped; depth ties -> lower face index.
- * workspace: gol_mesh_raster_workspace_bytes(B, F) bytes of device scratch.
+ * workspace: gol_mesh_raster_workspace_bytes(B, F) bytes of device scratch (face records, packed tile bounds, the
+ * per-view tile boxes and their in-box tile prefix).  The images are cleared by a streaming fill; only tiles inside a
+ * view's mesh box are rasterized, by a fixed grid of workgroups that strides over them.
  * ---------------------------------------------------------------------------------------- */
 int64_t gol_mesh_raster_workspace_bytes(int B, int F);
 int gol_mesh_raster(int B, int V, int F, int H, int W, const float* v_pix, const int32_t* vi, int32_t* index_img,
