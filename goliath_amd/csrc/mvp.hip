@@ -650,19 +650,19 @@ __global__ __launch_bounds__(256) void march_bwd_kernel(MarchArgs a, const float
           const bool mine = evs && (cellkey == key);
           const unsigned long long grp = gol_ballot(mine);
           todo &= ~grp;
-          // always reduce (even a one-lane group): memory-side atomics, not instructions, are the cost.  The two
-          // x-neighbour corners of a pair are adjacent 16-byte voxel records, so lanes 14|15 of every DPP row issue them
-          // together: one request covers both corners whenever they share a cache line.
+          // always reduce (even a one-lane group).  The group's lanes are selected ONCE, on the four sample gradients
+          // (the corner weights stay unmasked), and lanes 15, 31, 47, 63 -- which hold the four channel sums of a corner --
+          // issue that corner's atomics themselves: moving the second corner of a pair to lanes 14, 30, .. so that one
+          // instruction covers both cost six vector instructions per pair for one atomic instruction saved
+          // (profiles/r03g_mvp_bwd_probes.txt: all device atomics of this kernel together are 0.3 of its 11.4 ms).
+          const float m0 = mine ? sd0 : 0.f, m1 = mine ? sd1 : 0.f, m2 = mine ? sd2 : 0.f, m3 = mine ? sd3 : 0.f;
 #pragma unroll
-          for (int c = 0; c < 8; c += 2) {
-            const int i0 = __builtin_amdgcn_readlane(q.idx[c], leader), i1 = __builtin_amdgcn_readlane(q.idx[c + 1], leader);
-            if (i0 < 0 && i1 < 0) continue;
-            const float w0 = mine ? q.w[c] : 0.f, w1 = mine ? q.w[c + 1] : 0.f;
-            const float ra = gol_wave_sum4(w0 * sd0, w0 * sd1, w0 * sd2, w0 * sd3);   // lanes 15, 31, 47, 63
-            const float rb = gol_dpp_mov0<0x101>(gol_wave_sum4(w1 * sd0, w1 * sd1, w1 * sd2, w1 * sd3));  // row_shl:1 -> 14, 30, ..
-            const int l15 = lane & 15;
-            const int idx = (l15 == 15) ? i0 : i1;
-            if (l15 >= 14 && idx >= 0) atomicAdd(gol_at(gt, (unsigned)idx * 16u + (unsigned)(lane >> 4) * 4u), (l15 == 15) ? ra : rb);
+          for (int c = 0; c < 8; ++c) {
+            // (no branch around a missing corner -- only at the box border: the eight reduction chains stay in one basic
+            // block and the scheduler interleaves them; the kernel is bound by their dependent latency, not by issue)
+            const int ic = __builtin_amdgcn_readlane(q.idx[c], leader);
+            const float rc = gol_wave_sum4(q.w[c] * m0, q.w[c] * m1, q.w[c] * m2, q.w[c] * m3);   // lanes 15, 31, 47, 63
+            if ((lane & 15) == 15 && ic >= 0) atomicAdd(gol_at(gt, (unsigned)ic * 16u + (unsigned)(lane >> 4) * 4u), rc);
           }
         }
       }
