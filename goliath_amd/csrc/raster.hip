@@ -202,6 +202,7 @@ __global__ __launch_bounds__(128) void raster_fwd_kernel(
         // contributes: !(sigma < 0 || alpha < 1/255), as scalar lane masks (ballots of the plain compares)
         const unsigned long long mc0 = gol_ballot(!(sigma.x < 0.f)) & gol_ballot(!(alpha.x < GOL_ALPHA_FLOOR));
         const unsigned long long mc1 = gol_ballot(!(sigma.y < 0.f)) & gol_ballot(!(alpha.y < GOL_ALPHA_FLOOR));
+        // (an early-out for visits without a taker, as the backward has it, does not pay here: 602-612 vs 613 us)
         f2 vis = alpha * T_cur;
 #ifndef GOL_EXACT_MATH
         const f2 next_T = T_cur - vis;  // = T (1 - alpha)
