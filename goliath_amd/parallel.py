@@ -15,7 +15,7 @@ of the hot path, so the multi-GPU scheme is:
     ca_code/utils/train.py:189-204, global grad norm for clip_grad_norm_ :214) are all-reduced so
     every rank takes the same branch (`sync_mean`).
 """
-from typing import Iterable, List, Sequence
+from typing import Iterable, List
 
 import torch
 import torch.distributed as dist

@@ -18,7 +18,6 @@ Both are installed by `goliath_amd.dropin.patch_urhand()` / `patch_hand_teacher(
 `compute_tbn_uv_given_normal`, `xyz2normals`, `tile2d`, `index`, `build_cam_rot_mat`) are looked up in the module that
 defines the decoder class -- for the reference that is ca_code.models.urhand / hand_teacher_mvp themselves.
 """
-import math
 import sys
 from typing import Optional
 
