@@ -28,8 +28,9 @@ namespace {
 constexpr int kBatch = 256;
 // conics are staged in LDS pre-multiplied by log2(e) -- alpha = opacity * 2^(-sigma') is one v_exp_f32 with a negated
 // operand instead of a multiply + exp per pixel -- and the diagonal terms by the 1/2 of sigma = (a dx^2 + c dy^2) / 2 +
-// b dx dy as well; kUnA / kUnB bring the true conic back where the backward needs it
-constexpr float kScA = GOL_SC_A, kScB = GOL_SC_B, kUnA = GOL_UN_A, kUnB = GOL_UN_B;
+// b dx dy as well (GOL_SC_A / GOL_SC_B, applied where the records are written); kUnA / kUnB bring the true conic back
+// where the backward needs it
+constexpr float kUnA = GOL_UN_A, kUnB = GOL_UN_B;
 #ifdef GOL_EXACT_MATH
 // TEST-ONLY exact-math twin (goliath_amd/build.py, variant "exact"): the conic is staged unscaled, sigma is evaluated in
 // the order the CPU oracle (and gsplat) writes it -- 0.5 (a dx^2 + c dy^2) + b dx dy, every product and sum rounded
