@@ -656,13 +656,21 @@ __global__ __launch_bounds__(256) void march_bwd_kernel(MarchArgs a, const float
           // instruction covers both cost six vector instructions per pair for one atomic instruction saved
           // (profiles/r03g_mvp_bwd_probes.txt: all device atomics of this kernel together are 0.3 of its 11.4 ms).
           const float m0 = mine ? sd0 : 0.f, m1 = mine ? sd1 : 0.f, m2 = mine ? sd2 : 0.f, m3 = mine ? sd3 : 0.f;
+          // phase 1: the eight corners' reduction chains in ONE basic block (the scheduler interleaves them; with the
+          // atomic's exec-mask region after every corner they ran one after the other, each a ~60-cycle dependent chain)
+          float rc[8];
+          int ic[8];
 #pragma unroll
           for (int c = 0; c < 8; ++c) {
-            // (no branch around a missing corner -- only at the box border: the eight reduction chains stay in one basic
-            // block and the scheduler interleaves them; the kernel is bound by their dependent latency, not by issue)
-            const int ic = __builtin_amdgcn_readlane(q.idx[c], leader);
-            const float rc = gol_wave_sum4(q.w[c] * m0, q.w[c] * m1, q.w[c] * m2, q.w[c] * m3);   // lanes 15, 31, 47, 63
-            if ((lane & 15) == 15 && ic >= 0) atomicAdd(gol_at(gt, (unsigned)ic * 16u + (unsigned)(lane >> 4) * 4u), rc);
+            ic[c] = __builtin_amdgcn_readlane(q.idx[c], leader);
+            rc[c] = gol_wave_sum4(q.w[c] * m0, q.w[c] * m1, q.w[c] * m2, q.w[c] * m3);   // lanes 15, 31, 47, 63
+          }
+          // phase 2: one exec-mask region, the (wave-uniform) validity of a corner is a scalar branch inside it
+          if ((lane & 15) == 15) {
+            float* gl = gol_at(gt, (unsigned)(lane >> 4) * 4u);
+#pragma unroll
+            for (int c = 0; c < 8; ++c)
+              if (ic[c] >= 0) atomicAdd(gol_at(gl, (unsigned)ic[c] * 16u), rc[c]);
           }
         }
       }
