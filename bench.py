@@ -810,8 +810,6 @@ def main():
             run_step(t, cfg, world)
             drain()
         D.barrier()
-    if graph is None and on_gpu:
-        _lib.TIMING = []
     # the K timed steps are ONE region (barrier + synchronize on both sides); events recorded between up to five windows
     # of it give the spread without adding a sync
     plan = _window_plan(args.steps)
@@ -837,22 +835,24 @@ def main():
         D.barrier()
         exchange_ms = 1e3 * D.max_over_ranks(time.perf_counter() - te) / args.steps
     timing = []
-    if on_gpu:
+    if on_gpu and not args.stub:
         if graph is not None:
             splat.PLANNER.check_frozen()  # raises if a replayed render overflowed its intersection capacity
             splat.PLANNER.frozen = False
-            # HIP events cannot bracket nodes inside a captured graph: the per-call durations come from an eager,
-            # instrumented pass of the same K steps right after the timed replays (same buffers, same streams)
-            # (the micro-batches are issued on ONE stream here, so a call's events bracket that kernel sequence alone and the
-            # durations agree with rocprofv3's per-kernel trace; with two streams in flight they would include time-sharing)
-            streams, t["streams"] = t["streams"], [torch.cuda.current_stream()] * len(t["streams"])
-            _lib.TIMING = []
-            sync_keep, t["_sync"] = t["_sync"], None   # compute only
-            for _ in range(args.steps):
-                run_step(t, cfg, world)
-            t["_sync"] = sync_keep
-            D.barrier()
-            t["streams"] = streams
+        # The timed region runs UN-instrumented (graph replays, or the eager composite calls an unmodified training loop
+        # issues).  The per-call durations come from an eager, instrumented pass of the same K steps right after it (same
+        # buffers; HIP events cannot bracket nodes inside a captured graph, and the per-stage calls the events need are not
+        # what the product path issues).  The micro-batches go on ONE stream here, so a call's events bracket that kernel
+        # sequence alone and the durations agree with rocprofv3's per-kernel trace; with two streams in flight they would
+        # include time-sharing.
+        streams, t["streams"] = t["streams"], [torch.cuda.current_stream()] * len(t["streams"])
+        _lib.TIMING = []
+        sync_keep, t["_sync"] = t.get("_sync"), None   # compute only
+        for _ in range(args.steps):
+            run_step(t, cfg, world)
+        t["_sync"] = sync_keep
+        D.barrier()
+        t["streams"] = streams
         timing, _lib.TIMING = _lib.TIMING, None
         splat.PLANNER.poll(block=True)  # raises if any step overflowed its intersection capacity
     dt = D.max_over_ranks(dt)
@@ -925,8 +925,8 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": dict({"workload": cfg["workload"], "gaussians": N, "image": [cfg["height"], cfg["width"]],
                             "views_per_gpu": B, "micro_batches": args.micro,
-                            "launch": "eager" if graph is None else "hip_graph_replay (kernels_ms_per_call / roofline: "
-                                                                     "eager instrumented pass after the timed replays)",
+                            "launch": ("eager composite calls" if graph is None else "hip_graph_replay") +
+                                      " (kernels_ms_per_call / roofline: eager instrumented pass after the timed region)",
                             "relight": "envmap_4mips",
                             "slab_layout": "uv-coherent" if args.coherent_uv else "random permutation",
                             "normal_offsets": "smooth (decoder-like)" if args.smooth_normals else "white noise (SURVEY 8d)",

@@ -147,11 +147,16 @@ __global__ __launch_bounds__(256) void project_bwd_kernel(
     const float* __restrict__ v_depth, const float* __restrict__ v_conic,
     const float* __restrict__ v_compensation, const float* __restrict__ opacities,
     const float* __restrict__ v_opac_eff, int gs, float* __restrict__ v_mean3d, float* __restrict__ v_scale,
-    float* __restrict__ v_quat, float* __restrict__ v_opacity) {
+    float* __restrict__ v_quat, float* __restrict__ v_opacity, const float* __restrict__ v_rgb_rec,
+    float* __restrict__ v_colors_out) {
   const int b = blockIdx.y;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= N) return;
   const size_t e = (size_t)b * N + i;
+  if (v_colors_out) {  // the colour gradient out of the record (same cache line as the fields read below) as a dense [B,N,3]
+    const float* r = v_rgb_rec + e * gs;
+    v_colors_out[3 * e] = r[0]; v_colors_out[3 * e + 1] = r[1]; v_colors_out[3 * e + 2] = r[2];
+  }
   // upstream gradients: dense arrays (gs == 0) or fields of per-Gaussian records of gs floats (rasterize_bwd)
   const size_t e1 = gs ? e * gs : e, e2 = gs ? e * gs : 2 * e, e3 = gs ? e * gs : 3 * e;
   float vm[3] = {0, 0, 0}, vs[3] = {0, 0, 0}, vq[4] = {0, 0, 0, 0}, vo = 0.f;
@@ -286,6 +291,29 @@ extern "C" int gol_project_fwd(int B, int N, const float* means3d, const float* 
   return GOL_OK;
 }
 
+static int project_bwd_launch(int B, int N, const float* means3d, const float* scales, float glob_scale,
+                              const float* quats, const float* viewmats, const float* intrins,
+                              const float* cov3d, const int32_t* radii, const float* conics,
+                              const float* compensation, const float* v_xy, const float* v_depth,
+                              const float* v_conic, const float* v_compensation, const float* opacities,
+                              const float* v_opac_eff, int grad_stride, float* v_mean3d, float* v_scale,
+                              float* v_quat, float* v_opacity, const float* v_rgb_rec, float* v_colors_out, void* stream) {
+  GOL_REQUIRE(B >= 0 && N >= 0, "negative size");
+  GOL_REQUIRE(grad_stride >= 0, "negative grad_stride");
+  if (B == 0 || N == 0) return GOL_OK;
+  GOL_REQUIRE(means3d && scales && quats && viewmats && intrins && radii && conics && compensation, "null input");
+  GOL_REQUIRE(v_mean3d && v_scale && v_quat, "null output");
+  GOL_REQUIRE(!opacities || v_opacity, "v_opacity must be given with opacities");
+  GOL_REQUIRE(B <= 65535, "B > 65535");
+  dim3 grid(gol_cdiv(N, 256), B);
+  project_bwd_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(
+      N, means3d, scales, glob_scale, quats, viewmats, intrins, cov3d, radii, conics, compensation, v_xy,
+      v_depth, v_conic, v_compensation, opacities, v_opac_eff, grad_stride, v_mean3d, v_scale, v_quat, v_opacity,
+      v_rgb_rec, v_colors_out);
+  GOL_CHECK_LAUNCH();
+  return GOL_OK;
+}
+
 extern "C" int gol_project_bwd(int B, int N, const float* means3d, const float* scales, float glob_scale,
                                const float* quats, const float* viewmats, const float* intrins,
                                const float* cov3d, const int32_t* radii, const float* conics,
@@ -293,17 +321,19 @@ extern "C" int gol_project_bwd(int B, int N, const float* means3d, const float* 
                                const float* v_conic, const float* v_compensation, const float* opacities,
                                const float* v_opac_eff, int grad_stride, float* v_mean3d, float* v_scale,
                                float* v_quat, float* v_opacity, void* stream) {
-  GOL_REQUIRE(B >= 0 && N >= 0, "negative size");
-  GOL_REQUIRE(grad_stride >= 0, "negative grad_stride");
-  if (B == 0 || N == 0) return GOL_OK;
-  GOL_REQUIRE(means3d && scales && quats && viewmats && intrins && radii && conics && compensation, "null input");
-  GOL_REQUIRE(v_mean3d && v_scale && v_quat, "null output");
-  GOL_REQUIRE((v_opacity == nullptr) || (opacities != nullptr), "v_opacity needs opacities");
-  GOL_REQUIRE(B <= 65535, "B > 65535");
-  dim3 grid(gol_cdiv(N, 256), B);
-  project_bwd_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(
-      N, means3d, scales, glob_scale, quats, viewmats, intrins, cov3d, radii, conics, compensation, v_xy,
-      v_depth, v_conic, v_compensation, opacities, v_opac_eff, grad_stride, v_mean3d, v_scale, v_quat, v_opacity);
-  GOL_CHECK_LAUNCH();
-  return GOL_OK;
+  return project_bwd_launch(B, N, means3d, scales, glob_scale, quats, viewmats, intrins, cov3d, radii, conics, compensation,
+                            v_xy, v_depth, v_conic, v_compensation, opacities, v_opac_eff, grad_stride, v_mean3d, v_scale,
+                            v_quat, v_opacity, nullptr, nullptr, stream);
+}
+
+extern "C" int gol_project_bwd_records(int B, int N, const float* means3d, const float* scales, float glob_scale,
+                                       const float* quats, const float* viewmats, const float* intrins,
+                                       const int32_t* radii, const float* conics, const float* compensation,
+                                       const float* opacities, const float* grad_records, int with_depth, float* v_mean3d,
+                                       float* v_scale, float* v_quat, float* v_opacity, float* v_colors, void* stream) {
+  GOL_REQUIRE(grad_records != nullptr, "null gradient records");
+  const float* g = grad_records;
+  return project_bwd_launch(B, N, means3d, scales, glob_scale, quats, viewmats, intrins, nullptr, radii, conics, compensation,
+                            g + 4, with_depth ? g + 9 : nullptr, g + 6, nullptr, opacities, g + 3, GOL_GRAD_RECORD, v_mean3d,
+                            v_scale, v_quat, v_opacity, v_colors ? g : nullptr, v_colors, stream);
 }

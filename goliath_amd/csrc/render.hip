@@ -80,7 +80,7 @@ extern "C" int gol_render_bwd(int B, int N, int img_h, int img_w, float glob_sca
                               const gol_render_ws* L, const float* v_img, const float* v_depth, const float* v_alpha,
                               int use_l1_sign, const float* l1_mask, int l1_mask_c, const float* v_img_scale,
                               float* grad_records, float* v_mean, float* v_scale, float* v_quat, float* v_opacity,
-                              void* stream) {
+                              float* v_colors, void* stream) {
   GOL_REQUIRE(workspace != nullptr && L != nullptr && grad_records != nullptr, "null workspace / layout / gradient records");
   GOL_REQUIRE(!use_l1_sign || L->l1_sign >= 0, "layout was computed without the fused L1");
   if (B == 0 || N == 0) return GOL_OK;
@@ -100,8 +100,7 @@ extern "C" int gol_render_bwd(int B, int N, int img_h, int img_w, float glob_sca
                              use_l1_sign ? at<uint8_t>(ws, L->l1_sign) : nullptr, use_l1_sign ? l1_mask : nullptr,
                              use_l1_sign ? l1_mask_c : 0, v_img_scale, stream);
   if (rc != GOL_OK) return rc;
-  return gol_project_bwd(B, N, means, scales, glob_scale, quats, viewmats, intrins, nullptr,
-                         at<int32_t>(ws, L->radii), at<float>(ws, L->conics), at<float>(ws, L->comp), g + 4,
-                         use_depth ? g + 9 : nullptr, g + 6, nullptr, opacity, g + 3, GOL_GRAD_RECORD, v_mean, v_scale,
-                         v_quat, v_opacity, stream);
+  return gol_project_bwd_records(B, N, means, scales, glob_scale, quats, viewmats, intrins, at<int32_t>(ws, L->radii),
+                                 at<float>(ws, L->conics), at<float>(ws, L->comp), opacity, g, use_depth ? 1 : 0, v_mean,
+                                 v_scale, v_quat, v_opacity, v_colors, stream);
 }

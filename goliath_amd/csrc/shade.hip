@@ -658,6 +658,15 @@ __global__ __launch_bounds__(256) void shade_bwd_kernel(const gol_shade_in in, c
 }
 
 // [B,3,h,w] planar -> [B,h,w,16] footprint records (see bilinear_border), one lane per record
+// out[i] = sum over the B views of in[b][i]  (the per-view albedo gradients -> the shared parameter's)
+__global__ __launch_bounds__(256) void sum_views_kernel(int B, size_t M, const float* __restrict__ in, float* __restrict__ out) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= M) return;
+  float acc = 0.f;
+  for (int b = 0; b < B; ++b) acc += in[(size_t)b * M + i];
+  out[i] = acc;
+}
+
 __global__ __launch_bounds__(256) void envmap_pack_kernel(int h, int w, const float* __restrict__ src, float4* __restrict__ dst) {
   const int b = blockIdx.y, hw = h * w;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -764,5 +773,10 @@ extern "C" int gol_shade_bwd(const gol_shade_in* in, const gol_shade_out* saved,
   else if (rnd) GOL_SHADE_BWD_CASE(false, true);
   else GOL_SHADE_BWD_CASE(false, false);
   GOL_CHECK_LAUNCH();
+  if (gin->albedo) {  // gradient of the albedo shared by the views = sum over B of the per-view gradients
+    const size_t M = (size_t)in->N * 3;
+    sum_views_kernel<<<gol_cdiv((long long)M, 256), 256, 0, s>>>(in->B, M, gin->albedo_per_view, gin->albedo);
+    GOL_CHECK_LAUNCH();
+  }
   return GOL_OK;
 }

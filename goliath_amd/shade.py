@@ -45,7 +45,8 @@ class ShadeOutGrad(ctypes.Structure):
 
 
 class ShadeInGrad(ctypes.Structure):
-    _fields_ = [("f_vnocond", _fp), ("f_vcond", _fp), ("postex", _fp), ("tn", _fp), ("albedo_per_view", _fp)]
+    _fields_ = [("f_vnocond", _fp), ("f_vcond", _fp), ("postex", _fp), ("tn", _fp), ("albedo_per_view", _fp),
+                ("albedo", _fp)]
 
 
 def _p(t, dtype=torch.float32):
@@ -171,10 +172,14 @@ class _Shade(torch.autograd.Function):
         gin = ShadeInGrad()
         gin.f_vnocond, gin.f_vcond, gin.postex, gin.tn = _p(g_vn), _p(g_vc), _p(g_pt), _p(g_tn)
         gin.albedo_per_view = _p(g_alb)
+        # the shared albedo's gradient = the sum of the per-view ones, by a second small kernel of the same call
+        g_albedo = torch.empty(N, 3, device=dev) if ctx.needs_input_grad[4] else None
+        gin.albedo = _p(g_albedo)
         with _lib.device_guard(dev):
             _lib.call("gol_shade_bwd", ctypes.byref(sin), ctypes.byref(saved), ctypes.byref(up), ctypes.byref(gin),
                       stream_ptr())
-        g_albedo = g_alb.sum(0).reshape(albedo.shape) if ctx.needs_input_grad[4] else None
+        if g_albedo is not None:
+            g_albedo = g_albedo.reshape(albedo.shape)
         return (g_vn, g_vc, g_pt, g_tn, g_albedo) + (None,) * (9 + n_mips)
 
 

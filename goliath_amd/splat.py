@@ -546,15 +546,16 @@ class _RenderViews(torch.autograd.Function):
                                    background, ctx.capacity, ws, L, v_img_c, v_depth_c, v_alpha_c, v_l1 is not None,
                                    use_mask, v_scale, rec, v_mean, v_scale_g, v_quat, v_opacity)
             return (v_mean, v_scale_g, v_quat, v_opacity, rec[..., :3]) + (None,) * 14
+        v_color = torch.empty(B, N, 3, device=dev)  # dense copy of the records' colour gradient (written by the projection backward)
         with _lib.device_guard(dev):
             _lib.call("gol_render_bwd", c_int(B), c_int(N), c_int(img_h), c_int(img_w), c_float(glob_scale), fptr(means),
                       fptr(scales), fptr(quats), fptr(opacity), fptr(viewmats), fptr(intrins), fptr(background),
                       c_i64(ctx.capacity), ctypes.c_void_p(ws.data_ptr()), ctypes.byref(L), fptr(v_img_c),
                       fptr(v_depth_c), fptr(v_alpha_c), c_int(1 if v_l1 is not None else 0), fptr(use_mask),
                       c_int(0 if use_mask is None else use_mask.shape[1]), fptr(v_scale), fptr(rec), fptr(v_mean),
-                      fptr(v_scale_g), fptr(v_quat), fptr(v_opacity), stream_ptr())
+                      fptr(v_scale_g), fptr(v_quat), fptr(v_opacity), fptr(v_color), stream_ptr())
         # (the workspace stays alive with the node: retain_graph / a second backward re-reads the tile lists)
-        return (v_mean, v_scale_g, v_quat, v_opacity, rec[..., :3]) + (None,) * 14
+        return (v_mean, v_scale_g, v_quat, v_opacity, v_color) + (None,) * 14
 
 
 class _LazyRender(dict):

@@ -89,6 +89,15 @@ int gol_project_bwd(int B, int N, const float* means3d, const float* scales, flo
                     const float* v_conic, const float* v_compensation, const float* opacities,
                     const float* v_opac_eff, int grad_stride, float* v_mean3d, float* v_scale, float* v_quat,
                     float* v_opacity, void* stream);
+/* The same with its upstream gradients taken from the rasterizer's per-Gaussian gradient records (grad_records
+ * [B,N,GOL_GRAD_RECORD]: rgb | opacity | xy | conic a b c | depth | pad, gol_rasterize_bwd) and cov3d recomputed; v_colors
+ * [B,N,3] (may be NULL) additionally receives the records' colour gradient as a dense array -- the consumer (the shading
+ * tail's backward) then reads 12 contiguous bytes per Gaussian instead of a strided view of the records. */
+int gol_project_bwd_records(int B, int N, const float* means3d, const float* scales, float glob_scale,
+                            const float* quats, const float* viewmats, const float* intrins, const int32_t* radii,
+                            const float* conics, const float* compensation, const float* opacities,
+                            const float* grad_records, int with_depth, float* v_mean3d, float* v_scale, float* v_quat,
+                            float* v_opacity, float* v_colors, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Tile binning + per-tile depth sort.  Replaces gsplat: cumsum + map_gaussian_to_intersects +
@@ -182,7 +191,8 @@ int gol_rasterize_bwd(int B, int N, int img_h, int img_w, int block, int planar,
  *   and optionally out_depth[B,H,W] (NULL = skip); l1_target / l1_mask / l1_partial[B,T] as for gol_rasterize_fwd.
  *   bwd: v_img[B,3,H,W] / v_depth[B,H,W] (w.r.t. the UN-normalised depth image) / v_alpha[B,H,W] may be NULL;
  *   use_l1_sign != 0 adds the fused L1's gradient (v_img_scale = device scalar d loss / d l1 / (B*3*H*W));
- *   grad_records[B,N,GOL_GRAD_RECORD] scratch + output: d loss / d colour = its first three floats per Gaussian.
+ *   grad_records[B,N,GOL_GRAD_RECORD] scratch; v_colors[B,N,3] (may be NULL): d loss / d colour as a dense array (it is
+ *   also the first three floats of every record).
  * ---------------------------------------------------------------------------------------- */
 typedef struct gol_render_ws {
   int64_t cov3d, xys, depths, radii, conics, comp, nth, opac_eff, records, tile_count, tile_bins, keys, sorted_ids,
@@ -200,7 +210,7 @@ int gol_render_bwd(int B, int N, int img_h, int img_w, float glob_scale, const f
                    const float* background, int64_t capacity, void* workspace, const gol_render_ws* layout,
                    const float* v_img, const float* v_depth, const float* v_alpha, int use_l1_sign, const float* l1_mask,
                    int l1_mask_c, const float* v_img_scale, float* grad_records, float* v_mean, float* v_scale,
-                   float* v_quat, float* v_opacity, void* stream);
+                   float* v_quat, float* v_opacity, float* v_colors, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Fused RGCA shading tail.  Replaces the chain of ATen kernels in PrimDecoder.forward after the
@@ -272,6 +282,7 @@ typedef struct {  /* written in full */
   float* postex;           /* [B, 3, N] */
   float* tn;               /* [B, 3, N] */
   float* albedo_per_view;  /* [B, N, 3]  (sum over B = gradient of the shared albedo) */
+  float* albedo;           /* [N, 3] or NULL: that sum, written by a second small kernel of the same call */
 } gol_shade_in_grad;
 
 /* src[B,3,h,w] (the layout of EnvSpinDecorator's mip pyramid, light_decorator.py:100-140) ->

@@ -15,7 +15,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CALLS = {  # kernel-name prefix -> ABI call
-    "shade_fwd_kernel": "gol_shade_fwd", "shade_bwd_kernel": "gol_shade_bwd", "project_fwd_kernel": "gol_project_fwd",
+    "shade_fwd_kernel": "gol_shade_fwd", "shade_bwd_kernel": "gol_shade_bwd", "sum_views_kernel": "gol_shade_bwd", "project_fwd_kernel": "gol_project_fwd",
     "project_bwd_kernel": "gol_project_bwd", "count_lds_kernel": "gol_bin_sort", "count_kernel": "gol_bin_sort",
     "scan_kernel": "gol_bin_sort", "scatter_lds_kernel": "gol_bin_sort", "scatter_kernel": "gol_bin_sort",
     "sort_kernel": "gol_bin_sort", "sort_queue_kernel": "gol_bin_sort", "bin_": "gol_bin_sort",
