@@ -204,8 +204,8 @@ def algorithmic_bytes(name, N, I, P, n_mips_bytes):
         # effective opacity 4, raster record 64
         "gol_project_fwd": 56 * N + 100 * N,
         # in: means / scales / quats / opacity 44, radius 4, conic 12, compensation 4, the Gaussian's gradient record 64;
-        # out: gradients of means / scales / quats / opacity 44
-        "gol_project_bwd": 128 * N + 44 * N,
+        # out: gradients of means / scales / quats / opacity 44 + the dense colour gradient 12
+        "gol_project_bwd": 128 * N + 56 * N,
         # count pass 28 N (xy, radius, conic, opacity), scatter pass 2 x 28 N + depth 4 N; keys 8 I written + 8 I read, ids 4 I
         "gol_bin_sort": 88 * N + 8 * I + 8 * I + 4 * I,
         # per entry: id 4 + record 64; per pixel: final_T, final_idx, rgb, alpha, depth_norm written (28 B) + fused L1:
