@@ -44,6 +44,29 @@ CFG = dict(workload="rgca_config2_envrelight", gaussians=250_000, slab=500, heig
            views_per_gpu=8, focal=3000.0, cam_radius_mm=700.0, n_mips=4, seed=1234)
 
 
+
+# The contract is ONE JSON line on stdout.  Libraries write there too (RCCL prints a five-line version banner through C
+# stdio when its first communicator comes up, flushed at exit, i.e. AFTER the JSON line): once this process knows it is a
+# worker (not the self-spawning launcher), file descriptor 1 is pointed at stderr and the line goes to the saved descriptor.
+_REAL_STDOUT = None
+
+
+def _claim_stdout():
+    global _REAL_STDOUT
+    if _REAL_STDOUT is None:
+        sys.stdout.flush()
+        _REAL_STDOUT = os.dup(1)
+        os.dup2(2, 1)
+
+
+def emit(obj):
+    line = (json.dumps(obj) + "\n").encode()
+    if _REAL_STDOUT is None:
+        sys.stdout.write(line.decode()); sys.stdout.flush()
+    else:
+        sys.stdout.flush()
+        os.write(_REAL_STDOUT, line)
+
 def make_inputs(cfg, device, rank=0):
     """SURVEY.md 8d config-2 synthetic inputs (decoder-output surrogates + cameras + env map)."""
     g = torch.Generator().manual_seed(cfg["seed"] + 1000 * rank)
@@ -398,12 +421,12 @@ def _secondary_line(metric, unit, units_per_step, args, dt, ms, alg, config, win
     if dom in SECONDARY_VALU:
         v = _valu_roofline(rec, SECONDARY_VALU[dom], ms[dom])
         roof = dict(v, kernel=dom, traffic=None, hbm={k: hbm[k] for k in ("achieved", "peak", "unit", "frac")})
-    print(json.dumps({
+    emit({
         "metric": metric, "value": units_per_step * args.steps / dt, "unit": unit, "n_gpus": 1, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic", "config": config, "kernels_ms_per_call": ms,
         "algorithmic_GBs_per_call": {k: alg[k] / (ms[k] * 1e-3) / 1e9 for k in ms if k in alg},
-        "roofline": roof, "windows": windows}), flush=True)
+        "roofline": roof, "windows": windows})
 
 
 URHAND_CFG = dict(workload="urhand_config4_uvlight", uv=1024, lights=32, frames_per_gpu=1, seed=4)
@@ -679,7 +702,7 @@ def e2e_main(args):
             res["segments_ms"] = {"decoder_fwd" if not args.fused_tail else "decoder_trunk_fwd": seg[0] / args.steps,
                                   "tail_render_loss_and_all_backward": seg[1] / args.steps,
                                   "grad_sync_and_adam": seg[2] / args.steps}
-        print(json.dumps(res), flush=True)
+        emit(res)
     if world > 1:
         import torch.distributed as dist
 
@@ -737,6 +760,7 @@ def main():
     rc = launch.maybe_spawn(args.gpus)
     if rc is not None:
         sys.exit(rc)
+    _claim_stdout()  # a worker from here on: stdout carries the one JSON line and nothing else
     if args.workload != "rgca":
         return {"mvp": mvp_main, "urhand": urhand_main, "sg": sg_main, "e2e": e2e_main}[args.workload](args)
     cfg = dict(CFG, views_per_gpu=args.views, coherent_uv=bool(args.coherent_uv), smooth_normals=bool(args.smooth_normals))
@@ -878,11 +902,11 @@ def main():
                    "reduce-scatter + all-gather inside the step (serial)"),
                "grad_exchange_ms_alone": exchange_ms}
         if args.stub:
-            print(json.dumps({"metric": "STUB launcher self-test (no kernels ran; not a measurement)", "value": views / dt,
+            emit({"metric": "STUB launcher self-test (no kernels ran; not a measurement)", "value": views / dt,
                               "unit": "stub steps x views/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                               "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
                               "vs_baseline": None, "dtype": "f32", "data": "stub", "config": dict(par, workload="stub"),
-                              "stub_gradients_averaged": stub_ok}), flush=True)
+                              "stub_gradients_averaged": stub_ok})
             D.shutdown()
             if stub_ok is False:
                 sys.exit(3)
@@ -942,7 +966,7 @@ def main():
                            "measurement")
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(cfg)
-        print(json.dumps(res), flush=True)
+        emit(res)
     D.shutdown()
 
 
