@@ -19,8 +19,10 @@ def _run(args, env=None, timeout=300):
 
 
 def _json_line(stdout):
-    lines = [l for l in stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1, stdout
+    # the contract: ONE JSON line on stdout and NOTHING else -- a driver may take the last line (RCCL's version banner,
+    # written through C stdio and flushed at exit, used to follow the JSON: the workers now point fd 1 at stderr)
+    lines = [l for l in stdout.splitlines() if l.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{"), stdout
     return json.loads(lines[0])
 
 
@@ -48,6 +50,21 @@ def test_gpus_2_without_gpus_fails_loudly():
     assert r.returncode != 0
     assert not [l for l in r.stdout.splitlines() if l.startswith("{")], r.stdout
     assert "no GPU visible" in r.stderr or "needs" in r.stderr, r.stderr[-2000:]
+
+
+def test_library_chatter_on_stdout_does_not_reach_the_json_stream():
+    """A worker's fd 1 is stderr: whatever a library writes to C stdout (RCCL's banner) lands there, not before or after
+    the line.  PYTHONSTARTUP-free simulation: the stub run with a site hook that writes to fd 1 at interpreter exit."""
+    import tempfile
+
+    with tempfile.TemporaryDirectory() as d:
+        with open(os.path.join(d, "sitecustomize.py"), "w") as f:
+            f.write("import atexit, os\natexit.register(lambda: os.write(1, b'RCCL version : banner\\n'))\n")
+        e = dict(os.environ, PYTHONPATH=d + os.pathsep + os.environ.get("PYTHONPATH", ""))
+        r = _run(["--stub", "--steps", "2", "--warmup", "1"], env=e)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert _json_line(r.stdout)["data"] == "stub"
+    assert "RCCL version : banner" in r.stderr
 
 
 def test_world_size_mismatch_is_an_error():
