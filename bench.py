@@ -421,18 +421,18 @@ def _secondary_line(metric, unit, units_per_step, args, dt, ms, alg, config, win
     if dom in SECONDARY_VALU:
         v = _valu_roofline(rec, SECONDARY_VALU[dom], ms[dom])
         roof = dict(v, kernel=dom, traffic=None, hbm={k: hbm[k] for k in ("achieved", "peak", "unit", "frac")})
-    emit({
+    return {
         "metric": metric, "value": units_per_step * args.steps / dt, "unit": unit, "n_gpus": 1, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic", "config": config, "kernels_ms_per_call": ms,
         "algorithmic_GBs_per_call": {k: alg[k] / (ms[k] * 1e-3) / 1e9 for k in ms if k in alg},
-        "roofline": roof, "windows": windows})
+        "roofline": roof, "windows": windows}
 
 
 URHAND_CFG = dict(workload="urhand_config4_uvlight", uv=1024, lights=32, frames_per_gpu=1, seed=4)
 
 
-def urhand_main(args):
+def urhand_main(args, emit_line=True):
     """Secondary workload (BASELINE config 4): URHand UV light loops, S=1024, L=32 point lights on a
     1100 mm sphere, B=1: per-light mesh depth render (the drtk call of shadowmap.py:39-50; synthetic closed mesh of 5120
     faces, no dataset) + shadow-map PCF (shadowmap.py:30-96) + Phong features (urhand.py:419-445) + GGX shading
@@ -500,16 +500,19 @@ def urhand_main(args):
            "gol_shadow_pcf": 24 * T + sh + 9 * 4 * L * T,  # texels + shadow out + 9 nearest depth taps per light
            "gol_uvlight_phong_fwd": sh + 24 * T + 16 * T, "gol_uvlight_phong_bwd": sh + 24 * T + 16 * T + 24 * T,
            "gol_uvlight_ggx_fwd": sh + 40 * T + 28 * T, "gol_uvlight_ggx_bwd": sh + 40 * T + 28 * T + 40 * T}
-    _secondary_line("URHand UV light-loop frames/sec (Phong + GGX, fwd+bwd), 1024x1024 texels x 32 lights",
+    res = _secondary_line("URHand UV light-loop frames/sec (Phong + GGX, fwd+bwd), 1024x1024 texels x 32 lights",
                     "frames/s", B, args, dt, ms, alg,
                     {"workload": cfg["workload"], "uv": [S, S], "lights": L, "frames_per_gpu": B,
                      "shadow_depth_render": "32 x 1024^2 mesh z-buffer renders of a 5120-face closed mesh per frame"}, windows=win)
+    if emit_line:
+        emit(res)
+    return res
 
 
 SG_CFG = dict(workload="sgutils_native", gaussians=1_048_576, views=8, lights=8, seed=7)
 
 
-def sg_main(args):
+def sg_main(args, emit_line=True):
     """Secondary workload: sgutils evaluate_gaussian fwd+bwd at the reference-native N=1,048,576 Gaussians,
     B=8 views, 8 point lights per view (sgutils.py:17-98; SURVEY 8d sgutils bytes)."""
     from goliath_amd import sg
@@ -535,11 +538,14 @@ def sg_main(args):
 
     _, dt, ms, win = _time_steps(step, args)
     alg = {"gol_sg_eval_fwd": 40 * B * N, "gol_sg_eval_bwd": 56 * B * N}
-    _secondary_line("sgutils evaluate_gaussian Gaussians/sec (fwd+bwd), 8 lights", "Gaussians/s", B * N, args, dt, ms, alg,
+    res = _secondary_line("sgutils evaluate_gaussian Gaussians/sec (fwd+bwd), 8 lights", "Gaussians/s", B * N, args, dt, ms, alg,
                     {"workload": cfg["workload"], "gaussians": N, "views": B, "lights": L}, windows=win)
+    if emit_line:
+        emit(res)
+    return res
 
 
-def mvp_main(args):
+def mvp_main(args, emit_line=True):
     """Secondary workload (BASELINE config 5): MVP ray march fwd+bwd, 1 view of 2048x1334 per step."""
     from goliath_amd import _lib, mvp
 
@@ -562,16 +568,19 @@ def mvp_main(args):
     P = H * W
     tpl_bytes = t["template"].numel() * 4
     alg = {"gol_mvp_march_fwd": 32 * P + 28 * P + tpl_bytes, "gol_mvp_march_bwd": 32 * P + 28 * P + 3 * tpl_bytes}
-    _secondary_line("MVP ray-march views/sec (fwd+bwd) at 2048x1334, 4096 primitives", "views/s", 1, args, dt, ms, alg,
+    res = _secondary_line("MVP ray-march views/sec (fwd+bwd) at 2048x1334, 4096 primitives", "views/s", 1, args, dt, ms, alg,
                     {"workload": cfg["workload"], "prims": cfg["prims"], "template": list(cfg["tdim"]),
                      "image": [H, W], "stepsize": 1.0 / 64, "mean_alpha": float(out[..., 3].mean())}, windows=win)
+    if emit_line:
+        emit(res)
+    return res
 
 
 E2E_CFG = dict(workload="rgca_e2e_native_slab1024", slab=1024, height=2048, width=1334, views_per_gpu=8, focal=3000.0,
                cam_radius_mm=700.0, n_mips=4, seed=4321)
 
 
-def e2e_main(args):
+def e2e_main(args, emit_line=True):
     """SURVEY 8d mode B at the reference-native size: 1024^2 = 1,048,576 Gaussians, 8 views of 2048x1334 per
     step, random-init decoder of the reference architecture (goliath_amd.decoder) -> shading tail -> render ->
     L1 + SSIM losses (rgca_example.yml:43-52) -> backward -> Adam step (torch.optim.Adam, lr 5e-4).  Geometry (postex / tn)
@@ -702,15 +711,39 @@ def e2e_main(args):
             res["segments_ms"] = {"decoder_fwd" if not args.fused_tail else "decoder_trunk_fwd": seg[0] / args.steps,
                                   "tail_render_loss_and_all_backward": seg[1] / args.steps,
                                   "grad_sync_and_adam": seg[2] / args.steps}
-        emit(res)
+        # roofline of the longest call of the hot path at this size: algorithmic bytes with the list
+        # entries of the FINAL state of the fit (one extra forward) over the live event time
+        hot = {k: v for k, v in ms.items() if k in ("gol_shade_fwd", "gol_shade_bwd", "gol_project_fwd", "gol_project_bwd",
+                                                    "gol_bin_sort", "gol_rasterize_fwd", "gol_rasterize_bwd")}
+        if hot:
+            with torch.no_grad():
+                f_vn1, f_vc1 = dec(t["embs"], t["campos"])
+                p1 = shade.shading_tail(f_vn1, f_vc1, t["postex"], t["tn"], albedo, t["light_sh"], t["campos"],
+                                        preconv_envmap=t["mips"], lightrot=t["lightrot"])
+                intr = torch.stack([t["K"][:, 0, 0], t["K"][:, 1, 1], t["K"][:, 0, 2], t["K"][:, 1, 2]], -1)
+                o1 = splat.render_views(p1["primpos"], p1["primscale"], p1["primqvec"], p1["opacity"], p1["color"],
+                                        t["Rt"], intr, H, W)
+                bins = o1["tile_bins"]
+                I = float((bins[..., 1] - bins[..., 0]).sum(1).float().mean())
+                del f_vn1, f_vc1, p1, o1, bins
+            res["config"]["intersections_per_view"] = I
+            dom = max(hot, key=hot.get)
+            res["roofline"] = make_roofline(dom, hot[dom], B, N, I, H * W, 0)
+            if res["roofline"].get("bound") == "valu":
+                # the stamped instruction counts belong to the 250k-Gaussian scene: not transferable to this one
+                res["roofline"] = dict(res["roofline"]["hbm"], bound="valu (no PMC record at this size: HBM figures only)",
+                                       kernel=dom, traffic=None)
+        if emit_line:
+            emit(res)
     if world > 1:
         import torch.distributed as dist
 
         dist.barrier()
         dist.destroy_process_group()
+    return res if rank == 0 else None
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1,
                     help="N > 1 without torchrun: this script re-executes itself as N ranks (one per GPU) under "
@@ -718,7 +751,12 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--views", type=int, default=CFG["views_per_gpu"])
+    ap.add_argument("--views", type=int, default=None,
+                    help="views per GPU and step.  Default: BASELINE config 2's batch of 8 views, sharded 8 / N per GPU for "
+                         "N > 1 (config 3: strong scaling); given explicitly (or with --weak) every rank renders that many")
+    ap.add_argument("--weak", action="store_true",
+                    help="N > 1: every rank renders its own 8 views (weak scaling, 8 N views per step) instead of a share "
+                         "of the config-2 batch")
     ap.add_argument("--micro", type=int, default=2, help="micro-batches (HIP streams) per step")
     ap.add_argument("--coherent-uv", action="store_true",
                     help="lay the synthetic Gaussians out over the slab like a UV atlas (slab neighbours = spatial neighbours) "
@@ -730,8 +768,11 @@ def main():
                     help="size of the gradient set exchanged per step besides the albedo map (default: 60 M fp32 = the "
                          "config-3 decoder parameter set when N > 1, 0 when N = 1)")
     ap.add_argument("--serial-exchange", action="store_true",
-                    help="N > 1: wait for the gradient exchange inside the step instead of overlapping it with the next "
-                         "step's compute")
+                    help="N > 1: the gradient exchange is launched and waited for inside the step (the default since "
+                         "round 4: what a synchronous training loop can do)")
+    ap.add_argument("--overlap-exchange", action="store_true",
+                    help="N > 1: time ONLY the variant that overlaps step k's exchange with step k+1's compute (by default "
+                         "it is measured after the serial headline and reported under `overlapped_exchange`)")
     ap.add_argument("--share-gpu", action="store_true",
                     help="functional test mode for a 1-GPU box: the N ranks share the visible GPU(s) and exchange "
                          "gradients over gloo with device tensors (RCCL refuses two ranks on one device); the line says so "
@@ -747,29 +788,41 @@ def main():
                          "cannot be taken inside a graph: they come from an eager pass right after the timed replays")
     ap.add_argument("--workload", choices=["rgca", "mvp", "urhand", "sg", "e2e"], default="rgca",
                     help="rgca = the BASELINE metric (default); mvp = secondary BASELINE config 5 line")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="rgca, N = 1: skip the secondary workloads (one camera per GPU, e2e at 1 M Gaussians, MVP config 5, "
+                         "URHand config 4, the coherent / smooth env-map case) that the default line carries under `secondary`")
     ap.add_argument("--fused-tail", action="store_true", default=True,
                     help="e2e: light-contracted last decoder layers on gol_tail_conv_* (default)")
     ap.add_argument("--unfused-tail", dest="fused_tail", action="store_false",
                     help="e2e: last decoder layers as PyTorch/MIOpen transposed convs + bias adds (the reference's structure)")
     ap.add_argument("--no-ssim", action="store_true", help="e2e: L1 loss only (default: 10*L1 + 0.2*(1-SSIM))")
     ap.add_argument("--segments", action="store_true", help="e2e: also report per-segment times (adds a sync per step)")
-    args = ap.parse_args()
-    from goliath_amd import launch
+    return ap.parse_args(argv)
 
-    # N > 1 asked for and not started by torchrun: become the launcher of N ranks (the driver's own command line)
-    rc = launch.maybe_spawn(args.gpus)
-    if rc is not None:
-        sys.exit(rc)
-    _claim_stdout()  # a worker from here on: stdout carries the one JSON line and nothing else
-    if args.workload != "rgca":
-        return {"mvp": mvp_main, "urhand": urhand_main, "sg": sg_main, "e2e": e2e_main}[args.workload](args)
-    cfg = dict(CFG, views_per_gpu=args.views, coherent_uv=bool(args.coherent_uv), smooth_normals=bool(args.smooth_normals))
-    while args.views % args.micro:  # micro-batches must divide the views of a rank
-        args.micro -= 1
-    try:
-        D = launch.init(args.gpus, share_gpu=args.share_gpu, cpu=args.stub, force_group=args.force_dist)
-    except launch.LaunchError as e:
-        raise SystemExit(f"bench.py: {e}")
+
+CONFIG2_VIEWS = CFG["views_per_gpu"]   # BASELINE configs[1] / [2]: ONE batch of 8 views (config 3 = the same batch, 8 / N per GPU)
+
+
+def plan_views(args, world):
+    """(views per GPU, scaling, workload name) of the rgca line.  N = 1: config 2, 8 views.  N > 1: BASELINE config 3 as
+    written -- the config-2 batch sharded 8 / N views per GPU, one camera per GPU at N = 8 ("strong": the total work is
+    fixed).  --weak (or an explicit --views) keeps that many views on EVERY rank ("weak")."""
+    if args.views is not None:
+        return args.views, "weak", CFG["workload"]
+    if world > 1 and not args.weak:
+        return max(1, CONFIG2_VIEWS // world), "strong", "rgca_config3_viewparallel"
+    return CONFIG2_VIEWS, "weak", CFG["workload"]
+
+
+def run_rgca(args, D, views, scaling, workload, overlap, micro=None, extras=True):
+    """Warm up, capture and time the rgca step for `views` views per rank; returns the result dict (rank 0; None on the
+    other ranks).  overlap: exchange mode for N > 1 (see run_step).  extras: intersection counts, per-call HBM table."""
+    cfg = dict(CFG, workload=workload, views_per_gpu=views, coherent_uv=bool(args.coherent_uv),
+               smooth_normals=bool(args.smooth_normals))
+    micro = args.micro if micro is None else micro
+    micro = max(1, min(micro, views))
+    while views % micro:  # micro-batches must divide the views of a rank
+        micro -= 1
     world, rank, dev = D.world, D.rank, D.device
     on_gpu = dev.type == "cuda"
     from goliath_amd import parallel
@@ -779,7 +832,7 @@ def main():
     else:
         from goliath_amd import _lib, splat
 
-        t = make_step_inputs(cfg, dev, rank, args.micro)
+        t = make_step_inputs(cfg, dev, rank, micro)
 
     # Gradient exchange of the step.  Mode A has a single trainable tensor on the path (the albedo map, 3 MB); BASELINE
     # config 3 specifies the exchange of the 512^2-slab RGCA decoder parameter set (~60 M fp32) every step, so
@@ -791,7 +844,7 @@ def main():
     for p in dec:
         p.grad = torch.zeros_like(p)
     t["_sync"] = parallel.GradSync([t["albedo"]] + dec, single_rank_collectives=args.force_dist) if exchanging else None
-    t["overlap_exchange"] = exchanging and not args.serial_exchange
+    t["overlap_exchange"] = exchanging and overlap
     B, N = cfg["views_per_gpu"], cfg["gaussians"]
     P = cfg["height"] * cfg["width"]
 
@@ -889,28 +942,38 @@ def main():
         # every rank's "gradient" was albedo * (rank + 1): the average is albedo * (world + 1) / 2
         want = t["albedo"].detach() * (world + 1) / 2.0
         stub_ok = bool(torch.allclose(t["albedo"].grad, want, atol=1e-6)) if exchanging else None
-
-    if rank == 0:
-        views = B * world * args.steps
-        par = {"parallelism": f"view-parallel x{world}", "rccl_world_size": world if D.backend == "nccl" else 0,
-               "world_size": world, "dist_backend": D.backend,
-               "ranks_share_gpu": bool(D.shared_gpu),
-               "grad_exchange_bytes_per_step": 4 * (grad_floats + t["albedo"].numel()) if exchanging else 0,
-               "grad_exchange": None if not exchanging else (
-                   "reduce-scatter + all-gather of step k overlapped with the compute of step k+1 (waited before the next "
-                   "launch; the last one inside the timed region)" if t["overlap_exchange"] else
-                   "reduce-scatter + all-gather inside the step (serial)"),
-               "grad_exchange_ms_alone": exchange_ms}
-        if args.stub:
-            emit({"metric": "STUB launcher self-test (no kernels ran; not a measurement)", "value": views / dt,
-                              "unit": "stub steps x views/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-                              "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
-                              "vs_baseline": None, "dtype": "f32", "data": "stub", "config": dict(par, workload="stub"),
-                              "stub_gradients_averaged": stub_ok})
-            D.shutdown()
-            if stub_ok is False:
-                sys.exit(3)
-            return
+    if rank != 0:
+        return None
+    views_total = B * world * args.steps
+    par = {"parallelism": f"view-parallel x{world}", "rccl_world_size": world if D.backend == "nccl" else 0,
+           "world_size": world, "dist_backend": D.backend, "views_per_gpu": B, "views_per_step": B * world,
+           "ranks_share_gpu": bool(D.shared_gpu),
+           "grad_exchange_bytes_per_step": 4 * (grad_floats + t["albedo"].numel()) if exchanging else 0,
+           "grad_exchange": None if not exchanging else (
+               "reduce-scatter + all-gather of step k overlapped with the compute of step k+1 (waited before the next "
+               "launch; the last one inside the timed region)" if t["overlap_exchange"] else
+               "reduce-scatter + all-gather inside the step (serial): launched after the step's backward and waited for "
+               "before the next step starts"),
+           "grad_exchange_ms_alone": exchange_ms}
+    base = {"value": views_total / dt, "unit": "views/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": scaling, "vs_baseline": None}
+    if args.stub:
+        return dict(base, metric="STUB launcher self-test (no kernels ran; not a measurement)", unit="stub steps x views/s",
+                    dtype="f32", data="stub", config=dict(par, workload="stub"), stub_gradients_averaged=stub_ok)
+    res = dict(base, metric="relit views/sec (fwd+bwd) at 2048x1334, 250k Gaussians", dtype="f32", data="synthetic")
+    config = dict({"workload": cfg["workload"], "gaussians": N, "image": [cfg["height"], cfg["width"]],
+                   "micro_batches": micro,
+                   "launch": ("eager composite calls" if graph is None else "hip_graph_replay") +
+                             " (kernels_ms_per_call / roofline: eager instrumented pass after the timed region)",
+                   "relight": "envmap_4mips",
+                   "slab_layout": "uv-coherent" if args.coherent_uv else "random permutation",
+                   "normal_offsets": "smooth (decoder-like)" if args.smooth_normals else "white noise (SURVEY 8d)"}, **par)
+    res["config"] = config
+    res["windows"] = _window_stats(win_ms)
+    res["kernels_ms_per_call"] = kernels_ms
+    views_per_launch = B // micro  # every ABI call processes one micro-batch
+    I = 1.97e6   # stored list entries per view of the default scene (measured below when `extras`)
+    if extras:
         # measured intersection count (determines the raster/sort work)
         with torch.no_grad():
             from goliath_amd import render_gs, shade
@@ -924,14 +987,16 @@ def main():
             # list entries actually stored (n_isect is the RESERVED slot count since round 3: the tight tile boxes)
             bins = out["tile_bins"]
             I = float((bins[..., 1] - bins[..., 0]).sum(1).float().mean())
-            I_reserved = float(out["n_isect"].float().mean())
-            mean_alpha = float(out["alpha"].mean())
+            config["intersections_per_view"] = I
+            config["list_slots_reserved_per_view"] = float(out["n_isect"].float().mean())
+            config["mean_alpha"] = float(out["alpha"].mean())
+            del preds, out, bins
+    if kernels_ms:
         dom = max(kernels_ms, key=kernels_ms.get)
         mip_bytes = sum(m[0].numel() * 4 for m in t["micro"][0]["mips"])
-        views_per_launch = B // args.micro  # every ABI call processes one micro-batch
-        roofline = make_roofline(dom, kernels_ms[dom], views_per_launch, N, I, P, mip_bytes)
+        res["roofline"] = make_roofline(dom, kernels_ms[dom], views_per_launch, N, I, P, mip_bytes)
         # every streaming call beside it: algorithmic GB/s, fraction of the 8 TB/s spec, PMC traffic / algorithmic bytes
-        per_call = {}
+        per = {}
         tr = _stamped("traffic.json")
         for k, ms in kernels_ms.items():
             try:
@@ -939,33 +1004,122 @@ def main():
             except KeyError:
                 continue
             gbs = alg / (ms * 1e-3) / 1e9
-            per_call[k] = {"GBs": round(gbs, 1), "hbm_frac": round(gbs / HBM_PEAK_GBS, 4),
-                           "traffic_over_algorithmic": None if tr is None or k not in tr else
-                           round(tr[k] * views_per_launch / 8.0 / alg, 3)}
-        res = {
-            "metric": "relit views/sec (fwd+bwd) at 2048x1334, 250k Gaussians",
-            "value": views / dt, "unit": "views/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": dict({"workload": cfg["workload"], "gaussians": N, "image": [cfg["height"], cfg["width"]],
-                            "views_per_gpu": B, "micro_batches": args.micro,
-                            "launch": ("eager composite calls" if graph is None else "hip_graph_replay") +
-                                      " (kernels_ms_per_call / roofline: eager instrumented pass after the timed region)",
-                            "relight": "envmap_4mips",
-                            "slab_layout": "uv-coherent" if args.coherent_uv else "random permutation",
-                            "normal_offsets": "smooth (decoder-like)" if args.smooth_normals else "white noise (SURVEY 8d)",
-                            "intersections_per_view": I, "list_slots_reserved_per_view": I_reserved,
-                            "mean_alpha": mean_alpha}, **par),
-            "windows": _window_stats(win_ms),
-            "kernels_ms_per_call": kernels_ms,
-            "roofline": roofline,
-            "hbm_per_call": per_call,
-        }
-        if D.shared_gpu:
-            res["note"] = ("ranks share one GPU and exchange over gloo: a functional run of the N-rank path, NOT a scaling "
-                           "measurement")
+            per[k] = {"GBs": round(gbs, 1), "hbm_frac": round(gbs / HBM_PEAK_GBS, 4),
+                      "traffic_over_algorithmic": None if tr is None or k not in tr else
+                      round(tr[k] * views_per_launch / 8.0 / alg, 3)}
+        res["hbm_per_call"] = per
+    if D.shared_gpu:
+        res["note"] = ("ranks share one GPU and exchange over gloo: a functional run of the N-rank path, NOT a scaling "
+                       "measurement")
+    return res
+
+
+def _release():
+    import gc
+
+    gc.collect()
+    if torch.cuda.is_available():
+        torch.cuda.empty_cache()
+
+
+def _brief(res, keys=("value", "unit", "ms_per_step", "scaling", "kernels_ms_per_call", "roofline", "windows")):
+    """A secondary entry of the main line: the measurement without the boiler-plate fields."""
+    out = {k: res[k] for k in keys if k in res}
+    out["metric"] = res.get("metric")
+    out["config"] = res.get("config")
+    for k in ("loss_first_step", "loss_last_step", "hot_path_ms_per_step", "steps"):
+        if k in res:
+            out[k] = res[k]
+    return out
+
+
+def secondary_workloads(args, D):
+    """The other BASELINE configurations, measured by the SAME default command right after the headline (N = 1) and
+    attached to its line under `secondary` -- each with its own ms_per_step, per-call times and roofline:
+      views1    BASELINE config 3's per-GPU share at N = 8: ONE camera per GPU and step (no second micro-batch to hide a
+                view's small-grid phases behind)
+      e2e       SURVEY 8d mode B at the reference-native 1,048,576 Gaussians: decoder -> fused tail -> render -> L1 + SSIM
+                -> backward -> Adam, >= 60 steps so that the loss is past Adam's first overshoot
+      mvp       BASELINE config 5 (4096 primitives, 2048x1334)
+      urhand    BASELINE config 4 (1024^2 texels x 32 lights, incl. the 32 shadow depth renders)
+      env_coherent_smooth   the headline step on a UV-coherent slab with decoder-like smooth normal offsets: the realistic
+                case for the env-map gathers of shade_fwd (the default layout is the synthetic worst case)"""
+    import copy
+
+    out = {}
+
+    def guarded(name, fn):
+        try:
+            out[name] = fn()
+        except Exception as e:  # a secondary workload must never take the headline down with it
+            print(f"bench.py: secondary workload {name} failed: {type(e).__name__}: {e}", file=sys.stderr)
+            out[name] = {"error": f"{type(e).__name__}: {e}"}
+        _release()
+
+    guarded("views1", lambda: _brief(run_rgca(args, D, 1, "weak", "rgca_config3_one_view_per_gpu", False, micro=1)))
+    a2 = copy.copy(args)
+    a2.coherent_uv = a2.smooth_normals = True
+    guarded("env_coherent_smooth", lambda: _brief(run_rgca(a2, D, CONFIG2_VIEWS, "weak", "rgca_config2_coherent_smooth",
+                                                           False)))
+    guarded("mvp", lambda: _brief(mvp_main(args, emit_line=False)))
+    guarded("urhand", lambda: _brief(urhand_main(args, emit_line=False)))
+    a3 = copy.copy(args)
+    a3.steps, a3.views = max(args.steps, 60), CONFIG2_VIEWS
+    guarded("e2e", lambda: _brief(e2e_main(a3, emit_line=False)))
+    return out
+
+
+def main():
+    args = parse_args()
+    from goliath_amd import launch
+
+    # N > 1 asked for and not started by torchrun: become the launcher of N ranks (the driver's own command line)
+    rc = launch.maybe_spawn(args.gpus)
+    if rc is not None:
+        sys.exit(rc)
+    _claim_stdout()  # a worker from here on: stdout carries the one JSON line and nothing else
+    if args.workload != "rgca":
+        if args.views is None:
+            args.views = CONFIG2_VIEWS
+        return {"mvp": mvp_main, "urhand": urhand_main, "sg": sg_main, "e2e": e2e_main}[args.workload](args)
+    try:
+        D = launch.init(args.gpus, share_gpu=args.share_gpu, cpu=args.stub, force_group=args.force_dist)
+    except launch.LaunchError as e:
+        raise SystemExit(f"bench.py: {e}")
+    world = D.world
+    views, scaling, workload = plan_views(args, world)
+    multi = D.backend != "none"
+    # N > 1: the headline pays the exchange INSIDE the step (what a synchronous training loop can do: the optimizer needs
+    # the averaged gradients before the next forward); the overlapped variant (step k's exchange beside step k+1's
+    # compute) is measured right after it and reported beside it, never as `value`
+    overlap_only = bool(args.overlap_exchange) and not args.serial_exchange
+    res = run_rgca(args, D, views, scaling, workload, overlap=overlap_only)
+    if args.stub:
+        if D.rank == 0:
+            emit(res)
+        D.shutdown()
+        if D.rank == 0 and res.get("stub_gradients_averaged") is False:
+            sys.exit(3)
+        return
+    _release()
+    if multi and not overlap_only and not args.serial_exchange:
+        ov = run_rgca(args, D, views, scaling, workload, overlap=True, extras=False)
+        if D.rank == 0:
+            res["overlapped_exchange"] = {k: ov[k] for k in ("value", "unit", "ms_per_step", "windows")}
+            res["overlapped_exchange"]["grad_exchange"] = ov["config"]["grad_exchange"]
+        _release()
+    if world > 1 and scaling == "strong" and not D.shared_gpu:
+        # the previous rounds' line, for continuity: every rank renders its own 8 views (8 N views per step)
+        wk = run_rgca(args, D, CONFIG2_VIEWS, "weak", CFG["workload"], overlap=overlap_only, extras=False)
+        if D.rank == 0:
+            res["weak"] = {k: wk[k] for k in ("value", "unit", "ms_per_step", "scaling", "windows")}
+            res["weak"]["views_per_gpu"] = CONFIG2_VIEWS
+        _release()
+    if D.rank == 0:
+        if world == 1 and not args.no_secondary and args.views is None and not (args.coherent_uv or args.smooth_normals):
+            res["secondary"] = secondary_workloads(args, D)
         if world == 1 and not args.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(cfg)
+            res["cpu_baseline"] = cpu_baseline(dict(CFG))
         emit(res)
     D.shutdown()
 

@@ -9,7 +9,7 @@ OUT=gpurun_out/$TAG; mkdir -p $OUT
 export TMPDIR=/tmp
 cat .git_head 2>/dev/null > $OUT/head.txt
 python -c "from goliath_amd import build; print(build.source_digest())" > $OUT/csrc_sha16.txt
-M1="python bench.py --micro 1 --no-graph --no-cpu-baseline"
+M1="python bench.py --micro 1 --no-graph --no-cpu-baseline --no-secondary"
 python bench.py > $OUT/bench.json 2> $OUT/bench.err
 $M1 --steps 20 --warmup 3 > $OUT/bench_micro1.json 2>> $OUT/bench.err
 rocprofv3 --kernel-trace --stats -f csv -d $OUT/kt -o kt -- $M1 --steps 10 --warmup 2 > $OUT/kt.log 2>&1

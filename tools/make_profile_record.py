@@ -37,7 +37,7 @@ def main(tag):
         if os.path.exists(os.path.join(src, f)):
             shutil.copy(os.path.join(src, f), os.path.join(dst, f"{tag}_{f}"))
     stamp = {"csrc_sha16": sha, "commit": head, "source": f"profiles/{tag}_pmc_*.csv",
-             "command": "rocprofv3 --pmc <counters> -- python bench.py --micro 1 --no-graph --no-cpu-baseline --steps 3 "
+             "command": "rocprofv3 --pmc <counters> -- python bench.py --micro 1 --no-graph --no-cpu-baseline --no-secondary --steps 3 "
                         "--warmup 1 (8 views per launch; one pass per counter group; mean over the dispatches)"}
     tpath = os.path.join(src, "pmc_traffic.csv")
     if os.path.exists(tpath):

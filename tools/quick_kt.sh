@@ -2,7 +2,7 @@
 # quick kernel-time table of the micro1 bench command:  bash tools/quick_kt.sh TAG [extra bench args]
 TAG=${1:-q}; shift
 OUT=gpurun_out/$TAG; mkdir -p $OUT; export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats -f csv -d $OUT/kt -o kt -- python bench.py --micro 1 --no-graph --no-cpu-baseline --steps 10 --warmup 2 "$@" > $OUT/kt.log 2>&1
+rocprofv3 --kernel-trace --stats -f csv -d $OUT/kt -o kt -- python bench.py --micro 1 --no-graph --no-cpu-baseline --no-secondary --steps 10 --warmup 2 "$@" > $OUT/kt.log 2>&1
 python - "$OUT" <<'PY'
 import csv, sys
 csv.field_size_limit(1 << 30)
