@@ -254,22 +254,34 @@ __global__ __launch_bounds__(256) void scatter_kernel(BinArgs a, int64_t capacit
     }
 }
 
-// pass 2: exclusive scan of the T tile counts of one view (one 1024-thread workgroup per view);
-// writes tile_bins[t] = (start, start): .y is the scatter cursor and ends up as the end offset.
+// pass 2: exclusive scan of the T tile counts of one view (one 1024-thread workgroup per view).
+// Writes tile_bins[t] = (start, start): .y is the scatter cursor and ends up as the end offset.
+// Round 4: ONE pass -- the counts are staged in LDS (coalesced), every thread sums its own run of consecutive tiles, one
+// wave scan + one cross-wave step give the offsets (the 11 strided iterations with three barriers each of rounds 1-3 cost
+// 11.6 us per launch whatever B: one workgroup per view, i.e. a serial phase of every single-view step).
+// Measured and dropped in round 4: a launch order for the rasterizer computed here (per die the same tile rows, longest
+// list first, so that the longest lists start first): no effect on either raster kernel at 1, 2, 4 or 8 views per launch
+// (profiles/r04_raster_tail.txt) -- 2942 of a view's tiles are non-empty and 1050 of them hold more than 896 entries: the
+// long lists are the bulk of the work, not a tail, and a single-view launch lasts exactly as long as its longest list.
+constexpr int kScanLds = 12288;   // tiles of a view staged in LDS by the one-pass scan (48 KB); larger images loop
+
 __global__ __launch_bounds__(1024) void scan_kernel(int T, const int32_t* __restrict__ tile_count,
                                                     int32_t* __restrict__ tile_bins,
                                                     int32_t* __restrict__ n_isect) {
+  __shared__ int32_t s_cnt[kScanLds];
   __shared__ int32_t wave_tot[16];
   __shared__ int32_t carry_s;
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int32_t* cnt = tile_count + (size_t)b * T;
   int2* bins = reinterpret_cast<int2*>(tile_bins) + (size_t)b * T;
-  if (tid == 0) carry_s = 0;
-  __syncthreads();
-  for (int base = 0; base < T; base += 1024) {
-    const int t = base + tid;
-    const int v = t < T ? cnt[t] : 0;
-    int incl = v;
+  const bool staged = T <= kScanLds;
+  if (staged) {
+    for (int t = tid; t < T; t += 1024) s_cnt[t] = cnt[t];
+    __syncthreads();
+    const int per = (T + 1023) >> 10, t0 = tid * per, t1 = min(T, t0 + per);
+    int sum = 0;
+    for (int t = t0; t < t1; ++t) sum += s_cnt[t];
+    int incl = sum;
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
       const int u = __shfl_up(incl, off, 64);
@@ -277,23 +289,51 @@ __global__ __launch_bounds__(1024) void scan_kernel(int T, const int32_t* __rest
     }
     if (lane == 63) wave_tot[wv] = incl;
     __syncthreads();
-    int wave_off = 0, chunk_tot = 0;
+    int start = incl - sum, total = 0;
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
       const int w = wave_tot[k];
-      if (k < wv) wave_off += w;
-      chunk_tot += w;
+      if (k < wv) start += w;
+      total += w;
     }
-    const int carry = carry_s;
-    if (t < T) {
-      const int start = carry + wave_off + incl - v;
+    for (int t = t0; t < t1; ++t) {
       bins[t] = make_int2(start, start);
+      start += s_cnt[t];
     }
+    if (tid == 0) n_isect[b] = total;
+  } else {
+    if (tid == 0) carry_s = 0;
     __syncthreads();
-    if (tid == 0) carry_s = carry + chunk_tot;
-    __syncthreads();
+    for (int base = 0; base < T; base += 1024) {
+      const int t = base + tid;
+      const int v = t < T ? cnt[t] : 0;
+      int incl = v;
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        const int u = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += u;
+      }
+      if (lane == 63) wave_tot[wv] = incl;
+      __syncthreads();
+      int wave_off = 0, chunk_tot = 0;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) {
+        const int w = wave_tot[k];
+        if (k < wv) wave_off += w;
+        chunk_tot += w;
+      }
+      const int carry = carry_s;
+      if (t < T) {
+        const int start = carry + wave_off + incl - v;
+        bins[t] = make_int2(start, start);
+      }
+      __syncthreads();
+      if (tid == 0) carry_s = carry + chunk_tot;
+      __syncthreads();
+    }
+    if (tid == 0) n_isect[b] = carry_s;
   }
-  if (tid == 0) n_isect[b] = carry_s;
+  __syncthreads();   // (everyone is done with the counts)
   // the counts are consumed: their buffer becomes the view's two queues of long tile lists (sort_kernel); words 0, 1 = lengths
   if (tid < 2 && tid < T) const_cast<int32_t*>(cnt)[tid] = 0;
 }

@@ -20,6 +20,8 @@
 //     (GOL_GRAD_RECORD) the 10 atomics of a Gaussian share a cache line and are issued by 16 adjacent lanes --
 //     the memory-side atomic units, which cost 25 % of the kernel with dense [N,k] arrays, drop out of the profile;
 //   * tile -> workgroup mapping interleaves tile rows over the 8 XCDs (tile_of_block).
+#include <cstdlib>
+
 #include "gol_common.h"
 
 namespace {
@@ -70,25 +72,60 @@ __device__ __forceinline__ TileCoord tile_of_block(int bid, int T, int tiles_x) 
   return tc;
 }
 
+typedef float f1 __attribute__((ext_vector_type(1)));
 typedef float f2 __attribute__((ext_vector_type(2)));
+typedef int i1 __attribute__((ext_vector_type(1)));
 typedef int i2 __attribute__((ext_vector_type(2)));
 
-// 2-bit mask of the 16x8 halves (bit h = rows 8h..8h+7) that the alpha >= 1/255 region of a Gaussian can reach:
-// exact ellipse-vs-rectangle test (minimum of sigma over the half's pixel centres against ln(255*opacity)),
-// conservative only by a rounding margin; degenerate conics -> both.  tau, 1/a, 1/c and the validity flag come from the
+// Wave footprints.  PPL = pixels per lane.
+//   PPL = 2 (the default): 2 waves per 16x16 tile, wave w owns the 16x8 half (rows 8w..8w+7), lane = (x = lane & 15, row
+//           pair lane >> 4) owns two vertically adjacent pixels -- the per-pixel recurrences run on 2-vectors (packed fp32
+//           VALU ops) and the per-Gaussian work of a visit is shared by 128 pixels: the fewest instructions per pixel.
+//   PPL = 1 (round 4, launches of one or two views): 4 waves per tile, wave w owns the 8x8 quadrant (x half w & 1, y half
+//           w >> 1), one pixel per lane.  ~9 % more instructions in total, but a wave's chain through the tile's list -- which
+//           IS the duration of a single-view launch: 2942 non-empty tiles of 670 entries on average and up to 1280 fit on
+//           the chip at once, the launch ends when the longest list does (measured: raster_bwd 227 us for one view, 131 us
+//           per view in an 8-view launch; with every list clipped to 512 entries 130 us) -- is ~0.55x as long: the 8x8
+//           footprint is culled against 21 % more entries and a visit costs ~0.7x the instructions.
+template <int PPL> struct Pix;
+template <> struct Pix<2> { typedef f2 fv; typedef i2 iv; static constexpr int kWaves = 2; };
+template <> struct Pix<1> { typedef f1 fv; typedef i1 iv; static constexpr int kWaves = 4; };
+
+template <int PPL>
+__device__ __forceinline__ void wave_rect(int wave, float tile_x0, float tile_y0, float& x0, float& x1, float& y0, float& y1) {
+  if (PPL == 2) {
+    x0 = tile_x0 + 0.5f; x1 = x0 + 15.f; y0 = tile_y0 + (float)(wave * 8) + 0.5f; y1 = y0 + 7.f;
+  } else {
+    x0 = tile_x0 + (float)((wave & 1) * 8) + 0.5f; x1 = x0 + 7.f; y0 = tile_y0 + (float)((wave >> 1) * 8) + 0.5f; y1 = y0 + 7.f;
+  }
+}
+
+// bit w of the mask = the alpha >= 1/255 region of a Gaussian can reach the footprint of wave w:
+// exact ellipse-vs-rectangle test (minimum of sigma over the footprint's pixel centres against ln(255*opacity)),
+// conservative only by a rounding margin; degenerate conics -> all.  tau, 1/a, 1/c and the validity flag come from the
 // record (gol_common.h: computed once per Gaussian by the projection).
-__device__ __forceinline__ int half_mask(float gx, float gy, float ca, float cb, float cc, float tau, float ia, float ic,
+template <int PPL>
+__device__ __forceinline__ int wave_mask(float gx, float gy, float ca, float cb, float cc, float tau, float ia, float ic,
                                          float exact, float tile_x0, float tile_y0) {
+  constexpr int NW = Pix<PPL>::kWaves;
   if (!(tau >= 0.f)) return 0;  // alpha < 1/255 everywhere (also NaN opacity: skipped by gsplat too)
-  if (exact == 0.f) return 0x3;
+  if (exact == 0.f) return (1 << NW) - 1;
   int m = 0;
 #pragma unroll
-  for (int q = 0; q < 2; ++q) {
-    const float x0 = tile_x0 + 0.5f, y0 = tile_y0 + (float)(q * 8) + 0.5f;
-    const float ms = gol_min_sigma_rect(gx, gy, ca, cb, cc, ia, ic, x0, x0 + 15.f, y0, y0 + 7.f);
+  for (int q = 0; q < NW; ++q) {
+    float x0, x1, y0, y1;
+    wave_rect<PPL>(q, tile_x0, tile_y0, x0, x1, y0, y1);
+    const float ms = gol_min_sigma_rect(gx, gy, ca, cb, cc, ia, ic, x0, x1, y0, y1);
     m |= (ms <= tau) ? (1 << q) : 0;
   }
   return m;
+}
+
+// pixel coordinates of a lane: column j, first row i0 (the lane's PPL pixels are rows i0 .. i0 + PPL - 1)
+template <int PPL>
+__device__ __forceinline__ void lane_pixel(int tx, int ty, int wave, int lane, int& j, int& i0) {
+  if (PPL == 2) { j = tx * 16 + (lane & 15); i0 = ty * 16 + wave * 8 + (lane >> 4) * 2; }
+  else { j = tx * 16 + (wave & 1) * 8 + (lane & 7); i0 = ty * 16 + (wave >> 1) * 8 + (lane >> 3); }
 }
 
 // stage one list entry: four 16-byte loads from the Gaussian's 64-byte record
@@ -96,6 +133,7 @@ __device__ __forceinline__ int half_mask(float gx, float gy, float ca, float cb,
 struct __attribute__((aligned(16))) StagedRow { float4 a, b; float2 c; float2 pad; };
 
 struct Staged { float4 a, b; float2 c; int mask; };
+template <int PPL>
 __device__ __forceinline__ Staged stage_entry(const float* __restrict__ records, size_t g, float tile_x0, float tile_y0) {
   const float4* R = reinterpret_cast<const float4*>(records + g * GOL_SPLAT_RECORD);
   const float4 q0 = R[0], q1 = R[1], q2 = R[2], q3 = R[3];
@@ -103,13 +141,19 @@ __device__ __forceinline__ Staged stage_entry(const float* __restrict__ records,
   s.a = q0;                              // x, y, a', b'
   s.b = q1;                              // c', opacity, r, g
   s.c = make_float2(q2.x, q2.y);         // b, extra
-  s.mask = half_mask(q0.x, q0.y, q0.z * kUnA, q0.w * kUnB, q1.x * kUnA, q2.z, q2.w, q3.x, q3.y, tile_x0, tile_y0);
+  s.mask = wave_mask<PPL>(q0.x, q0.y, q0.z * kUnA, q0.w * kUnB, q1.x * kUnA, q2.z, q2.w, q3.x, q3.y, tile_x0, tile_y0);
   return s;
 }
 
-// Forward.  128-thread workgroup per 16x16 tile: wave w owns the 16x8 half (rows 8w..8w+7) and every lane two
-// vertically adjacent pixels, so the per-pixel recurrence runs on 2-vectors = packed fp32 VALU ops
-// (v_pk_fma/mul/add_f32), half the instructions per pixel of a one-pixel-per-lane loop.
+template <typename V, int P>
+__device__ __forceinline__ bool any_live(const V& live) {
+  unsigned u = 0u;
+#pragma unroll
+  for (int q = 0; q < P; ++q) u |= __float_as_uint(live[q]);
+  return u != 0u;
+}
+
+// Forward.  One workgroup per 16x16 tile (PPL = 2: 128 threads, PPL = 1: 256; see Pix).
 // LAZY (the fused path, planar images): everything that only changes when a pixel STOPS -- its liveness, the index the
 // backward may start from, the "is this half finished" test -- moves out of the per-visit instruction stream into a
 // wave-uniform branch taken only on visits where some pixel of the half stops (a pixel stops once; a visit costs 7 vector
@@ -117,16 +161,19 @@ __device__ __forceinline__ Staged stage_entry(const float* __restrict__ records,
 // the entry it stopped at: stop index - 1, or the end of the list for a pixel that never stopped.  The backward only needs
 // that (entries between the true last contributor and the bound fail its alpha >= 1/255 test again).  !LAZY (the
 // gsplat-compatible operator): gsplat's exact final_idx.
-template <bool EXTRA, bool LAZY>
-__global__ __launch_bounds__(128) void raster_fwd_kernel(
+template <bool EXTRA, bool LAZY, int PPL>
+__global__ __launch_bounds__(64 * Pix<PPL>::kWaves) void raster_fwd_kernel(
     int N, int img_h, int img_w, int planar, int tiles_x, int tiles_y, const int2* __restrict__ tile_bins,
     const int32_t* __restrict__ sorted_ids, int64_t capacity, const float* __restrict__ records,
     const float* __restrict__ background, float* __restrict__ out_img,
     float* __restrict__ out_extra, float* __restrict__ final_Ts, int32_t* __restrict__ final_idx,
     float* __restrict__ out_alpha, float* __restrict__ out_extra_norm, float norm_lo,
     const float* __restrict__ l1_target, const float* __restrict__ l1_mask, int l1_mask_c,
-    uint8_t* __restrict__ l1_sign, float* __restrict__ l1_partial) {
-  __shared__ float s_l1[2];
+    uint8_t* __restrict__ l1_sign, float* __restrict__ l1_partial, int n_views) {
+  typedef typename Pix<PPL>::fv fv;
+  typedef typename Pix<PPL>::iv iv;
+  constexpr int NW = Pix<PPL>::kWaves, NT = 64 * NW;
+  __shared__ float s_l1[NW];
   // (separate arrays: the 48-byte rows of the backward kernel, which save it an address register move per visit, cost the
   // forward 3-5 % -- measured side by side on one box, profiles/r03g_raster_ab.txt)
   __shared__ float4 s_a[kBatch];  // x, y, conic.a, conic.b
@@ -134,38 +181,47 @@ __global__ __launch_bounds__(128) void raster_fwd_kernel(
   __shared__ float2 s_c[kBatch];  // b, extra  (an 8-byte stride on purpose: with a 16-byte one the compiler issues all
                                   // three reads of a visit at the loop top from one address register, and the forward
                                   // runs 3-4 % slower -- profiles/r03g_raster_ab.txt)
-  __shared__ int32_t s_mask[kBatch];  // half mask
+  __shared__ int32_t s_mask[kBatch];  // wave mask
   const int T = tiles_x * tiles_y;
-  const TileCoord tc = tile_of_block(blockIdx.x, T, tiles_x);
+  // workgroup g = slot * B + view (the view is the fastest index: the workgroups of all views of a launch are handed out
+  // together -- the last view's long lists do not start when the others are already done; with B = 8 a view also stays
+  // on one die, with B = 4 on two)
+  const int view = blockIdx.x % n_views, slot = blockIdx.x / n_views;
+  const TileCoord tc = tile_of_block(slot, T, tiles_x);
   if (!tc.ok) return;
-  const int view = blockIdx.y;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int j = tc.tx * 16 + (lane & 15), i0 = tc.ty * 16 + wave * 8 + (lane >> 4) * 2;
-  const bool in0 = (i0 < img_h) && (j < img_w), in1 = (i0 + 1 < img_h) && (j < img_w);
+  int j, i0;
+  lane_pixel<PPL>(tc.tx, tc.ty, wave, lane, j, i0);
+  bool in[PPL];
+  fv py, live;
+#pragma unroll
+  for (int q = 0; q < PPL; ++q) {
+    in[q] = (i0 + q < img_h) && (j < img_w);
+    py[q] = (float)(i0 + q) + 0.5f;
+    // 1 while the pixel still composites, 0 once it stopped (or lies outside the image).  Carried as a FLOAT in a VGPR
+    // and multiplied into alpha: a dead pixel then fails the alpha >= 1/255 test by itself.  As loop-carried booleans the
+    // same state lived in SGPR lane masks and cost ~30 scalar instructions per visit to maintain (PMC: the scalar pipes
+    // of this kernel were as busy as the vector pipes, 76 % / 78 %).
+    live[q] = in[q] ? 1.f : 0.f;
+  }
   const float px = (float)j + 0.5f;
-  const f2 py = {(float)i0 + 0.5f, (float)i0 + 1.5f};
 
   const int2 range = tile_bins[(size_t)view * T + tc.tile];
   const int32_t* ids = sorted_ids + (size_t)view * capacity;
   const size_t goff = (size_t)view * N;
 
-  f2 T_cur = {1.f, 1.f};
-  i2 cur_idx = {0, 0};
-  f2 acc0 = {0.f, 0.f}, acc1 = acc0, acc2 = acc0, acc3 = acc0;
-  // 1 while the pixel still composites, 0 once it stopped (or lies outside the image).  Carried as a FLOAT in a VGPR
-  // and multiplied into alpha: a dead pixel then fails the alpha >= 1/255 test by itself.  As loop-carried booleans the
-  // same state lived in SGPR lane masks and cost ~30 scalar instructions per visit to maintain (PMC: the scalar pipes
-  // of this kernel were as busy as the vector pipes, 76 % / 78 %).
-  f2 live = {in0 ? 1.f : 0.f, in1 ? 1.f : 0.f};
+  fv T_cur = 1.f;
+  iv cur_idx = 0;
+  fv acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
 
   const int n_batches = (range.y - range.x + kBatch - 1) / kBatch;
   for (int bb = 0; bb < n_batches; ++bb) {
-    if (__syncthreads_and((__float_as_uint(live.x) | __float_as_uint(live.y)) == 0u)) break;  // also protects the LDS batch from being overwritten early
+    if (__syncthreads_and(!any_live<fv, PPL>(live))) break;  // also protects the LDS batch from being overwritten early
     const int batch_start = range.x + bb * kBatch;
-    for (int k = tid; k < kBatch; k += 128) {
+    for (int k = tid; k < kBatch; k += NT) {
       const int idx = batch_start + k;
       if (idx < range.y) {
-        const Staged st = stage_entry(records, goff + (size_t)ids[idx], (float)(tc.tx * 16), (float)(tc.ty * 16));
+        const Staged st = stage_entry<PPL>(records, goff + (size_t)ids[idx], (float)(tc.tx * 16), (float)(tc.ty * 16));
         s_a[k] = st.a; s_b[k] = st.b; s_c[k] = st.c; s_mask[k] = st.mask;
       } else {
         s_mask[k] = 0;
@@ -173,13 +229,13 @@ __global__ __launch_bounds__(128) void raster_fwd_kernel(
     }
     __syncthreads();
     const int batch_size = min(kBatch, range.y - batch_start);
-    // Each wave walks ONLY the entries whose alpha >= 1/255 region touches its half: one ballot per
+    // Each wave walks ONLY the entries whose alpha >= 1/255 region touches its footprint: one ballot per
     // 64 entries, then a scalar loop over the set bits (s_ff1) -- culled entries cost nothing.
     for (int chunk = 0; chunk < batch_size; chunk += 64) {
       unsigned long long bits = gol_ballot((s_mask[chunk + lane] >> wave) & 1);
-      if (LAZY && gol_ballot((__float_as_uint(live.x) | __float_as_uint(live.y)) != 0u) == 0ull) break;  // half finished
+      if (LAZY && gol_ballot(any_live<fv, PPL>(live)) == 0ull) break;  // footprint finished
       while (bits) {
-        if (!LAZY && gol_ballot((__float_as_uint(live.x) | __float_as_uint(live.y)) != 0u) == 0ull) { chunk = batch_size; break; }  // this wave's half is finished
+        if (!LAZY && gol_ballot(any_live<fv, PPL>(live)) == 0ull) { chunk = batch_size; break; }  // this wave's footprint is finished
         const int t = chunk + __builtin_ctzll(bits);
         bits &= bits - 1;
         const float4 a4 = s_a[t];
@@ -187,57 +243,71 @@ __global__ __launch_bounds__(128) void raster_fwd_kernel(
         const float2 c2 = s_c[t];
         // branch-free pixel update: selects instead of exec-mask regions (the loop is issue-bound)
         const float dx = a4.x - px;
-        const f2 dy = a4.y - py;
+        const fv dy = a4.y - py;
+        fv sigma, alpha;
 #ifndef GOL_EXACT_MATH
-        const f2 sigma = (a4.z * dx * dx + b4.x * dy * dy) + (a4.w * dx) * dy;  // log2e * gsplat's sigma
-        f2 alpha;
-        alpha.x = fminf(GOL_ALPHA_CAP_FWD, b4.y * __builtin_amdgcn_exp2f(-sigma.x));
-        alpha.y = fminf(GOL_ALPHA_CAP_FWD, b4.y * __builtin_amdgcn_exp2f(-sigma.y));
+        sigma = (a4.z * dx * dx + b4.x * dy * dy) + (a4.w * dx) * dy;  // log2e * gsplat's sigma
+#pragma unroll
+        for (int q = 0; q < PPL; ++q) alpha[q] = fminf(GOL_ALPHA_CAP_FWD, b4.y * __builtin_amdgcn_exp2f(-sigma[q]));
 #else
-        const f2 sigma = {exact_sigma(a4.z, a4.w, b4.x, dx, dy.x), exact_sigma(a4.z, a4.w, b4.x, dx, dy.y)};
-        f2 alpha;
-        alpha.x = fminf(GOL_ALPHA_CAP_FWD, b4.y * exact_exp_neg(sigma.x));
-        alpha.y = fminf(GOL_ALPHA_CAP_FWD, b4.y * exact_exp_neg(sigma.y));
+#pragma unroll
+        for (int q = 0; q < PPL; ++q) {
+          sigma[q] = exact_sigma(a4.z, a4.w, b4.x, dx, dy[q]);
+          alpha[q] = fminf(GOL_ALPHA_CAP_FWD, b4.y * exact_exp_neg(sigma[q]));
+        }
 #endif
         alpha *= live;
-        // contributes: !(sigma < 0 || alpha < 1/255), as scalar lane masks (ballots of the plain compares)
-        const unsigned long long mc0 = gol_ballot(!(sigma.x < 0.f)) & gol_ballot(!(alpha.x < GOL_ALPHA_FLOOR));
-        const unsigned long long mc1 = gol_ballot(!(sigma.y < 0.f)) & gol_ballot(!(alpha.y < GOL_ALPHA_FLOOR));
-        // (an early-out for visits without a taker, as the backward has it, does not pay here: 602-612 vs 613 us)
-        f2 vis = alpha * T_cur;
+        fv vis = alpha * T_cur;
 #ifndef GOL_EXACT_MATH
-        const f2 next_T = T_cur - vis;  // = T (1 - alpha)
+        const fv next_T = T_cur - vis;  // = T (1 - alpha)
 #else
-        const f2 next_T = {exact_next_T(T_cur.x, alpha.x), exact_next_T(T_cur.y, alpha.y)};
+        fv next_T;
+#pragma unroll
+        for (int q = 0; q < PPL; ++q) next_T[q] = exact_next_T(T_cur[q], alpha[q]);
 #endif
-        // stop / take as scalar lane-mask algebra: one compare per pixel (written with bools the compiler issues a second,
-        // NaN-aware compare for the negation)
-        const unsigned long long ms0 = gol_ballot(next_T.x <= GOL_T_STOP), ms1 = gol_ballot(next_T.y <= GOL_T_STOP);
-        const bool take0 = __builtin_amdgcn_inverse_ballot_w64(mc0 & ~ms0), take1 = __builtin_amdgcn_inverse_ballot_w64(mc1 & ~ms1);
-        bool half_done = false;
-        if (!LAZY || ((mc0 & ms0) | (mc1 & ms1)) != 0ull) {   // LAZY: wave-uniform and rare -- some pixel stops here
-          const bool stop0 = __builtin_amdgcn_inverse_ballot_w64(mc0 & ms0), stop1 = __builtin_amdgcn_inverse_ballot_w64(mc1 & ms1);
-          live.x = stop0 ? 0.f : live.x; live.y = stop1 ? 0.f : live.y;
-          if (LAZY) {
-            cur_idx.x = stop0 ? (batch_start + t - 1) : cur_idx.x; cur_idx.y = stop1 ? (batch_start + t - 1) : cur_idx.y;
-            half_done = gol_ballot((__float_as_uint(live.x) | __float_as_uint(live.y)) != 0u) == 0ull;
-          }
+        // contributes: !(sigma < 0 || alpha < 1/255); stop / take: one compare per pixel -- all as scalar lane masks
+        // (ballots of the plain compares; written with bools the compiler issues a second, NaN-aware compare for the
+        // negation).  (An early-out for visits without a taker, as the backward has it, does not pay here: 602-612 vs 613 us)
+        unsigned long long mc[PPL], ms[PPL], any_stop = 0ull;
+        bool take[PPL];
+#pragma unroll
+        for (int q = 0; q < PPL; ++q) {
+          mc[q] = gol_ballot(!(sigma[q] < 0.f)) & gol_ballot(!(alpha[q] < GOL_ALPHA_FLOOR));
+          ms[q] = gol_ballot(next_T[q] <= GOL_T_STOP);
+          take[q] = __builtin_amdgcn_inverse_ballot_w64(mc[q] & ~ms[q]);
+          any_stop |= mc[q] & ms[q];
         }
-        vis.x = take0 ? vis.x : 0.f; vis.y = take1 ? vis.y : 0.f;
+        bool half_done = false;
+        if (!LAZY || any_stop != 0ull) {   // LAZY: wave-uniform and rare -- some pixel stops here
+#pragma unroll
+          for (int q = 0; q < PPL; ++q) {
+            const bool stop = __builtin_amdgcn_inverse_ballot_w64(mc[q] & ms[q]);
+            live[q] = stop ? 0.f : live[q];
+            if (LAZY) cur_idx[q] = stop ? (batch_start + t - 1) : cur_idx[q];
+          }
+          if (LAZY) half_done = gol_ballot(any_live<fv, PPL>(live)) == 0ull;
+        }
+#pragma unroll
+        for (int q = 0; q < PPL; ++q) vis[q] = take[q] ? vis[q] : 0.f;
         acc0 += b4.z * vis; acc1 += b4.w * vis; acc2 += c2.x * vis;
         if (EXTRA) acc3 += c2.y * vis;
 #ifndef GOL_EXACT_MATH
         T_cur -= vis;                   // unchanged where the entry is not taken
 #else
-        T_cur.x = take0 ? next_T.x : T_cur.x; T_cur.y = take1 ? next_T.y : T_cur.y;
+#pragma unroll
+        for (int q = 0; q < PPL; ++q) T_cur[q] = take[q] ? next_T[q] : T_cur[q];
 #endif
-        if (!LAZY) { cur_idx.x = take0 ? (batch_start + t) : cur_idx.x; cur_idx.y = take1 ? (batch_start + t) : cur_idx.y; }
+        if (!LAZY) {
+#pragma unroll
+          for (int q = 0; q < PPL; ++q) cur_idx[q] = take[q] ? (batch_start + t) : cur_idx[q];
+        }
         if (LAZY && half_done) { chunk = batch_size; break; }
       }
     }
   }
   if (LAZY) {   // a pixel that never stopped may have taken entries up to the end of the list
-    cur_idx.x = live.x != 0.f ? range.y - 1 : cur_idx.x; cur_idx.y = live.y != 0.f ? range.y - 1 : cur_idx.y;
+#pragma unroll
+    for (int q = 0; q < PPL; ++q) cur_idx[q] = live[q] != 0.f ? range.y - 1 : cur_idx[q];
   }
 
   // planar: [B,3,H,W] (what the model consumes, rgca.py:139); else gsplat's [B,H,W,3].
@@ -259,19 +329,21 @@ __global__ __launch_bounds__(128) void raster_fwd_kernel(
   // channel planes as separate uniform bases (non-planar: element 3 * pix + c)
   float* __restrict__ o_img1 = o_img + (planar ? hw : 1u);
   float* __restrict__ o_img2 = o_img + (planar ? 2u * hw : 2u);
+  // a tile without entries: its final_idx / sign bytes are never read (the backward skips the tile: its range is
+  // empty) -- 5 of the 41 bytes per pixel that the epilogue moves for the ~70 % empty tiles of a head-and-shoulders view
+  // (final_T = 1 is still written: render_gsplat.render returns it)
+  const bool bwd_state = range.y > range.x;
   float l1_acc = 0.f;
 #pragma unroll
-  for (int q = 0; q < 2; ++q) {
-    const bool in = q ? in1 : in0;
-    if (!in) continue;
+  for (int q = 0; q < PPL; ++q) {
+    if (!in[q]) continue;
     const unsigned pix = (unsigned)(i0 + q) * (unsigned)img_w + (unsigned)j;
     const unsigned b4 = pix * 4u;                  // byte offset inside a one-channel plane (checked < 4 GiB on the host)
     const unsigned bimg = planar ? b4 : 3u * b4;
-    const float Tq = q ? T_cur.y : T_cur.x;
-    const float c0 = (q ? acc0.y : acc0.x) + Tq * bg0, c1 = (q ? acc1.y : acc1.x) + Tq * bg1,
-                c2 = (q ? acc2.y : acc2.x) + Tq * bg2, ex = q ? acc3.y : acc3.x;
+    const float Tq = T_cur[q];
+    const float c0 = acc0[q] + Tq * bg0, c1 = acc1[q] + Tq * bg1, c2 = acc2[q] + Tq * bg2, ex = acc3[q];
     *gol_at(o_T, b4) = Tq;
-    *gol_at(o_idx, b4) = q ? cur_idx.y : cur_idx.x;
+    if (bwd_state || !LAZY) *gol_at(o_idx, b4) = cur_idx[q];
     *gol_at(o_img, bimg) = c0; *gol_at(o_img1, bimg) = c1; *gol_at(o_img2, bimg) = c2;
     if (o_ex) *gol_at(o_ex, b4) = ex;
     // optional fused epilogue of AutoEncoder.render (rgca.py:137,144-145): alpha = 1 - T, depth / clamp(alpha, lo, 1)
@@ -293,30 +365,34 @@ __global__ __launch_bounds__(128) void raster_fwd_kernel(
         l1_acc += fabsf(d);
         code |= (d > 0.f ? 2u : (d < 0.f ? 0u : 1u)) << (2 * c);
       }
-      *gol_at(o_sign, pix) = (uint8_t)code;
+      if (bwd_state) *gol_at(o_sign, pix) = (uint8_t)code;
     }
   }
   if (l1_target) {  // (kernel-uniform) per-tile sum of |difference|: the caller adds the tiles up (deterministic)
     const float ws = gol_wave_sum_to_lane63(l1_acc);
     if (lane == 63) s_l1[wave] = ws;
     __syncthreads();
-    if (tid == 0) l1_partial[(size_t)view * T + tc.tile] = s_l1[0] + s_l1[1];
+    if (tid == 0) {
+      float tot = 0.f;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) tot += s_l1[w];
+      l1_partial[(size_t)view * T + tc.tile] = tot;
+    }
   }
 }
 
 constexpr int kBatchB = 64;   // backward batch (smaller: per-wave gradient slots live in LDS)
 constexpr int kAcc = 12;      // r g b v_opacity | Mx My Mxx Mxy | Myy extra - -   (M = moments of gop, see the loop)
 
-// ---- backward, two pixels per lane -------------------------------------------------------------
-// 128-thread workgroup per tile: wave w owns the 16x8 half (rows 8w..8w+7), lane = (x = lane&15, row pair
-// lane>>4) owns the two vertically adjacent pixels of a column.  The per-pixel recurrences of the two pixels are
-// independent, so the body is written on 2-vectors and maps onto packed fp32 VALU ops (v_pk_fma/mul/add_f32:
+// ---- backward ------------------------------------------------------------------------------------
+// Same workgroup / wave / lane layout as the forward (Pix).  With two pixels per lane the per-pixel recurrences of the
+// two pixels are independent, so the body is written on 2-vectors and maps onto packed fp32 VALU ops (v_pk_fma/mul/add_f32:
 // two pixels per instruction), and the cross-lane reduction of the 10 per-Gaussian sums -- the largest single cost
 // of the one-pixel-per-lane kernel -- is paid once per 128 pixels instead of once per 64.
 static_assert(kBatchB == 64, "raster_bwd_kernel ballots one 64-entry chunk per batch");
 
-template <bool EXTRA, bool PACKED>
-__global__ __launch_bounds__(128) void raster_bwd_kernel(
+template <bool EXTRA, bool PACKED, int PPL>
+__global__ __launch_bounds__(64 * Pix<PPL>::kWaves) void raster_bwd_kernel(
     int N, int img_h, int img_w, int planar, int tiles_x, int tiles_y, const int2* __restrict__ tile_bins,
     const int32_t* __restrict__ sorted_ids, int64_t capacity, const float* __restrict__ records,
     const float* __restrict__ background,
@@ -325,42 +401,52 @@ __global__ __launch_bounds__(128) void raster_bwd_kernel(
     const float* __restrict__ v_out_alpha, float* __restrict__ v_xy, float* __restrict__ v_conic,
     float* __restrict__ v_colors, float* __restrict__ v_extra, float* __restrict__ v_opacity,
     const uint8_t* __restrict__ v_sign, const float* __restrict__ v_sign_mask, int v_sign_mask_c,
-    const float* __restrict__ v_img_scale) {
+    const float* __restrict__ v_img_scale, int n_views) {
+  typedef typename Pix<PPL>::fv fv;
+  typedef typename Pix<PPL>::iv iv;
+  constexpr int NW = Pix<PPL>::kWaves, NT = 64 * NW;
   __shared__ StagedRow s_e[kBatchB];  // one 48-byte row per entry: the reads of a visit share their address register
   __shared__ int32_t s_mask[kBatchB];
   __shared__ int32_t s_id[kBatchB];
-  __shared__ __attribute__((aligned(16))) float s_acc[2][kBatchB][kAcc];
-  __shared__ int32_t s_touched[2][kBatchB];
-  __shared__ int32_t s_wmax[2];
+  __shared__ __attribute__((aligned(16))) float s_acc[NW][kBatchB][kAcc];
+  __shared__ int32_t s_touched[NW][kBatchB];
+  __shared__ int32_t s_wmax[NW];
   const int T = tiles_x * tiles_y;
-  const TileCoord tc = tile_of_block(blockIdx.x, T, tiles_x);
+  const int view = blockIdx.x % n_views, slot = blockIdx.x / n_views;   // (see raster_fwd_kernel)
+  const TileCoord tc = tile_of_block(slot, T, tiles_x);
   if (!tc.ok) return;
-  const int view = blockIdx.y;
   const int2 range = tile_bins[(size_t)view * T + tc.tile];
   if (range.y <= range.x) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int j = tc.tx * 16 + (lane & 15), i0 = tc.ty * 16 + wave * 8 + (lane >> 4) * 2;
+  int j, i0;
+  lane_pixel<PPL>(tc.tx, tc.ty, wave, lane, j, i0);
   const float px = (float)j + 0.5f;
-  const f2 py = {(float)i0 + 0.5f, (float)i0 + 1.5f};
-  const bool in0 = (i0 < img_h) && (j < img_w), in1 = (i0 + 1 < img_h) && (j < img_w);
   const size_t hw = (size_t)img_h * img_w;
-  const size_t p0 = in0 ? ((size_t)view * img_h + i0) * img_w + j : 0, p1 = in1 ? p0 + img_w : p0;
   const int32_t* ids = sorted_ids + (size_t)view * capacity;
   const size_t goff = (size_t)view * N;
-
-  const f2 T_final = {in0 ? final_Ts[p0] : 1.f, in1 ? final_Ts[p1] : 1.f};
-  f2 T_cur = T_final;
-  const i2 bin_final = {in0 ? final_idx[p0] : (range.x - 1), in1 ? final_idx[p1] : (range.x - 1)};
-  f2 vo0 = {0.f, 0.f}, vo1 = vo0, vo2 = vo0, vo3 = vo0, voa = vo0;
+  bool in[PPL];
+  size_t pp[PPL];
+  fv py, T_final;
+  iv bin_final;
+#pragma unroll
+  for (int q = 0; q < PPL; ++q) {
+    in[q] = (i0 + q < img_h) && (j < img_w);
+    py[q] = (float)(i0 + q) + 0.5f;
+    pp[q] = in[q] ? ((size_t)view * img_h + i0 + q) * img_w + j : 0;
+    T_final[q] = in[q] ? final_Ts[pp[q]] : 1.f;
+    bin_final[q] = in[q] ? final_idx[pp[q]] : (range.x - 1);
+  }
+  fv T_cur = T_final;
+  fv vo0 = 0.f, vo1 = 0.f, vo2 = 0.f, vo3 = 0.f, voa = 0.f;
   {
     // upstream image gradient = v_out_img (optional) + the fused L1's term: (sign code - 1) x mask x v_img_scale, with the
     // sign codes the forward epilogue left (one byte per pixel) and the scalar g / n as a device value (no sync)
     const float vsc = v_img_scale ? v_img_scale[0] : 1.f;
     const size_t os = planar ? hw : 1;
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      if (!(q ? in1 : in0)) continue;
-      const size_t p = q ? p1 : p0;
+    for (int q = 0; q < PPL; ++q) {
+      if (!in[q]) continue;
+      const size_t p = pp[q];
       const int i = i0 + q;
       const size_t o = planar ? (size_t)view * 3 * hw + (size_t)i * img_w + j : 3 * p;
       float g0 = 0.f, g1 = 0.f, g2 = 0.f;
@@ -376,21 +462,26 @@ __global__ __launch_bounds__(128) void raster_bwd_kernel(
         g1 += (float)((int)((code >> 2) & 3u) - 1) * m1;
         g2 += (float)((int)((code >> 4) & 3u) - 1) * m2;
       }
-      if (q) { vo0.y = g0; vo1.y = g1; vo2.y = g2; } else { vo0.x = g0; vo1.x = g1; vo2.x = g2; }
-      if (EXTRA && v_out_extra) { if (q) vo3.y = v_out_extra[p]; else vo3.x = v_out_extra[p]; }
-      if (v_out_alpha) { if (q) voa.y = v_out_alpha[p]; else voa.x = v_out_alpha[p]; }
+      vo0[q] = g0; vo1[q] = g1; vo2[q] = g2;
+      if (EXTRA && v_out_extra) vo3[q] = v_out_extra[p];
+      if (v_out_alpha) voa[q] = v_out_alpha[p];
     }
   }
-  const f2 tail = T_final * (voa - (background[0] * vo0 + background[1] * vo1 + background[2] * vo2));
-  f2 q = {0.f, 0.f};  // running sum over the Gaussians behind of fac * <colour, v_out>
+  const fv tail = T_final * (voa - (background[0] * vo0 + background[1] * vo1 + background[2] * vo2));
+  fv qsum = 0.f;  // running sum over the Gaussians behind of fac * <colour, v_out>
 
-  int wmax = max(bin_final.x, bin_final.y);
+  int wmax = bin_final[0];
+#pragma unroll
+  for (int q = 1; q < PPL; ++q) wmax = max(wmax, bin_final[q]);
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) wmax = max(wmax, __shfl_xor(wmax, off, 64));
   wmax = __builtin_amdgcn_readfirstlane(wmax);
   if (lane == 0) s_wmax[wave] = wmax;
   __syncthreads();
-  const int bmax = min(max(s_wmax[0], s_wmax[1]), range.y - 1);
+  int bmax = s_wmax[0];
+#pragma unroll
+  for (int w = 1; w < NW; ++w) bmax = max(bmax, s_wmax[w]);
+  bmax = min(bmax, range.y - 1);
   if (bmax < range.x) return;
 
   float* acc_lane = &s_acc[wave][0][lane >> 4];  // this lane's column (lanes 15, 31, 47, 63 hold sums 0..3 / 4..7)
@@ -402,14 +493,14 @@ __global__ __launch_bounds__(128) void raster_bwd_kernel(
     if (tid < kBatchB) {
       if (tid < batch_size) {
         const int gid = ids[batch_end - tid];
-        const Staged st = stage_entry(records, goff + (size_t)gid, (float)(tc.tx * 16), (float)(tc.ty * 16));
+        const Staged st = stage_entry<PPL>(records, goff + (size_t)gid, (float)(tc.tx * 16), (float)(tc.ty * 16));
         s_e[tid].a = st.a; s_e[tid].b = st.b; s_e[tid].c = st.c; s_mask[tid] = st.mask;
         s_id[tid] = gid;
       } else {
         s_mask[tid] = 0;
       }
     }
-    (&s_touched[0][0])[tid] = 0;  // 2 * kBatchB == 128 == blockDim
+    (&s_touched[0][0])[tid] = 0;  // NW * kBatchB == blockDim
     __syncthreads();
 
     const int t0 = max(0, batch_end - wmax);
@@ -423,56 +514,73 @@ __global__ __launch_bounds__(128) void raster_bwd_kernel(
       const float2 c2 = s_e[t].c;
       const int li = batch_end - t;
       const float dx = a4.x - px;
-      const f2 dy = a4.y - py;
+      const fv dy = a4.y - py;
+      fv sigma, vis;
 #ifndef GOL_EXACT_MATH
-      const f2 sigma = (a4.z * dx * dx + b4.x * dy * dy) + (a4.w * dx) * dy;
-      f2 vis;
-      vis.x = __builtin_amdgcn_exp2f(-sigma.x); vis.y = __builtin_amdgcn_exp2f(-sigma.y);  // sigma = log2e * gsplat's
+      sigma = (a4.z * dx * dx + b4.x * dy * dy) + (a4.w * dx) * dy;
+#pragma unroll
+      for (int q = 0; q < PPL; ++q) vis[q] = __builtin_amdgcn_exp2f(-sigma[q]);  // sigma = log2e * gsplat's
 #else
-      const f2 sigma = {exact_sigma(a4.z, a4.w, b4.x, dx, dy.x), exact_sigma(a4.z, a4.w, b4.x, dx, dy.y)};
-      f2 vis;
-      vis.x = exact_exp_neg(sigma.x); vis.y = exact_exp_neg(sigma.y);
+#pragma unroll
+      for (int q = 0; q < PPL; ++q) { sigma[q] = exact_sigma(a4.z, a4.w, b4.x, dx, dy[q]); vis[q] = exact_exp_neg(sigma[q]); }
 #endif
-      f2 alpha = b4.y * vis;
-      alpha.x = fminf(GOL_ALPHA_CAP_BWD, alpha.x); alpha.y = fminf(GOL_ALPHA_CAP_BWD, alpha.y);
+      fv alpha = b4.y * vis;
       // taken by the pixel: within its list && !(sigma < 0 || alpha < 1/255) -- as scalar lane masks (ballots of the plain
       // compares; the ballot of a combined bool costs a v_cndmask + v_cmp)
-      const unsigned long long mv0 = gol_ballot(li <= bin_final.x) & gol_ballot(!(sigma.x < 0.f)) & gol_ballot(!(alpha.x < GOL_ALPHA_FLOOR));
-      const unsigned long long mv1 = gol_ballot(li <= bin_final.y) & gol_ballot(!(sigma.y < 0.f)) & gol_ballot(!(alpha.y < GOL_ALPHA_FLOOR));
-      if ((mv0 | mv1) == 0ull) continue;
-      const bool v0 = __builtin_amdgcn_inverse_ballot_w64(mv0), v1 = __builtin_amdgcn_inverse_ballot_w64(mv1);
-      // an entry the pixel did not take enters with alpha = 0: 1 / (1 - 0) = 1 exactly, so T and the running sums pass
-      // through unchanged without further selects
-      alpha.x = v0 ? alpha.x : 0.f; alpha.y = v1 ? alpha.y : 0.f;
-      const f2 one_m = 1.f - alpha;
-      f2 ra;
-      ra.x = __builtin_amdgcn_rcpf(one_m.x); ra.y = __builtin_amdgcn_rcpf(one_m.y);
-      const f2 T_new = T_cur * ra;
-      const f2 fac = alpha * T_new;
+      unsigned long long mv[PPL], many = 0ull;
+#pragma unroll
+      for (int q = 0; q < PPL; ++q) {
+        alpha[q] = fminf(GOL_ALPHA_CAP_BWD, alpha[q]);
+        mv[q] = gol_ballot(li <= bin_final[q]) & gol_ballot(!(sigma[q] < 0.f)) & gol_ballot(!(alpha[q] < GOL_ALPHA_FLOOR));
+        many |= mv[q];
+      }
+      if (many == 0ull) continue;
+      bool v[PPL];
+      fv ra;
+#pragma unroll
+      for (int q = 0; q < PPL; ++q) {
+        v[q] = __builtin_amdgcn_inverse_ballot_w64(mv[q]);
+        // an entry the pixel did not take enters with alpha = 0: 1 / (1 - 0) = 1 exactly, so T and the running sums pass
+        // through unchanged without further selects
+        alpha[q] = v[q] ? alpha[q] : 0.f;
+      }
+      const fv one_m = 1.f - alpha;
+#pragma unroll
+      for (int q = 0; q < PPL; ++q) ra[q] = __builtin_amdgcn_rcpf(one_m[q]);
+      const fv T_new = T_cur * ra;
+      const fv fac = alpha * T_new;
       T_cur = T_new;
       // gsplat: v_alpha = sum_c (rgb_c T - buffer_c ra) v_out_c + T_final ra (v_out_alpha - <bg, v_out>) with
       // buffer_c = sum over the Gaussians behind of rgb_c alpha T.  All channels enter through ONE dot product with the
       // upstream gradient, w = <colour, v_out>, so the three running colour buffers collapse into the running scalar
       // q = sum_behind fac w:  v_alpha = T w + ra (tail - q)
-      f2 w = b4.z * vo0 + b4.w * vo1 + c2.x * vo2;
+      fv w = b4.z * vo0 + b4.w * vo1 + c2.x * vo2;
       if (EXTRA) w += c2.y * vo3;
-      const f2 v_alpha = T_new * w + ra * (tail - q);
-      q += fac * w;
-      // colour gradients of the two pixels, summed: one multiply + one scalar FMA each (written on scalars: from the
-      // 2-vector form the compiler builds v_mul + v_pk_fma and throws the packed op's upper half away)
-      const float g0s = __builtin_fmaf(fac.x, vo0.x, fac.y * vo0.y), g1s = __builtin_fmaf(fac.x, vo1.x, fac.y * vo1.y),
-                  g2s = __builtin_fmaf(fac.x, vo2.x, fac.y * vo2.y);
-      float g3 = 0.f;
-      if (EXTRA) g3 = __builtin_fmaf(fac.x, vo3.x, fac.y * vo3.y);
+      const fv v_alpha = T_new * w + ra * (tail - qsum);
+      qsum += fac * w;
       // d loss / d sigma per pixel is -opacity * gop; the (wave-uniform) factor -opacity is applied once per Gaussian in
       // the merge step: the lanes reduce the moments of gop itself, whose zeroth moment IS v_opacity
-      f2 gop = vis * v_alpha;
-      gop.x = v0 ? gop.x : 0.f; gop.y = v1 ? gop.y : 0.f;
-      const f2 gy = gop * dy;
-      const float m0 = gop.x + gop.y;       // sum_pix gop
-      const float my = gy.x + gy.y;         // sum gop dy
-      const f2 gyy = gy * dy;
-      const float myy = gyy.x + gyy.y;
+      fv gop = vis * v_alpha;
+#pragma unroll
+      for (int q = 0; q < PPL; ++q) gop[q] = v[q] ? gop[q] : 0.f;
+      const fv gy = gop * dy;
+      const fv gyy = gy * dy;
+      // the lane's pixels, summed (PPL = 2: one multiply + one scalar FMA per colour sum -- written on scalars: from the
+      // 2-vector form the compiler builds v_mul + v_pk_fma and throws the packed op's upper half away)
+      float g0s, g1s, g2s, g3 = 0.f, m0, my, myy;
+      if (PPL == 2) {
+        g0s = __builtin_fmaf(fac[0], vo0[0], fac[PPL - 1] * vo0[PPL - 1]);
+        g1s = __builtin_fmaf(fac[0], vo1[0], fac[PPL - 1] * vo1[PPL - 1]);
+        g2s = __builtin_fmaf(fac[0], vo2[0], fac[PPL - 1] * vo2[PPL - 1]);
+        if (EXTRA) g3 = __builtin_fmaf(fac[0], vo3[0], fac[PPL - 1] * vo3[PPL - 1]);
+        m0 = gop[0] + gop[PPL - 1];       // sum_pix gop
+        my = gy[0] + gy[PPL - 1];         // sum gop dy
+        myy = gyy[0] + gyy[PPL - 1];
+      } else {
+        g0s = fac[0] * vo0[0]; g1s = fac[0] * vo1[0]; g2s = fac[0] * vo2[0];
+        if (EXTRA) g3 = fac[0] * vo3[0];
+        m0 = gop[0]; my = gy[0]; myy = gyy[0];
+      }
       const float mx = m0 * dx, mxx = mx * dx, mxy = my * dx;
       const float r0 = gol_wave_sum4(g0s, g1s, g2s, m0);
       const float r1 = gol_wave_sum4(mx, my, mxx, mxy);
@@ -492,10 +600,12 @@ __global__ __launch_bounds__(128) void raster_bwd_kernel(
       // gradients live in 64-byte records [r g b | opacity | x y | conic a b c | extra | pad]: 16 consecutive
       // lanes own one Gaussian's record, so an atomic instruction touches 4 cache lines instead of 64
       float* rec = v_colors;
-      for (int idx = tid; idx < batch_size * 16; idx += 128) {
+      for (int idx = tid; idx < batch_size * 16; idx += NT) {
         const int t = idx >> 4, c = idx & 15;
-        const bool t0w = s_touched[0][t] != 0, t1w = s_touched[1][t] != 0;
-        if (!(t0w || t1w) || c > (EXTRA ? 9 : 8)) continue;
+        bool any = false;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) any = any || (s_touched[w][t] != 0);
+        if (!any || c > (EXTRA ? 9 : 8)) continue;
         // component c = w1 * S[k1] + w2 * S[k2] of the wave-summed slots S; slots 4..8 hold moments of gop:
         // v_sigma-sums = -opacity * moment (conic back from its log2e scaling with ln 2)
         const float4 a4 = s_e[t].a;
@@ -505,8 +615,13 @@ __global__ __launch_bounds__(128) void raster_bwd_kernel(
         const float w1 = (c == 4) ? nop * a4.z * kUnA : (c == 5) ? nop * a4.w * kUnB : (c == 6 || c == 8) ? 0.5f * nop
                        : (c == 7) ? nop : 1.f;
         const float w2 = (c == 4) ? nop * a4.w * kUnB : (c == 5) ? nop * cc * kUnA : 0.f;
-        const float s1 = (t0w ? s_acc[0][t][k1] : 0.f) + (t1w ? s_acc[1][t][k1] : 0.f);
-        const float s2 = (t0w ? s_acc[0][t][k2] : 0.f) + (t1w ? s_acc[1][t][k2] : 0.f);
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) {
+          const bool tw = s_touched[w][t] != 0;
+          s1 += tw ? s_acc[w][t][k1] : 0.f;
+          s2 += tw ? s_acc[w][t][k2] : 0.f;
+        }
         atomicAdd(rec + (goff + (size_t)s_id[t]) * 16 + c, w1 * s1 + w2 * s2);
       }
     } else if (tid < batch_size) {
@@ -515,7 +630,7 @@ __global__ __launch_bounds__(128) void raster_bwd_kernel(
       for (int k = 0; k < kAcc; ++k) a[k] = 0.f;
       bool any = false;
 #pragma unroll
-      for (int w = 0; w < 2; ++w) {
+      for (int w = 0; w < NW; ++w) {
         if (s_touched[w][tid]) {
           any = true;
           const float4* q = reinterpret_cast<const float4*>(&s_acc[w][tid][0]);
@@ -560,6 +675,19 @@ __global__ __launch_bounds__(256) void splat_pack_kernel(size_t n, const float* 
 
 }  // namespace
 
+// The forward's wave footprint for a launch of B views (GOL_RASTER_PPL = 1 | 2 overrides it for experiments).  One or two
+// views do not fill the chip for the whole launch: all their workgroups are resident at once, every SIMD keeps the waves it
+// was dealt, and the launch lasts until the most loaded SIMD is done (per-workgroup timeline, profiles/r04_raster_tail.txt:
+// 2942 workgroups of a view start within 5 us, half of them are done after 120 us, the last one after 257 us; an 8-view
+// launch takes 131-148 us per view).  Four waves per tile spread a tile's work over more SIMDs: forward 121 -> 106 us for
+// one view; in the backward the 17 % extra instructions of the finer footprint cancel the gain (236 -> 240 us): it keeps
+// two pixels per lane.  From three views on the instruction count decides.
+extern "C" int gol_raster_plan(int B, int* fwd_pixels_per_lane) {
+  static const int forced = getenv("GOL_RASTER_PPL") ? atoi(getenv("GOL_RASTER_PPL")) : 0;
+  if (fwd_pixels_per_lane) *fwd_pixels_per_lane = (forced == 1 || forced == 2) ? forced : (B <= 2 ? 1 : 2);
+  return GOL_OK;
+}
+
 extern "C" int gol_splat_pack(int B, int N, const float* xys, const float* conics, const float* colors,
                               const float* extra, const float* opacities, float* records, void* stream) {
   GOL_REQUIRE(B >= 0 && N >= 0, "negative size");
@@ -577,12 +705,13 @@ extern "C" int gol_rasterize_fwd(int B, int N, int img_h, int img_w, int block, 
                                  const float* background, float* out_img,
                                  float* out_extra, float* final_Ts, int32_t* final_idx, float* out_alpha,
                                  float* out_extra_norm, float norm_lo, const float* l1_target, const float* l1_mask,
-                                 int l1_mask_c, uint8_t* l1_sign, float* l1_partial, void* stream) {
+                                 int l1_mask_c, uint8_t* l1_sign, float* l1_partial, int pixels_per_lane,
+                                 void* stream) {
   GOL_REQUIRE(B >= 0 && N >= 0, "negative size");
   GOL_REQUIRE(block == 16, "only block_width == 16 is implemented (the reference's value, render_gsplat.py:28)");
   GOL_REQUIRE(img_h > 0 && img_w > 0, "empty image");
   if (B == 0) return GOL_OK;
-  GOL_REQUIRE(B <= 65535, "B > 65535");
+  GOL_REQUIRE((int64_t)B * 8 * (((img_h + 15) / 16 + 7) / 8) * ((img_w + 15) / 16) < (1ll << 31), "too many tiles");
   GOL_REQUIRE(tile_bins && background && out_img && final_Ts && final_idx, "null pointer");
   GOL_REQUIRE((uint64_t)img_h * (uint64_t)img_w * 12ull < (1ull << 32), "image too large (32-bit byte offsets inside a view)");
   GOL_REQUIRE(capacity == 0 || sorted_ids, "null sorted_ids");
@@ -592,14 +721,27 @@ extern "C" int gol_rasterize_fwd(int B, int N, int img_h, int img_w, int block, 
   GOL_REQUIRE(!l1_target || (planar && l1_sign && l1_partial), "the fused L1 needs planar images, l1_sign and l1_partial");
   GOL_REQUIRE(!l1_mask || (l1_target && (l1_mask_c == 1 || l1_mask_c == 3)), "l1_mask: 1 or 3 channels, with l1_target");
   const int tiles_x = (img_w + 15) / 16, tiles_y = (img_h + 15) / 16;
-  dim3 grid(8 * ((tiles_y + 7) / 8) * tiles_x, B);
+  dim3 grid(8 * ((tiles_y + 7) / 8) * tiles_x * B);
   const int2* bins = reinterpret_cast<const int2*>(tile_bins);
   hipStream_t s = (hipStream_t)stream;
+  GOL_REQUIRE(pixels_per_lane >= 0 && pixels_per_lane <= 2, "pixels_per_lane: 0 (choose by B), 1 or 2");
+  // one pixel per lane (4 waves per tile) for launches of one or two views: their duration is the longest list's chain
+  // through one wave, which the finer footprint shortens to ~0.55x for ~9 % more instructions in total (see Pix)
+  int ppl = pixels_per_lane;
+  if (ppl == 0) gol_raster_plan(B, &ppl);
 #define GOL_LAUNCH_FWD(EX, LZ)                                                                                          \
-  raster_fwd_kernel<EX, LZ><<<grid, 128, 0, s>>>(N, img_h, img_w, planar, tiles_x, tiles_y, bins, sorted_ids, capacity, \
-                                                 records, background, out_img, out_extra, final_Ts, final_idx,         \
-                                                 out_alpha, EX ? out_extra_norm : nullptr, norm_lo, l1_target, l1_mask, \
-                                                 l1_mask_c, l1_sign, l1_partial)
+  do {                                                                                                                  \
+    if (ppl == 2)                                                                                                       \
+      raster_fwd_kernel<EX, LZ, 2><<<grid, 128, 0, s>>>(N, img_h, img_w, planar, tiles_x, tiles_y, bins, sorted_ids,   \
+                                                        capacity, records, background, out_img, out_extra, final_Ts,   \
+                                                        final_idx, out_alpha, EX ? out_extra_norm : nullptr, norm_lo,   \
+                                                        l1_target, l1_mask, l1_mask_c, l1_sign, l1_partial, B);         \
+    else                                                                                                                \
+      raster_fwd_kernel<EX, LZ, 1><<<grid, 256, 0, s>>>(N, img_h, img_w, planar, tiles_x, tiles_y, bins, sorted_ids,   \
+                                                        capacity, records, background, out_img, out_extra, final_Ts,   \
+                                                        final_idx, out_alpha, EX ? out_extra_norm : nullptr, norm_lo,   \
+                                                        l1_target, l1_mask, l1_mask_c, l1_sign, l1_partial, B);         \
+  } while (0)
   const bool ex = out_extra || out_extra_norm;
   // planar = the fused path: final_idx is the backward's start bound (see raster_fwd_kernel); gsplat's layout: exact
   if (ex && planar) GOL_LAUNCH_FWD(true, true);
@@ -617,12 +759,13 @@ extern "C" int gol_rasterize_bwd(int B, int N, int img_h, int img_w, int block, 
                                  const int32_t* final_idx, const float* v_out_img, const float* v_out_extra,
                                  const float* v_out_alpha, float* v_xy, float* v_conic, float* v_colors,
                                  float* v_extra, float* v_opacity, int grad_stride, const uint8_t* v_sign,
-                                 const float* v_sign_mask, int v_sign_mask_c, const float* v_img_scale, void* stream) {
+                                 const float* v_sign_mask, int v_sign_mask_c, const float* v_img_scale,
+                                 int pixels_per_lane, void* stream) {
   GOL_REQUIRE(B >= 0 && N >= 0, "negative size");
   GOL_REQUIRE(block == 16, "only block_width == 16 is implemented (the reference's value, render_gsplat.py:28)");
   GOL_REQUIRE(img_h > 0 && img_w > 0, "empty image");
   if (B == 0 || N == 0 || capacity == 0) return GOL_OK;
-  GOL_REQUIRE(B <= 65535, "B > 65535");
+  GOL_REQUIRE((int64_t)B * 8 * (((img_h + 15) / 16 + 7) / 8) * ((img_w + 15) / 16) < (1ll << 31), "too many tiles");
   GOL_REQUIRE(tile_bins && sorted_ids && background && final_Ts && final_idx, "null pointer");
   GOL_REQUIRE(v_out_img || v_sign, "no upstream image gradient (v_out_img or v_sign)");
   GOL_REQUIRE(!v_sign || planar, "the sign image of the fused L1 goes with planar images");
@@ -637,16 +780,27 @@ extern "C" int gol_rasterize_bwd(int B, int N, int img_h, int img_w, int block, 
                     (!v_extra || v_extra == v_colors + 9),
                 "record layout is [rgb | opacity | xy | conic | extra | pad] (GOL_GRAD_RECORD floats)");
   const int tiles_x = (img_w + 15) / 16, tiles_y = (img_h + 15) / 16;
-  dim3 grid(8 * ((tiles_y + 7) / 8) * tiles_x, B);
+  dim3 grid(8 * ((tiles_y + 7) / 8) * tiles_x * B);
   const int2* bins = reinterpret_cast<const int2*>(tile_bins);
   hipStream_t s = (hipStream_t)stream;
+  GOL_REQUIRE(pixels_per_lane >= 0 && pixels_per_lane <= 2, "pixels_per_lane: 0 (2), 1 or 2");
+  const int ppl = pixels_per_lane ? pixels_per_lane : 2;
   const bool ex = with_extra && (v_out_extra || v_extra);
-#define GOL_LAUNCH_BWD(EX, PK)                                                                                      \
-  raster_bwd_kernel<EX, PK><<<grid, 128, 0, s>>>(N, img_h, img_w, planar, tiles_x, tiles_y, bins, sorted_ids, capacity, \
-                                                 records, background,                                                 \
-                                                 final_Ts, final_idx, v_out_img, EX ? v_out_extra : nullptr,          \
-                                                 v_out_alpha, v_xy, v_conic, v_colors, EX ? v_extra : nullptr, v_opacity, \
-                                                 v_sign, v_sign_mask, v_sign_mask_c, v_img_scale)
+#define GOL_LAUNCH_BWD(EX, PK)                                                                                          \
+  do {                                                                                                                  \
+    if (ppl == 2)                                                                                                       \
+      raster_bwd_kernel<EX, PK, 2><<<grid, 128, 0, s>>>(N, img_h, img_w, planar, tiles_x, tiles_y, bins, sorted_ids,   \
+                                                        capacity, records, background, final_Ts, final_idx, v_out_img, \
+                                                        EX ? v_out_extra : nullptr, v_out_alpha, v_xy, v_conic,        \
+                                                        v_colors, EX ? v_extra : nullptr, v_opacity, v_sign,           \
+                                                        v_sign_mask, v_sign_mask_c, v_img_scale, B);                   \
+    else                                                                                                                \
+      raster_bwd_kernel<EX, PK, 1><<<grid, 256, 0, s>>>(N, img_h, img_w, planar, tiles_x, tiles_y, bins, sorted_ids,   \
+                                                        capacity, records, background, final_Ts, final_idx, v_out_img, \
+                                                        EX ? v_out_extra : nullptr, v_out_alpha, v_xy, v_conic,        \
+                                                        v_colors, EX ? v_extra : nullptr, v_opacity, v_sign,           \
+                                                        v_sign_mask, v_sign_mask_c, v_img_scale, B);                   \
+  } while (0)
   if (ex && packed) GOL_LAUNCH_BWD(true, true);
   else if (ex) GOL_LAUNCH_BWD(true, false);
   else if (packed) GOL_LAUNCH_BWD(false, true);

@@ -71,7 +71,7 @@ extern "C" int gol_render_fwd(int B, int N, int img_h, int img_w, float glob_sca
                            capacity, at<float>(ws, L->records), with_depth ? 1 : 0, background, out_img,
                            with_depth ? out_depth : nullptr, at<float>(ws, L->final_T), at<int32_t>(ws, L->final_idx),
                            out_alpha, with_depth ? out_depth_norm : nullptr, norm_lo, l1_target, l1_mask, l1_mask_c,
-                           l1_target ? at<uint8_t>(ws, L->l1_sign) : nullptr, l1_partial, stream);
+                           l1_target ? at<uint8_t>(ws, L->l1_sign) : nullptr, l1_partial, 0, stream);
 }
 
 extern "C" int gol_render_bwd(int B, int N, int img_h, int img_w, float glob_scale, const float* means,
@@ -98,7 +98,7 @@ extern "C" int gol_render_bwd(int B, int N, int img_h, int img_w, float glob_sca
                              at<float>(ws, L->final_T), at<int32_t>(ws, L->final_idx), v_img, v_depth, v_alpha, g + 4, g + 6,
                              g, use_depth ? g + 9 : nullptr, g + 3, GOL_GRAD_RECORD,
                              use_l1_sign ? at<uint8_t>(ws, L->l1_sign) : nullptr, use_l1_sign ? l1_mask : nullptr,
-                             use_l1_sign ? l1_mask_c : 0, v_img_scale, stream);
+                             use_l1_sign ? l1_mask_c : 0, v_img_scale, 0, stream);
   if (rc != GOL_OK) return rc;
   return gol_project_bwd_records(B, N, means, scales, glob_scale, quats, viewmats, intrins, at<int32_t>(ws, L->radii),
                                  at<float>(ws, L->conics), at<float>(ws, L->comp), opacity, g, use_depth ? 1 : 0, v_mean,

@@ -23,6 +23,9 @@ from ._lib import c_float, c_i64, c_int, fptr, iptr, ptr, stream_ptr
 BLOCK = 16  # tile width; the reference's only value (render_gsplat.py:28)
 GRAD_RECORD = 16  # include/goliath_hip.h: GOL_GRAD_RECORD
 SPLAT_RECORD = 16  # include/goliath_hip.h: GOL_SPLAT_RECORD (the rasterizer's packed per-Gaussian record, 64 bytes)
+# pixels per lane of the raster kernels where this module calls them stage by stage (include/goliath_hip.h: 0 = chosen by
+# the number of views in the launch -- what gol_render_fwd / bwd always use; tests set 1 or 2 to pin a footprint)
+RASTER_PPL = 0
 
 
 def _tiles(img_h, img_w, block=BLOCK):
@@ -303,7 +306,8 @@ class _RasterizeGaussians(torch.autograd.Function):
                           c_int(BLOCK), c_int(0), iptr(ws.tile_bins), iptr(ws.sorted_ids), c_i64(ws.capacity),
                           fptr(records), c_int(0), fptr(background),
                           fptr(out_img), fptr(None), fptr(final_Ts), iptr(final_idx), fptr(None), fptr(None),
-                          c_float(0.0), fptr(None), fptr(None), c_int(0), fptr(None), fptr(None), stream_ptr())
+                          c_float(0.0), fptr(None), fptr(None), c_int(0), fptr(None), fptr(None), c_int(RASTER_PPL),
+                          stream_ptr())
             ctx.ws = ws
             ctx.save_for_backward(xys, conics, colors, opacity, background, final_Ts, final_idx, records)
             out_img, final_Ts = out_img[0], final_Ts[0]
@@ -332,7 +336,7 @@ class _RasterizeGaussians(torch.autograd.Function):
                           fptr(background), fptr(final_Ts),
                           iptr(final_idx), fptr(vo), fptr(None), fptr(va), fptr(v_xy),
                           fptr(v_conic), fptr(v_colors), fptr(None), fptr(v_opacity), c_int(0), fptr(None), fptr(None),
-                          c_int(0), fptr(None), stream_ptr())
+                          c_int(0), fptr(None), c_int(RASTER_PPL), stream_ptr())
         # ctx.ws stays: a second backward through this node (retain_graph=True, per-loss backward calls) needs the tile
         # lists again; autograd frees them with the graph
         return (v_xy, None, None, v_conic, None, v_colors, v_opacity[:, None]) + (None,) * 5
@@ -415,7 +419,8 @@ def _render_fwd_stages(B, N, img_h, img_w, glob_scale, clip, means, scales, quat
               p(L.tile_bins), p(L.sorted_ids), c_i64(cap), p(L.records), c_int(1 if with_depth else 0), fptr(background),
               fptr(out_img), fptr(out_depth), p(L.final_T), p(L.final_idx), fptr(alpha), fptr(depth_norm),
               c_float(norm_lo), fptr(l1_target), fptr(l1_mask), c_int(l1_mask_c),
-              p(L.l1_sign) if l1_target is not None else ctypes.c_void_p(0), fptr(l1_partial), stream_ptr())
+              p(L.l1_sign) if l1_target is not None else ctypes.c_void_p(0), fptr(l1_partial), c_int(RASTER_PPL),
+              stream_ptr())
 
 
 def _render_bwd_stages(B, N, img_h, img_w, glob_scale, means, scales, quats, opacity, viewmats, intrins, background, cap,
@@ -431,7 +436,7 @@ def _render_bwd_stages(B, N, img_h, img_w, glob_scale, means, scales, quats, opa
               p(L.final_T), p(L.final_idx), fptr(v_img), fptr(v_depth), fptr(v_alpha), field(4), field(6), field(0),
               field(9) if use_depth else null, field(3), c_int(GRAD_RECORD), p(L.l1_sign) if use_l1 else null,
               fptr(l1_mask) if use_l1 else null, c_int(0 if (l1_mask is None or not use_l1) else l1_mask.shape[1]),
-              fptr(v_scale), stream_ptr())
+              fptr(v_scale), c_int(0), stream_ptr())
     _lib.call("gol_project_bwd", c_int(B), c_int(N), fptr(means), fptr(scales), c_float(glob_scale), fptr(quats),
               fptr(viewmats), fptr(intrins), p(L.cov3d), p(L.radii), p(L.conics), p(L.comp), field(4),
               field(9) if use_depth else null, field(6), null, fptr(opacity), field(3), c_int(GRAD_RECORD), fptr(v_mean),

@@ -158,6 +158,14 @@ int gol_bin_sort(int B, int N, const float* xys, const float* depths, const int3
  *   v_sign[B,H,W] (NULL = none; v_sign_mask[B,v_sign_mask_c,H,W] or NULL = 1; v_img_scale device scalar, NULL = 1), so
  *   passing v_sign = l1_sign, v_sign_mask = l1_mask, v_img_scale = d loss_total / d l1 / (B*3*H*W) back-propagates the
  *   loss without the two extra passes over the image a separate loss kernel needs; at least one of v_out_img / v_sign.
+ * pixels_per_lane (fwd and bwd): the wave footprint.  2 = two waves per 16x16 tile, 16x8 pixels each, two pixels per lane
+ *   (fewest instructions per pixel: launches that fill the chip); 1 = four waves per tile, 8x8 pixels each (~9-17 % more
+ *   instructions, but a tile's work is spread over more SIMDs: launches of one or two views, whose workgroups are all
+ *   resident at once and which last until the most loaded SIMD is done);
+ *   0 = the forward chooses by B (gol_raster_plan), the backward takes 2.  Same images, final_T / final_idx and gradients
+ *   either way (a footprint only skips entries none of its pixels can take), up to the summation order of the gradient atomics.
+ *   In the fused path (planar = 1) final_idx / l1_sign of pixels in tiles WITHOUT list entries are not written (the
+ *   backward never reads them; final_T = 1 is).
  * ---------------------------------------------------------------------------------------- */
 #define GOL_GRAD_RECORD 16
 #define GOL_SPLAT_RECORD 16
@@ -168,14 +176,16 @@ int gol_rasterize_fwd(int B, int N, int img_h, int img_w, int block, int planar,
                       const float* background, float* out_img,
                       float* out_extra, float* final_Ts, int32_t* final_idx, float* out_alpha,
                       float* out_extra_norm, float norm_lo, const float* l1_target, const float* l1_mask, int l1_mask_c,
-                      uint8_t* l1_sign, float* l1_partial, void* stream);
+                      uint8_t* l1_sign, float* l1_partial, int pixels_per_lane, void* stream);
 int gol_rasterize_bwd(int B, int N, int img_h, int img_w, int block, int planar, const int32_t* tile_bins,
                       const int32_t* sorted_ids, int64_t capacity, const float* records, int with_extra,
                       const float* background, const float* final_Ts,
                       const int32_t* final_idx, const float* v_out_img, const float* v_out_extra,
                       const float* v_out_alpha, float* v_xy, float* v_conic, float* v_colors,
                       float* v_extra, float* v_opacity, int grad_stride, const uint8_t* v_sign, const float* v_sign_mask,
-                      int v_sign_mask_c, const float* v_img_scale, void* stream);
+                      int v_sign_mask_c, const float* v_img_scale, int pixels_per_lane, void* stream);
+/* What pixels_per_lane = 0 means for the forward of a launch of B views (1 for B <= 2, else 2). */
+int gol_raster_plan(int B, int* fwd_pixels_per_lane);
 
 /* ------------------------------------------------------------------------------------------
  * One render direction of a batch of views as ONE call (csrc/render.hip): what AutoEncoder.render issues per view from

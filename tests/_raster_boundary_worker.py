@@ -22,6 +22,9 @@ def rel(a, b):
     return float((a - b).norm() / b.norm().clamp(min=1e-30))
 
 
+PPL = int(os.environ.get("RASTER_BOUNDARY_PPL", "2"))   # wave footprint of the raster kernels (include/goliath_hip.h)
+
+
 def main(n_views):
     import bench
     from goliath_amd import _lib, splat
@@ -34,7 +37,7 @@ def main(n_views):
     cref.set_threads(min(32, os.cpu_count() or 1))
     torch.set_num_threads(min(32, os.cpu_count() or 1))
     dev = torch.device("cuda")
-    rep = {"lib": os.path.basename(_lib.LIB_PATH), "views": n_views, "gaussians": N, "image": [H, W]}
+    rep = {"lib": os.path.basename(_lib.LIB_PATH), "pixels_per_lane": PPL, "views": n_views, "gaussians": N, "image": [H, W]}
     acc = {k: [0.0, 0.0] for k in ("v_xy", "v_conic", "v_colors", "v_opacity", "v_depth")}   # [err^2, ref^2]
     out_err = {"rgb": 0.0, "alpha": 0.0, "depth_norm": 0.0}
     flips = n_isect_hip = n_isect_orc = 0
@@ -83,7 +86,7 @@ def main(n_views):
                       iptr(ws.tile_bins), iptr(ws.sorted_ids), c_i64(ws.capacity), fptr(records), c_int(1),
                       fptr(bgd), fptr(out_img), fptr(None), fptr(fT), iptr(fidx), fptr(alpha),
                       fptr(dnorm), c_float(0.05), fptr(d_tgt), fptr(None), c_int(0), ptr(sign, torch.uint8), fptr(part),
-                      stream_ptr())
+                      c_int(PPL), stream_ptr())
             rec = torch.zeros(1, N, 16, device=dev)
             field = lambda k: ctypes.c_void_p(rec.data_ptr() + 4 * k)
             vsc = torch.full((1,), scale, device=dev)
@@ -91,7 +94,7 @@ def main(n_views):
                       iptr(ws.tile_bins), iptr(ws.sorted_ids), c_i64(ws.capacity), fptr(records), c_int(0),
                       fptr(bgd), fptr(fT), iptr(fidx), fptr(None), fptr(None), fptr(None),
                       field(4), field(6), field(0), fptr(None), field(3), c_int(16), ptr(sign, torch.uint8), fptr(None),
-                      c_int(0), fptr(vsc), stream_ptr())
+                      c_int(0), fptr(vsc), c_int(PPL), stream_ptr())
             torch.cuda.synchronize()
             n_isect_hip += int(ws.n_isect[0])
             Th = fT[0].cpu()

@@ -29,8 +29,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 TOL = 1e-4  # north_star: within 1e-4 L2
 
 
-def _run(lib, views=2):
-    env = dict(os.environ)
+def _run(lib, views=2, ppl=2):
+    env = dict(os.environ, RASTER_BOUNDARY_PPL=str(ppl))
     if lib:
         env["GOLIATH_HIP_LIB"] = lib
     else:
@@ -49,18 +49,24 @@ def test_raster_boundary_all_gaussians_within_1e5_product_and_exact_math_builds(
     assert os.path.exists(exact), "build the test-only twin first: python -m goliath_amd.build --exact"
     rep_exact = _run(exact)
     rep_fast = _run(None)
+    # round 4: the one-pixel-per-lane footprint (4 waves per tile; the forward of launches of one or two views) -- same bar
+    rep_fast1 = _run(None, ppl=1)
+    rep_exact1 = _run(exact, views=1, ppl=1)
     out_dir = os.path.join(ROOT, "gpurun_out")
     if os.path.isdir(out_dir):
-        json.dump({"exact_math_build": rep_exact, "product_build": rep_fast},
+        json.dump({"exact_math_build": rep_exact, "product_build": rep_fast, "product_build_1px_per_lane": rep_fast1,
+                   "exact_math_build_1px_per_lane": rep_exact1},
                   open(os.path.join(out_dir, "exact_math_parity.json"), "w"), indent=1)
-    print("\nEXACT", json.dumps(rep_exact), "\nFAST", json.dumps(rep_fast))
+    print("\nEXACT", json.dumps(rep_exact), "\nFAST", json.dumps(rep_fast), "\nFAST 1px", json.dumps(rep_fast1))
+    assert rep_fast1["pixels_per_lane"] == 1 and rep_fast["pixels_per_lane"] == 2
     assert rep_exact["lib"] == "libgoliath_hip_exact.so" and rep_fast["lib"] == "libgoliath_hip.so"
     n_pix = rep_exact["views"] * rep_exact["image"][0] * rep_exact["image"][1]
     # exact build: the decisions coincide (allow the odd last-bit difference of the two exp implementations)
     assert rep_exact["flip_pixels"] <= 4, rep_exact["flip_pixels"]
     # product build: a handful of pixels more
     assert rep_fast["flip_pixels"] <= 1e-5 * n_pix, rep_fast["flip_pixels"]
-    for rep in (rep_exact, rep_fast):   # identical inputs: every output and gradient, ALL Gaussians, 10x inside 1e-4
+    assert rep_exact1["flip_pixels"] <= 4 and rep_fast1["flip_pixels"] <= 1e-5 * n_pix
+    for rep in (rep_exact, rep_fast, rep_fast1, rep_exact1):   # identical inputs: every output and gradient, ALL Gaussians, 10x inside 1e-4
         for k, v in rep["outputs_rel_l2"].items():
             assert v < 0.1 * TOL, (rep["lib"], k, v)
         for k, v in rep["raster_boundary_grads_rel_l2_all_gaussians"].items():
