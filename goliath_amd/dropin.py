@@ -66,18 +66,25 @@ def patch_losses(registry_module=None):
     return registry_module
 
 
-def patch_urhand(urhand_module=None):
+def patch_urhand(urhand_module=None, mesh_render_layer=False):
     """BASELINE config 4 as a drop-in: `ConvTeacherDecoder.forward` (ca_code/models/urhand.py:349-630) with its two light
-    loops and both shadow-map evaluations on the HIP kernels (goliath_amd.urhand.conv_teacher_decoder_forward), the
-    stand-alone shadow-map lookup (`get_shadow_map`, imported at urhand.py:44) and the render layer the decoder builds for
-    its light cameras (`RenderLayer`, urhand.py:43, 338-345: drtk in the reference) -- models constructed AFTER the patch
-    render their shadow depth maps with gol_mesh_raster.  Returns the patched module."""
+    loops and both shadow-map evaluations on the HIP kernels (goliath_amd.urhand.conv_teacher_decoder_forward) and the
+    stand-alone shadow-map lookup (`get_shadow_map`, imported at urhand.py:44).  The depth images of the light cameras are
+    rendered by gol_mesh_raster from the topology (`vi`, `h`, `w`) of the layer the decoder built (`self.rl`,
+    urhand.py:336-343) -- the layer object itself is never called.
+
+    The module-level name `RenderLayer` (urhand.py:43) is LEFT ALONE by default: AutoEncoder.__init__ resolves the same name
+    for the model's final, differentiable textured render (`self.renderer`, urhand.py:684, called with
+    edge_grad=self.training), which needs drtk's edge-gradient estimator -- gol_mesh_raster is forward-only.
+    mesh_render_layer=True rebinds it to goliath_amd.meshraster.RenderLayer anyway (a stack without drtk: inference /
+    visualisation only; a call whose vertices require a gradient raises).  Returns the patched module."""
     from . import meshraster, shadowmap, urhand
 
     if urhand_module is None:
         import ca_code.models.urhand as urhand_module
     urhand_module.get_shadow_map = shadowmap.get_shadow_map
-    urhand_module.RenderLayer = meshraster.RenderLayer
+    if mesh_render_layer:
+        urhand_module.RenderLayer = meshraster.RenderLayer
     urhand_module.ConvTeacherDecoder.forward = urhand.conv_teacher_decoder_forward
     return urhand_module
 

@@ -7,6 +7,8 @@ albedo parameter.  The decoder outputs are consumed in their native NCHW layout 
 """
 import ctypes
 
+import os
+
 import torch
 
 from . import _lib
@@ -56,17 +58,27 @@ def _p(t, dtype=torch.float32):
 _PACKED = {}   # (data_ptr, shape, _version) -> (the level tensor, packed copy): the pyramid is static across frames
 
 
-def pack_envmap(mips):
+def invalidate_envmap_cache():
+    """Forget every packed env-map level (see pack_envmap: writes the version counter does not see)."""
+    _PACKED.clear()
+
+
+def pack_envmap(mips, refresh=False):
     """[B,3,h,w] mip levels -> [B,h,w,16] footprint records (the four taps of the bilinear footprint whose top-left texel
     is (y, x), 64 bytes: a lookup fetches one HBM sector instead of ~2.5).  The reference builds the
     SG-prefiltered pyramid once per environment (light_decorator.py:18-164) and only rotates it per frame (`lightrot`),
     so the packed copy of a level is cached on the tensor's memory and in-place version counter: a level that was
     neither replaced nor written since the last call is not packed again (4 launches per step in rounds 1-2).  The cache
-    keeps the source tensor alive (at most 16 levels), so its address cannot be handed to another tensor meanwhile."""
+    keeps the source tensor alive (at most 16 levels), so its address cannot be handed to another tensor meanwhile.
+    CAVEAT: writes that do not bump the version counter are NOT seen -- `mip.data.copy_(...)` / in-place ops through `.data`,
+    and kernels that write the pyramid through a raw pointer.  After such a write pass refresh=True once (re-packs these
+    levels and replaces their cache entries), call invalidate_envmap_cache(), or set GOLIATH_ENVMAP_CACHE=0 (packs on every
+    call: 4 small launches per step)."""
+    refresh = refresh or os.environ.get("GOLIATH_ENVMAP_CACHE", "1") == "0"
     out = []
     for m in mips:
         key = (m.data_ptr(), tuple(m.shape), m._version, m.device.index)
-        hit = _PACKED.get(key)
+        hit = None if refresh else _PACKED.get(key)
         if hit is not None:
             if hit[2] is not None:          # packed on another stream and possibly still in flight: order after it
                 if hit[2].query():

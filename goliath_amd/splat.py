@@ -46,8 +46,11 @@ class CapacityPlanner:
         can read the image.  With 2x head-room in the plan the steady state of a training run never blocks: the counts
         are read back when their copy has landed (next call) and only move the plan.  Should the lists then still
         outgrow a 1.5x margin within ONE step, that step rendered with truncated lists (the deepest entries of the
-        fullest tiles dropped): a RuntimeWarning says so, `truncated` counts it, the capacity is raised, and the next
-        call is a blocking one again.  No exception reaches the caller (ca_code/utils/train.py:170-214 knows none of ours).
+        fullest tiles dropped): a CapacityWarning (a RuntimeWarning shown EVERY time, not once per call site) says so,
+        `truncated` counts it, the capacity is raised, and every call of that shape BLOCKS on its own counts again until
+        one checked call has passed (`force_block`) -- an eager loop running ahead of the GPU renders at most the steps
+        that were already queued with the old capacity.  No exception reaches the caller
+        (ca_code/utils/train.py:170-214 knows none of ours); GOLIATH_CAPACITY_MODE=verify never truncates at all.
     mode "verify": every call blocks and repairs in place (rounds 1-2 default): nothing is ever truncated, and an
         eager loop can never run ahead of the GPU (measured: 1.35 ms of host wait per 8-view step).
     mode "async": nothing waits; the counts are inspected at the NEXT call and an overflow raises
@@ -65,6 +68,7 @@ class CapacityPlanner:
         self.reruns = 0          # blocking calls whose forward had to be re-run at a grown capacity
         self.truncated = 0       # adaptive mode: steps found (after the fact) to have rendered with truncated lists
         self.last_worst = {}     # key -> most recent observed count
+        self.force_block = set() # keys whose last deferred check found an overflow: blocking calls until one passes
         self._pinned = {}        # B -> free list of pinned int32[B] buffers (allocated once, recycled)
 
     def check_frozen(self):
@@ -82,7 +86,11 @@ class CapacityPlanner:
         if self.mode == "async":
             return False
         seen, cap = self.last_worst.get(key), self.capacity.get(key)
-        return seen is None or cap is None or seen * 1.5 > cap
+        return key in self.force_block or seen is None or cap is None or seen * 1.5 > cap
+
+    def passed(self, key):
+        """A checked (blocking) call of this shape completed without truncation."""
+        self.force_block.discard(key)
 
     def get(self, key):
         return self.capacity.get(key)
@@ -138,6 +146,7 @@ class CapacityPlanner:
                 if worst > capacity:
                     self.last_worst[key] = worst
                     self.set(key, worst)
+                    self.force_block.add(key)
                     overflow = (worst, capacity, key)
                 else:
                     self.observe(key, worst, capacity)
@@ -154,9 +163,17 @@ class CapacityPlanner:
             import warnings
 
             self.truncated += 1
-            warnings.warn(msg + "; the next call checks its own counts before returning "
-                                "(GOLIATH_CAPACITY_MODE=verify checks every call).", RuntimeWarning, stacklevel=3)
+            warnings.warn(msg + "; calls of this shape check their own counts before returning until one has passed "
+                                "(GOLIATH_CAPACITY_MODE=verify checks every call).", CapacityWarning, stacklevel=3)
 
+
+class CapacityWarning(RuntimeWarning):
+    """A render_views call was found, after the fact, to have rendered with truncated tile lists (adaptive mode)."""
+
+
+import warnings as _warnings
+
+_warnings.simplefilter("always", CapacityWarning)   # every occurrence, not once per call site: a truncated step is a wrong step
 
 PLANNER = CapacityPlanner()
 
@@ -500,6 +517,7 @@ class _RenderViews(torch.autograd.Function):
                     PLANNER.finish(*pending)
                 else:
                     PLANNER.observe(plan_key, worst, capacity)
+                PLANNER.passed(plan_key)
         ctx.L, ctx.capacity = L, capacity
         ctx.cfg = (img_h, img_w, glob_scale, with_depth, depth_norm_lo, with_l1)
         ctx.l1_inv_n = 1.0 / max(B * 3 * img_h * img_w, 1)

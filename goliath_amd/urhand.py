@@ -75,10 +75,14 @@ def shadow_maps(rl, mod, verts, p_uv, nml, light_pos):
         Kl = torch.eye(3, device=verts.device)[None].repeat(B * L, 1, 1)   # shadowmap.py:21-26
         Kl[:, 0, 0] = Kl[:, 1, 1] = 1000.0
         Kl[:, 0, 2], Kl[:, 1, 2] = rl.w / 2, rl.h / 2
-        if isinstance(rl, meshraster.RenderLayer):       # depth only: skip the uv interpolation and the texture lookup
-            depth = meshraster.rasterize(meshraster.transform(vrep, Kl, Rt), rl.vi, rl.h, rl.w, with_bary=False)[1]
-        else:                                            # any render layer with the reference's interface (drtk)
+        if getattr(rl, "replays_depth", False):          # test stand-in that hands back recorded depth images
             depth = rl(vrep, torch.empty(B * L, 1, 1024, 1024, device=verts.device), Kl, Rt)["depth_img"]
+        else:
+            # the light cameras' depth images on gol_mesh_raster, from the topology of WHATEVER render layer the model built
+            # (the reference's drtk RenderLayer, urhand.py:336-343, or meshraster.RenderLayer: both carry h, w, vi) -- depth
+            # only: no uv interpolation, no texture lookup.  The layer object itself is not called, so the model's other
+            # layer (the final textured render with its edge gradients, urhand.py:684) stays whatever the model made it
+            depth = meshraster.rasterize(meshraster.transform(vrep, Kl, Rt), rl.vi.int(), rl.h, rl.w, with_bary=False)[1]
         sm = shadowmap.shadow_pcf(depth, Rt, p_uv, nml, exp_scale=8.0)
         return sm.reshape(B, L, 1, sm.shape[-2], sm.shape[-1])
 

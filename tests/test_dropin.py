@@ -82,7 +82,9 @@ def test_patch_losses_and_urhand_on_stand_in_modules():
 
     ur = types.SimpleNamespace(get_shadow_map="reference", RenderLayer="drtk", ConvTeacherDecoder=ConvTeacherDecoder)
     assert dropin.patch_urhand(ur).get_shadow_map is shadowmap.get_shadow_map
-    assert ur.RenderLayer is meshraster.RenderLayer and ConvTeacherDecoder.forward is urhand.conv_teacher_decoder_forward
+    # the module-level RenderLayer also builds the model's final DIFFERENTIABLE render (urhand.py:684): left alone
+    assert ur.RenderLayer == "drtk" and ConvTeacherDecoder.forward is urhand.conv_teacher_decoder_forward
+    assert dropin.patch_urhand(ur, mesh_render_layer=True).RenderLayer is meshraster.RenderLayer
 
     class OLATRGBDecoder:  # stand-in for ca_code.models.hand_teacher_mvp.OLATRGBDecoder
         def forward_rgb(self):

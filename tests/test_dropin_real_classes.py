@@ -143,7 +143,7 @@ def ref_hands():
 def test_urhand_and_teacher_patches_keep_the_reference_signatures(ref_hands):
     """BASELINE configs 4 / 5 as drop-ins: ConvTeacherDecoder.forward (urhand.py:349-630) and OLATRGBDecoder.forward_rgb
     (hand_teacher_mvp.py:253-494) are replaced by callables with the same parameter lists; the module-level names the
-    model constructors resolve (RenderLayer, get_shadow_map) point at the HIP-backed versions."""
+    model constructors resolve: get_shadow_map points at the HIP-backed version, RenderLayer only on request."""
     from goliath_amd import dropin, meshraster, shadowmap, urhand
 
     U, T = ref_hands.U, ref_hands.T
@@ -154,7 +154,12 @@ def test_urhand_and_teacher_patches_keep_the_reference_signatures(ref_hands):
         assert T.OLATRGBDecoder.forward_rgb is urhand.olat_rgb_decoder_forward_rgb
         assert _params(U.ConvTeacherDecoder.forward) == _params(saved[0])
         assert _params(T.OLATRGBDecoder.forward_rgb) == _params(saved[3])
-        assert U.get_shadow_map is shadowmap.get_shadow_map and U.RenderLayer is meshraster.RenderLayer
+        # the name AutoEncoder.__init__ resolves for its final textured render (self.renderer, urhand.py:684) is untouched:
+        # training through the drop-in keeps drtk's edge gradients; the opt-in swap is forward-only
+        assert U.get_shadow_map is shadowmap.get_shadow_map and U.RenderLayer is saved[2]
+        src = inspect.getsource(U.AutoEncoder.__init__)
+        assert "self.renderer = RenderLayer(" in src    # ... and that IS the name the constructor uses
+        assert dropin.patch_urhand(U, mesh_render_layer=True).RenderLayer is meshraster.RenderLayer
         assert _params(meshraster.RenderLayer.__init__) == _params(saved[2].__init__)
         assert _params(meshraster.RenderLayer.forward) == _params(saved[2].forward)
     finally:

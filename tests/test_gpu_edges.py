@@ -150,11 +150,20 @@ def test_adaptive_capacity_mode_blocks_only_when_it_matters():
         truncated0 = splat.PLANNER.truncated
         splat.render_views(**big, img_h=H, img_w=W)
         torch.cuda.synchronize()
-        with warnings.catch_warnings(record=True) as w:
-            warnings.simplefilter("always")
-            out = splat.render_views(**big, img_h=H, img_w=W)     # ... but by the next one: warning, bigger plan, checked call
-        assert any(issubclass(x.category, RuntimeWarning) for x in w)
+        blocked = []
+        must_block0 = splat.PLANNER.must_block
+        splat.PLANNER.must_block = lambda k: (blocked.append(must_block0(k)), blocked[-1])[1]
+        try:
+            with warnings.catch_warnings(record=True) as w:
+                out = splat.render_views(**big, img_h=H, img_w=W)     # ... but by the next one: warning, bigger plan, checked call
+        finally:
+            del splat.PLANNER.must_block
+        assert any(issubclass(x.category, splat.CapacityWarning) for x in w)   # shown every time (module-level "always" filter)
         assert splat.PLANNER.truncated == truncated0 + 1
+        # the call that found the overflow (and every later one until a checked call passed) BLOCKS, although
+        # the freshly raised plan has 2x head-room again
+        assert blocked == [True] and key not in splat.PLANNER.force_block
+        assert not splat.PLANNER.must_block(key)                  # ... after which the steady state resumes
         full = splat.render_views(**big, img_h=H, img_w=W, capacity=int(out["n_isect"].max()) + 16)
         assert torch.equal(out["render"], full["render"])
     finally:
@@ -179,8 +188,8 @@ def test_ragged_image_sizes_match_oracle(H, W):
     _, ids, bins = cref.bin_and_sort(xys, depths, radii, nth, H, W, 16)
     ref, ref_T, _ = cref.rasterize_forward(ids, bins, xys, conics, s["colors"], s["opacity"][:, 0] * comp, H, W, 16,
                                            torch.zeros(3))
-    assert rel_l2(out["render"].permute(1, 2, 0), ref) < 1e-4
-    assert rel_l2(1 - out["alpha"][0], ref_T) < 1e-4
+    assert rel_l2(out["render"].permute(1, 2, 0), ref) < 2e-5   # measured 1.3e-6
+    assert rel_l2(1 - out["alpha"][0], ref_T) < 2e-6           # measured 1.5e-7
 
 
 def test_batch_with_an_empty_view():

@@ -22,6 +22,9 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 TOL = 1e-4           # north_star: within 1e-4 L2 -- outputs AND gradients
+# all-Gaussian cap on every gradient tensor incl. its explained outliers (measured: config 2 <= 1.25e-3; config 1, 10 k
+# Gaussians, <= 2.75e-2 -- all of it from 8 Gaussians under flip pixels)
+ALL_CAP = {"config2": 3e-3, "config1": 5e-2}
 MAX_EXPLAINED = 2e-3  # at most this fraction of the Gaussians may need an explanation (measured: ~1e-4)
 LEAVES = ("f_vn", "f_vc", "postex", "tn", "albedo")
 STAGE = ("color", "opacity", "primpos", "primscale", "primqvec")
@@ -221,7 +224,7 @@ def test_bench_step_matches_oracle_chain(name):
     N = cfg["gaussians"]
     ex = {k: torch.stack(v).flatten() for k, v in explained.items()}             # [B*N]
     ex_raster = ex["flip"]
-    ex_any = ex["flip"] | ex["border"] | ex["pole"] | ex["kink"]
+    ex_any = ex["flip"] | ex["border"] | ex["kink"]      # (pole: only together with the fp64 yardstick, see judge)
     report["outputs"] = worst
     report["flip_pixel_fraction"] = flips / (B * H * W)
     report["flip_pixels"] = flips
@@ -232,15 +235,40 @@ def test_bench_step_matches_oracle_chain(name):
     report["tolerance"] = TOL
     failures = []
 
-    def judge(kind, k, a, b, allowed, b64=None):
-        """a, b: [B, C, N].  Remove the smallest worst set W that brings the rest under TOL; every member must be explained."""
+    def judge(kind, k, a, b, allowed, b64=None, pole=None):
+        """a, b: [B, C, N].  Remove the smallest worst set W that brings the rest under TOL; every member must be explained.
+        ADVICE r3: position alone (`pole`, 2 % of all directions) excuses nothing -- near-pole members of W are explained only
+        while HIP is as close to the fp64 evaluation over the WHOLE near-pole class as the fp32 oracle is; and an
+        all-Gaussian cap bounds what the explained outliers may add up to."""
         W_idx, all_rel, rest_rel = _worst_set(a, b, TOL)
         by = {kk: int(ex[kk][W_idx].sum()) for kk in ex}
+        allowed_in = allowed
         if b64 is not None:   # fp64 predicate: the fp32 oracle's own distance from its fp64 evaluation, per Gaussian
             e_h = (a.double().cpu() - b.double().cpu()).pow(2).sum(1).flatten()
             e_o = (b.double().cpu() - b64.double().cpu()).pow(2).sum(1).flatten()
             fp64 = e_o >= 0.0625 * e_h
             allowed = allowed | fp64
+            if pole is not None:
+                # near the poles BOTH fp32 evaluations are ill-conditioned (1 - r_y^2 cancels: the derivative of acos / atan2
+                # carries a relative error of 6e-8 / (1 - r_y^2)), and which of the two lands further from fp64 on ONE
+                # Gaussian is chance -- so the yardstick is taken over the whole class: HIP's distance from the fp64 evaluation
+                # over ALL near-pole Gaussians, relative to the fp32 oracle's.  Measured (profiles/r04_parity_ledger.json):
+                # 3.6x at config 2 (2.5e-5 vs 7.0e-6 of the tensor's norm over 12.9 k Gaussians), 2.1x at config 1 -- HIP's
+                # reflection direction carries 2-3 more roundings than torch's (reciprocal-multiply normalisations), which
+                # the (1 - r_y^2)^-3/2 conditioning magnifies; in absolute terms the class stays 4x under the 1e-4 bar.  The
+                # tripwire is 5x: a regression of the shade backward confined to near-pole directions inflates the ratio
+                # and un-explains every pole member of W.
+                # (class = near-pole Gaussians that no other predicate touches: a flip pixel under a near-pole Gaussian changes
+                # HIP's UPSTREAM gradient, which the fp64 evaluation -- fed the oracle's upstream -- does not see)
+                e_h64 = (a.double().cpu() - b64.double().cpu()).pow(2).sum(1).flatten()
+                pure = pole & ~allowed_in
+                hip_vs_64, orc_vs_64 = float(e_h64[pure].sum().sqrt()), float(e_o[pure].sum().sqrt())
+                class_ok = hip_vs_64 <= 5.0 * orc_vs_64 + 1e-30
+                report.setdefault("pole_class_vs_fp64", {})[k] = {"hip": hip_vs_64, "fp32_oracle": orc_vs_64,
+                                                                   "gaussians": int(pure.sum()), "ok": bool(class_ok)}
+                if class_ok:
+                    allowed = allowed | pole
+                by["pole_class_yardstick_ok"] = int(class_ok)
             by["fp64"] = int(fp64[W_idx].sum())
             report.setdefault("fp32_oracle_vs_fp64_oracle_rel_l2", {})[k] = float(
                 (e_o.sum() / b64.double().pow(2).sum()).sqrt())
@@ -260,7 +288,7 @@ def test_bench_step_matches_oracle_chain(name):
                     info.update({kk: float(vv[g]) for kk, vv in view_diag[vb].items()})
                 det.append(info)
             report[kind][k]["unexplained_examples"] = det
-        if unexplained or rest_rel > TOL or W_idx.numel() > MAX_EXPLAINED * B * N:
+        if unexplained or rest_rel > TOL or W_idx.numel() > MAX_EXPLAINED * B * N or all_rel > ALL_CAP[name]:
             failures.append((kind, k, report[kind][k]))
 
     for b in range(B):   # per-Gaussian relative error of the stage gradients (diagnostics of the leaf outliers)
@@ -277,12 +305,12 @@ def test_bench_step_matches_oracle_chain(name):
             ref = torch.stack(ref_grads[k]).sum(0)                                              # [1, N, 3]
             ref64 = torch.stack(ref_grads64[k]).sum(0)
             judge("grads", k, mb[k].grad.reshape(1, N, 3).transpose(1, 2), ref.reshape(1, N, 3).transpose(1, 2),
-                  ex_any.reshape(B, N).any(0), ref64.reshape(1, N, 3).transpose(1, 2))
+                  ex_any.reshape(B, N).any(0), ref64.reshape(1, N, 3).transpose(1, 2), ex["pole"].reshape(B, N).any(0))
             report["grads"][k]["W_fraction"] = report["grads"][k]["W_size"] / N
             continue
         ref = torch.cat(ref_grads[k], 0)
         judge("grads", k, mb[k].grad.reshape(B, -1, N), ref.reshape(B, -1, N), ex_any,
-              torch.cat(ref_grads64[k], 0).reshape(B, -1, N))
+              torch.cat(ref_grads64[k], 0).reshape(B, -1, N), ex["pole"])
     print(f"\nCHAIN_PARITY {name} " + json.dumps(report))
     out_dir = os.path.join(ROOT, "gpurun_out")
     if os.path.isdir(out_dir):
@@ -291,6 +319,9 @@ def test_bench_step_matches_oracle_chain(name):
     assert abs(loss - ref_loss) < 1e-5 * abs(ref_loss)
     for k in ("rgb", "alpha", "depth_without_flip_pixels"):
         assert worst[k] < TOL, (k, worst[k])
-    assert worst["depth"] < 3e-4, worst["depth"]   # incl. the flip pixels: depth / clamp(alpha, .05, 1) amplifies them 20x
+    # depth / clamp(alpha, .05, 1): under the flip predicate -- without the flip pixels (a few hundred of 10.9 M, asserted
+    # < 1e-3 of the image below) it is 1.2e-6; with them 1.03e-4 (the division amplifies a flipped list 20x)
+    assert worst["depth_without_flip_pixels"] < 2e-5, worst["depth_without_flip_pixels"]
+    assert worst["depth"] < 1.5e-4, worst["depth"]
     assert report["flip_pixel_fraction"] < 1e-3, report["flip_pixel_fraction"]  # expected << 0.1 %
     assert not failures, failures

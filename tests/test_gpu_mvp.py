@@ -25,11 +25,11 @@ def test_mvp_matches_reference_golden(tag):
                           G[f"{tag}/tminmax"].cuda(), (leaf["primpos"] * 0.3, leaf["primrot"].contiguous(),
                                                        torch.exp(0.1 * leaf["primscale"])),
                           template, None, fadescale=fs, fadeexp=fe, accum=0)
-    assert rel_l2(out, G[f"{tag}/rayrgba"]) < 1e-4, rel_l2(out, G[f"{tag}/rayrgba"])
+    assert rel_l2(out, G[f"{tag}/rayrgba"]) < 2e-6, rel_l2(out, G[f"{tag}/rayrgba"])   # measured 1.7e-7
     out.backward(torch.ones_like(out))
     for k in leaf:
         e = rel_l2(leaf[k].grad, G[f"{tag}/grad_{k}"])
-        assert e < 3e-4, (k, e)
+        assert e < 2e-5, (k, e)   # measured 1.8e-6 (sums of float atomics)
 
 
 def _random_case(N, H, W, K, T, seed, step=0.05):
@@ -97,9 +97,9 @@ def test_mvp_vs_oracle_with_shadow(N, H, W, K, T, fe):
                                                case["primrot"], case["primscale"], case["template"], 6.5, fe,
                                                with_shadow=True)
     assert float(ref[..., 3].max()) > 0.2
-    assert rel_l2(out, ref) < 1e-4, rel_l2(out, ref)
+    assert rel_l2(out, ref) < 3e-6, rel_l2(out, ref)   # measured 3.1e-7
     ref_sh = ref_shadow[..., 0:1] / (ref_shadow[..., 1:] + 1e-5)
-    assert rel_l2(shadow, ref_sh) < 1e-3
+    assert rel_l2(shadow, ref_sh) < 4e-5   # measured 3.7e-6
     gen = torch.Generator().manual_seed(1)
     go = torch.randn(out.shape, generator=gen)
     out.backward(go.cuda())
@@ -107,7 +107,7 @@ def test_mvp_vs_oracle_with_shadow(N, H, W, K, T, fe):
                                        case["primscale"], case["template"], raysat, go, 6.5, fe)
     for k, g in (("primpos", gp), ("primrot", gr), ("primscale", gs), ("template", gt)):
         e = rel_l2(leaf[k].grad, g)
-        assert e < 3e-4, (k, e)
+        assert e < 2e-5, (k, e)   # measured 1.4e-6
 
 
 def test_mvp_far_from_the_origin_with_a_small_step():
@@ -134,7 +134,7 @@ def test_mvp_far_from_the_origin_with_a_small_step():
                                       case["primscale"], case["template"], 6.5, 8.0)
     assert float(ref[..., 3].max()) > 0.2
     # positions carry ~1e-5 of absolute rounding here (ulp of 60), i.e. ~3e-4 of a voxel: looser than at the origin
-    assert rel_l2(out, ref) < 2e-3, rel_l2(out, ref)
+    assert rel_l2(out, ref) < 4e-5, rel_l2(out, ref)   # measured 3.3e-6
     gen = torch.Generator().manual_seed(1)
     go = torch.randn(out.shape, generator=gen)
     out.backward(go.cuda())
@@ -142,7 +142,7 @@ def test_mvp_far_from_the_origin_with_a_small_step():
                                        case["primscale"], case["template"], raysat, go, 6.5, 8.0)
     for k, g in (("primscale", gs), ("template", gt)):
         e = rel_l2(leaf[k].grad, g)
-        assert e < 5e-3, (k, e)
+        assert e < 1e-4, (k, e)   # measured 8.4e-6
 
 
 def test_mvp_warp_fields_match_reference_golden():
@@ -157,11 +157,11 @@ def test_mvp_warp_fields_match_reference_golden():
     out = mvp.mvpraymarch(G["w/raypos"].cuda(), G["w/raydir"].cuda(), float(G["w/stepsize"]), G["w/tminmax"].cuda(),
                           (leaf["primpos"] * 0.3, leaf["primrot"].contiguous(), torch.exp(0.1 * leaf["primscale"])),
                           template, warp, algo=1, fadescale=fs, fadeexp=fe, accum=0)
-    assert rel_l2(out, G["w/rayrgba"]) < 1e-4, rel_l2(out, G["w/rayrgba"])
+    assert rel_l2(out, G["w/rayrgba"]) < 2e-6, rel_l2(out, G["w/rayrgba"])   # measured 1.8e-7
     out.backward(torch.ones_like(out))
     for k in leaf:
         e = rel_l2(leaf[k].grad, G[f"w/grad_{k}"])
-        assert e < 3e-4, (k, e)
+        assert e < 2e-5, (k, e)   # measured 1.2e-6
 
 
 @pytest.mark.parametrize("N,H,W,K,T,WT,amp", [(2, 70, 50, 64, (4, 8, 8), (3, 4, 5), 0.05), (1, 33, 17, 27, (3, 5, 6), (2, 2, 2), 0.6)])
@@ -187,16 +187,16 @@ def test_mvp_warp_fields_vs_oracle_with_shadow(N, H, W, K, T, WT, amp):
                                                case["primrot"], case["primscale"], case["template"], 6.5, 7.5,
                                                with_shadow=True, warp=warp)
     assert float(ref[..., 3].max()) > 0.2
-    assert rel_l2(out, ref) < 1e-4, rel_l2(out, ref)
+    assert rel_l2(out, ref) < 3e-6, rel_l2(out, ref)   # measured 3.1e-7
     ref_sh = ref_shadow[..., 0:1] / (ref_shadow[..., 1:] + 1e-5)
-    assert rel_l2(shadow, ref_sh) < 1e-3
+    assert rel_l2(shadow, ref_sh) < 4e-5   # measured 3.7e-6
     go = torch.randn(out.shape, generator=torch.Generator().manual_seed(1))
     out.backward(go.cuda())
     gp, gr, gs, gt, gw = cref.mvp_backward(rp.cpu(), rd.cpu(), case["step"], tm.cpu(), case["primpos"], case["primrot"],
                                            case["primscale"], case["template"], raysat, go, 6.5, 7.5, warp=warp)
     for k, gref in (("primpos", gp), ("primrot", gr), ("primscale", gs), ("template", gt), ("warp", gw)):
         e = rel_l2(leaf[k].grad, gref)
-        assert e < 3e-4, (k, e)
+        assert e < 2e-5, (k, e)   # measured 1.4e-6
 
 
 def test_raymarcher_wrapper_and_errors():
@@ -248,7 +248,7 @@ def test_light_batched_shadow_march_equals_per_light_copies():
                                               fadescale=6.5, fadeexp=8.0, with_shadow=True)
     assert shadow.shape == ref_shadow.shape == (B * L, K, *T, 1)
     assert float(ref_shadow.max()) > 0.1
-    assert rel_l2(shadow, ref_shadow) < 1e-5, rel_l2(shadow, ref_shadow)
+    assert rel_l2(shadow, ref_shadow) < 1e-6, rel_l2(shadow, ref_shadow)   # measured 7e-8
     assert rel_l2(img[..., 3], ref_img[..., 3]) < 1e-6
     with pytest.raises(ValueError):
         mvp.shadow_march(rp, rd, case["step"], tm, prims, c(alpha), L + 1)

@@ -54,7 +54,7 @@ def test_prim_decoder_forward_dropin(tag):
         c("light_sh"), c("n_lights"), [c(f"mip{i}") for i in range(4)] if env else None, c("lightrot") if env else None)
     for k, v in preds.items():
         ref = G[f"{tag}/out/{k}"]
-        assert rel_l2(v.reshape(ref.shape), ref) < 1e-4, k
+        assert rel_l2(v.reshape(ref.shape), ref) < 6e-5, k   # measured 6.1e-6
 
 
 def test_autoencoder_render_dropin_and_random_light():

@@ -99,7 +99,7 @@ def test_shade_vs_oracle_4096(env):
     lr.backward()
     lo.backward()
     for k in cpu:
-        assert rel_l2(gpu[k].grad, cpu[k].grad) < 2 * TOL, (k, rel_l2(gpu[k].grad, cpu[k].grad))
+        assert rel_l2(gpu[k].grad, cpu[k].grad) < TOL, (k, rel_l2(gpu[k].grad, cpu[k].grad))   # measured 4.3e-5
 
 
 def test_shade_full_size_linearity_in_light():
@@ -124,3 +124,21 @@ def test_shade_full_size_linearity_in_light():
     assert torch.equal(b["primpos"], a["primpos"]) and torch.equal(b["spec_color"], a["spec_color"])
     assert rel_l2(z["color"], z["spec_color"].clamp(min=0)) < 1e-6
     assert rel_l2(a["primqvec"].norm(dim=-1), torch.ones(B, N)) < 1e-6
+
+
+def test_packed_envmap_cache_and_its_refresh():
+    """shade.pack_envmap caches the footprint records of a level on (address, shape, version counter): a write through
+    `.data` is not seen (documented caveat) until refresh=True / invalidate_envmap_cache()."""
+    from goliath_amd import shade
+
+    m = [torch.rand(1, 3, 8, 16, device="cuda")]
+    a = shade.pack_envmap(m)[0].clone()
+    m[0].data.mul_(2.0)                                   # the version counter of m[0] does not move
+    assert torch.equal(shade.pack_envmap(m)[0], a)        # stale: the caveat
+    fresh = shade.pack_envmap(m, refresh=True)[0]
+    assert torch.allclose(fresh, 2 * a)
+    assert torch.equal(shade.pack_envmap(m)[0], fresh)    # the refreshed copy replaced the cache entry
+    m[0].mul_(0.5)                                        # an ordinary in-place op IS seen
+    assert torch.allclose(shade.pack_envmap(m)[0], a)
+    shade.invalidate_envmap_cache()
+    assert torch.allclose(shade.pack_envmap(m)[0], a)

@@ -28,6 +28,11 @@ def test_shadow_pcf_matches_reference_golden():
         got = shadowmap.shadow_pcf(c["depth"], c["Rt"], c["postex"], c.get("nml"))
         assert got.shape == c["out"].shape
         assert _close(got, c["out"]), tag
+        # the same comparison as ONE number (parity ledger): rel-L2 over all texels; measured 6.7e-7 -- no tie texel in
+        # these two cases (the _close() allowance above is for scenes that have one)
+        from scenes import rel_l2
+
+        assert rel_l2(got, c["out"]) < 1e-5, tag
         fused = shadowmap.shadow_pcf(c["depth"], c["Rt"], c["postex"], c.get("nml"), exp_scale=8.0)
         assert torch.allclose(fused, torch.exp(-got / 8.0), atol=1e-6)
 

@@ -10,7 +10,8 @@ import torch
 from scenes import head_scene, rel_l2
 
 pytestmark = pytest.mark.gpu
-TOL = 1e-4
+TOL = 1e-4      # north_star bar; the per-assertion bars below are ~10x what profiles/r04_parity_ledger.json measured
+TIGHT = 5e-6    # small scenes, identical inputs: measured 3e-8 ... 4e-7
 
 
 def _cuda(s):
@@ -140,8 +141,8 @@ def test_rasterize_forward_backward_vs_oracle(H, W, N):
     op = opac.cuda()[:, None].clone().requires_grad_(True)
     img, alpha = splat.rasterize_gaussians(cx, hip[1], hip[2], cc, hip[5], col, op, H, W, 16, bg.cuda(),
                                            return_alpha=True)
-    assert rel_l2(img, ref_img) < TOL
-    assert rel_l2(1 - alpha, ref_T) < TOL
+    assert rel_l2(img, ref_img) < TIGHT
+    assert rel_l2(1 - alpha, ref_T) < TIGHT
     assert float(alpha.detach().max()) > 0.5
 
     gen = torch.Generator().manual_seed(9)
@@ -150,10 +151,10 @@ def test_rasterize_forward_backward_vs_oracle(H, W, N):
     (img * v_out.cuda()).sum().add((alpha * v_alpha.cuda()).sum()).backward()
     r_xy, r_conic, r_col, r_op = cref.rasterize_backward(ids, bins, xys, conics, s["colors"], opac, H, W, 16, bg,
                                                          ref_T, ref_idx, v_out, v_alpha)
-    assert rel_l2(col.grad, r_col) < TOL
-    assert rel_l2(op.grad, r_op) < TOL
-    assert rel_l2(cx.grad, r_xy) < 5 * TOL  # sums of signed terms: float32 accumulation order differs
-    assert rel_l2(cc.grad, r_conic) < 5 * TOL
+    assert rel_l2(col.grad, r_col) < TIGHT
+    assert rel_l2(op.grad, r_op) < TIGHT
+    assert rel_l2(cx.grad, r_xy) < TIGHT  # (sums of signed terms, float32 accumulation order differs: measured 2.9e-7)
+    assert rel_l2(cc.grad, r_conic) < TIGHT  # measured 3.7e-7
 
 
 def test_rasterize_zero_intersections_quirk():
@@ -188,9 +189,9 @@ def test_project_backward_vs_oracle():
     _, _, r_mean, r_scale, r_quat = cref.project_gaussians_backward(
         s["means"], s["scales"], 1.0, s["quats"], s["viewmat"], s["fx"], s["fy"], fw[6], fw[2], fw[3], fw[4],
         v_xy, v_d, v_con, v_cmp)
-    assert rel_l2(m.grad, r_mean) < TOL
-    assert rel_l2(sc.grad, r_scale) < TOL
-    assert rel_l2(q.grad, r_quat) < TOL
+    assert rel_l2(m.grad, r_mean) < TIGHT
+    assert rel_l2(sc.grad, r_scale) < TIGHT
+    assert rel_l2(q.grad, r_quat) < 1e-5   # measured 8.9e-7
 
 
 def test_fused_render_matches_compat_chain_and_reference_wrapper_semantics():
@@ -224,7 +225,7 @@ def test_fused_render_matches_compat_chain_and_reference_wrapper_semantics():
     ((out["render"] * w_img).sum() + (out["depth"][0] * w_d).sum() + out["alpha"].sum()).backward()
     ((img.permute(2, 0, 1) * w_img).sum() + (dimg * w_d).sum() + alpha.sum()).backward()
     for a, b, n in ((m, m2, "means"), (q, q2, "quats"), (sc, sc2, "scales"), (op, op2, "opacity"), (col, col2, "colors")):
-        assert rel_l2(a.grad, b.grad) < 2e-4, (n, rel_l2(a.grad, b.grad))
+        assert rel_l2(a.grad, b.grad) < TIGHT, (n, rel_l2(a.grad, b.grad))   # measured 1.9e-7
 
 
 def test_config2_full_size_properties():
@@ -260,8 +261,8 @@ def test_config2_full_size_properties():
     (xys, depths, radii, conics, comp, nth), ids, bins = _lists(proj, s)
     opac = (s["opacity"][:, 0] * comp).contiguous()
     ref_img, ref_T, _ = cref.rasterize_forward(ids, bins, xys, conics, s["colors"], opac, H, W, 16, torch.zeros(3))
-    assert rel_l2(img.permute(1, 2, 0), ref_img) < TOL
-    assert rel_l2(1 - alpha[0], ref_T) < TOL
+    assert rel_l2(img.permute(1, 2, 0), ref_img) < 4e-5   # measured 3.2e-6
+    assert rel_l2(1 - alpha[0], ref_T) < TIGHT
 
 
 def test_render_batch_matches_per_view_loop():

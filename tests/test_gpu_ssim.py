@@ -18,7 +18,7 @@ def test_ssim_matches_reference_golden():
         val = losses.ssim_image(pred, c["target"].cuda(), mask)
         (grad,) = torch.autograd.grad(val, pred)
         assert abs(float(val) - float(c["value"])) < 1e-5, tag
-        assert rel_l2(grad, c["grad"]) < 1e-4, tag
+        assert rel_l2(grad, c["grad"]) < 1e-5, tag   # measured 1.0e-6
 
 
 def test_rgb_ssim_full_size_vs_oracle():
@@ -36,7 +36,7 @@ def test_rgb_ssim_full_size_vs_oracle():
     got = losses.rgb_ssim({"rendered_rgb": p}, {"image": target.cuda(), "image_mask": mask.cuda()})
     (g_got,) = torch.autograd.grad(got, p)
     assert abs(float(got) - float(ref)) < 1e-5
-    assert rel_l2(g_got, g_ref) < 1e-4
+    assert rel_l2(g_got, g_ref) < 2e-5   # measured 1.8e-6
     # normalize_mask=False route and the unmasked mean
     got2 = losses.rgb_ssim({"rendered_rgb": p}, {"image": target.cuda(), "image_mask": mask.cuda()}, normalize_mask=False)
     assert abs(float(got2) - float(ssim_ref.rgb_ssim(pred, target, mask, normalize_mask=False))) < 1e-5

@@ -180,4 +180,4 @@ def test_whole_decoder_gradients_fused_vs_unfused():
     names = [n for n, _ in dec.named_parameters()] + ["albedo"]
     for n, a, b in zip(names, g1, g0):
         assert float(b.norm()) > 0, n
-        assert rel_l2(a, b) < 2e-3, n   # through the sign() of L1 and float atomics: looser than the per-kernel bound
+        assert rel_l2(a, b) < 1e-4, n   # through the sign() of L1 and float atomics (measured 2.5e-5 over 49 tensors)

@@ -35,7 +35,18 @@ def test_conv_teacher_decoder_forward_matches_the_reference_forward(tag, depth):
     dec = S.ShapedConvTeacherDecoder(seed=0)
     gf = dec.geo_fn
     if depth == "hip":
-        dec.rl = meshraster.RenderLayer(512, 512, gf.vi.int(), gf.vt, gf.vti)
+        # a foreign render layer with the reference's attributes (what drtk's RenderLayer looks like to the binding): the
+        # depth images must come from gol_mesh_raster off its topology, the layer itself must never be called
+        class ForeignLayer(torch.nn.Module):
+            def __init__(self):
+                super().__init__()
+                self.h = self.w = 512
+                self.register_buffer("vi", gf.vi.int(), persistent=False)
+
+            def forward(self, *a, **k):
+                raise AssertionError("the shadow path called the model's render layer")
+
+        dec.rl = ForeignLayer()
     dec = dec.cuda().train(tag == "train")
     if depth == "golden":
         dec.rl = S.ReplayRenderLayer(512, 512, [torch.from_numpy(GOLD[f"urhand_{tag}_depth{i}"]) for i in range(2)])
@@ -69,19 +80,19 @@ def test_conv_teacher_decoder_forward_matches_the_reference_forward(tag, depth):
         worst[k] = rel_l2(res[k].detach().cpu(), want)
     print("\nURHAND_MODEL outputs", tag, depth, {k: float("%.2e" % v) for k, v in worst.items()})
     for k in list(worst):
-        assert worst[k] < loose * tol.get(k, 1e-4), (k, worst[k])
+        assert worst[k] < loose * tol.get(k, 3e-5), (k, worst[k])   # measured <= 3.3e-6 (profiles/r04_parity_ledger.json)
     g = torch.Generator().manual_seed(5)
     loss = sum((res[k] * torch.randn(res[k].shape, generator=g).cuda()).sum() for k in ("tex", "phys_tex", "diff_feature_raw"))
     loss.backward()
     for k, v in leaves.items():
         e = rel_l2(v.grad.cpu(), torch.from_numpy(GOLD[f"urhand_{tag}_grad_{k}"]))
         worst["grad_" + k] = e
-        assert e < loose * 1e-3, (k, e)
+        assert e < loose * 3e-5, (k, e)   # measured <= 3.4e-6
     params = dict(dec.named_parameters())
     for n in ("global_scale", "global_albedo_scale", "geo_refiner.geo.weight", "texmod1.0.weight"):
         e = rel_l2(params[n].grad.cpu(), torch.from_numpy(GOLD[f"urhand_{tag}_grad_{n}"]))
         worst["grad_" + n] = e
-        assert e < loose * 1e-3, (n, e)
+        assert e < loose * 3e-5, (n, e)   # measured <= 2.6e-6
     print("\nURHAND_MODEL", tag, depth, {k: float("%.2e" % v) for k, v in worst.items()})
 
 
@@ -103,4 +114,5 @@ def test_olat_rgb_decoder_forward_rgb_matches_the_reference_forward_rgb():
     e_rgb = rel_l2(res["primrgb"].cpu(), torch.from_numpy(GOLD["teacher_primrgb"]))
     e_ps = rel_l2(res["primshadow"].cpu(), torch.from_numpy(GOLD["teacher_primshadow"]))
     print("\nTEACHER_MODEL", dict(dirs=e_dirs, deep_shadow=e_shadow, primrgb=e_rgb, primshadow=e_ps))
-    assert e_dirs < 1e-5 and e_shadow < 1e-3 and e_rgb < 1e-3 and e_ps < 1e-3
+    # measured: 3.9e-8 / 3.7e-5 (the deep-shadow march accumulates over ~100 samples of exp()) / 8.3e-8 / 2.7e-6
+    assert e_dirs < 1e-6 and e_shadow < 1e-4 and e_rgb < 2e-6 and e_ps < 3e-5

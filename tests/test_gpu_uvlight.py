@@ -59,12 +59,24 @@ def test_uvlight_olat_32_lights_vs_oracle():
     wf, wr = torch.randn(rf.shape, generator=g), torch.randn(rr.shape, generator=g)
     ((rf * wf).sum() + (rr * wr).sum()).backward()
     ((of * wf.cuda()).sum() + (orr * wr.cuda()).sum()).backward()
-    for a, b, n in zip(gpu, cpu, ("p_uv", "nml", "roughness", "tex")):
+    # fp64 evaluation of the same reference expression with the same upstream gradient
+    c64 = [t.clone().double().requires_grad_(True) for t in (p_uv, nml, rough, tex)]
+    rf64, rr64 = urhand_ref.ggx_features(c64[0], c64[1], cam.double(), lp.double(), li.double(), c64[2], c64[3], shm.double())
+    ((rf64 * wf.double()).sum() + (rr64 * wr.double()).sum()).backward()
+    for a, b, c, n in zip(gpu, cpu, c64, ("p_uv", "nml", "roughness", "tex")):
         # torch yields NaN (0 * inf) where spec^31 overflows behind the clamp(max=1) -- a quirk of the
         # reference expression that the kernel does not reproduce (it returns the gated 0); compare elsewhere
-        ok = torch.isfinite(b.grad)
+        ok = torch.isfinite(b.grad) & torch.isfinite(c.grad.float())
         assert float(ok.float().mean()) > 0.99 and bool(torch.isfinite(a.grad).all())
-        assert rel_l2(a.grad.cpu()[ok], b.grad[ok]) < 5 * TOL, (n, rel_l2(a.grad.cpu()[ok], b.grad[ok]))  # 32 lights x pow(.,32): conditioning
+        # 32 lights x pow(., 32): the fp32 torch evaluation is itself ill-conditioned here.  Yardstick = the SAME reference
+        # code in fp64 (c): HIP must be within 1e-4 of it, or at least as close to it as the fp32 reference is (measured,
+        # profiles/r04_parity_ledger.json: HIP vs fp32 reference 2.3e-4 on the worst tensor -- and the fp32 reference is that
+        # far from its own fp64 evaluation)
+        e_hip64 = rel_l2(a.grad.cpu().double()[ok], c.grad[ok])
+        e_ref64 = rel_l2(b.grad.double()[ok], c.grad[ok])
+        print(f"\nOLAT_GRAD {n}: hip vs fp64 {e_hip64:.2e}, fp32 reference vs fp64 {e_ref64:.2e}, "
+              f"hip vs fp32 reference {rel_l2(a.grad.cpu()[ok], b.grad[ok]):.2e}")
+        assert e_hip64 < max(TOL, 1.5 * e_ref64), (n, e_hip64, e_ref64)
     # Phong path, no shadow map
     rd, rs = urhand_ref.phong_features(p_uv, nml, cam, lp, li, None)
     od, os_ = uvlight.phong_features(p_uv.cuda(), nml.cuda(), cam.cuda(), lp.cuda(), li.cuda(), None)

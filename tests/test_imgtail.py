@@ -88,10 +88,10 @@ def test_fused_image_tail_matches_reference_modules(tag):
            "g_cal": rel_l2(g_cal, G[f"{tag}/g_cal"]) if use_cal else 0.0,
            "g_blur": rel_l2(g_blur, G[f"{tag}/g_blur"]) if use_blur else 0.0}
     print("\nIMGTAIL", tag, {k: "%.1e" % v for k, v in err.items()})
-    assert err["out"] < 1e-5 and err["g_rgb"] < 1e-5, err
+    assert err["out"] < 2e-6 and err["g_rgb"] < 2e-6, err   # measured 2e-7
     # parameter gradients are sums of ~1e4 signed terms; the blur weights' pass through the softmax Jacobian, which
     # subtracts their weighted mean (cancellation): fp32 summation order shows at the 1e-5 level
-    assert err["g_cal"] < 1e-4 and err["g_blur"] < 2e-4, err
+    assert err["g_cal"] < 5e-6 and err["g_blur"] < 1e-4, err   # measured 2.8e-7 / 2.4e-5
 
 
 @pytest.mark.gpu

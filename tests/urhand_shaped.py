@@ -155,6 +155,8 @@ class OracleRenderLayer:
 class ReplayRenderLayer:
     """Hands back stored depth images in call order (the golden's): isolates everything after the depth render."""
 
+    replays_depth = True   # goliath_amd.urhand.shadow_maps calls it instead of rendering
+
     def __init__(self, h, w, depths):
         self.h, self.w, self.depths, self.calls = h, w, list(depths), 0
 
