@@ -10,9 +10,12 @@
 //       RaySubsetFixedBVH<false,512,true> (utils.h:949-1045)
 // The reference is written around 32-lane warps (8x4-pixel footprints, __any_sync / __shfl_down_sync
 // with literal 32s).  This is a wave64 redesign:
-//   * a wave owns an 8x8-pixel footprint and builds ONE hit list for it (512 entries, in LDS) with a
-//     wave-synchronous, stackless walk of the implicit heap: node AABBs and box transforms are
-//     wave-uniform (scalar loads), only the ray tests are per lane;
+//   * a wave owns an 8x8-pixel footprint and builds ONE hit list for it (in LDS) with a wave-synchronous, stackless
+//     walk of the implicit heap: node AABBs and box transforms are wave-uniform (scalar loads), only the ray tests are
+//     per lane.  The wave's two halves (lanes 0-31 = rows 0-3, lanes 32-63 = rows 4-7) are exactly two of the
+//     reference's 8x4-pixel warps (its (8, 16) thread block, mvpraymarch.py:334); every list entry carries which of the
+//     two keeps it, so that each half evaluates precisely the boxes the reference warp's own list holds -- the first 512
+//     boxes, in DFS order, that any of ITS 32 rays hits (utils.h:993-1012) -- also in scenes that exceed that cap;
 //   * the list is annotated with the range of march iterations in which ANY lane of the wave can be
 //     inside the box.  The reference re-tests every hit box at every step (steps x boxes transform
 //     evaluations); here a box costs work only while some ray of the wave is inside it (~20x fewer
@@ -26,7 +29,28 @@
 namespace {
 
 constexpr int kTgSlots = 48;  // hit-list slots with an LDS accumulator for the transform gradients (backward)
-constexpr int kMaxHits = 512;  // per wave (reference: per 32-lane warp, utils.h:993-1012)
+constexpr int kMaxHits = 512;  // per 8x4-pixel half of the wave = per 32-lane warp of the reference (utils.h:993-1012)
+// entries of the wave's merged list (the union of what its two halves keep: at most 2 x 512, in practice the halves -- four
+// image rows apart -- keep nearly the same boxes).  896 entries x 8 bytes x 4 waves + the backward's gradient slots = 40 KB
+// = four workgroups per CU, what the backward's registers allow anyway.  Entries the merged list has no room for are dropped
+// for both halves (only in scenes beyond the reference's own cap whose halves differ by more than 384 boxes).
+constexpr int kListCap = 896;
+constexpr int kKeepA = 0x40000000, kKeepB = (int)0x80000000u, kBoxMask = 0x3fffffff;   // flags in the list entry: kept by half A (rows 0-3) / B
+
+// iteration window [lo, hi] of a list entry, packed: lo clamped to [0, 65535] in the low half, hi in the high half with
+// 65535 = unbounded; an empty window is (65535, 0).  Clamping only ever widens a window (a box evaluated in vain fails
+// valid() for every lane).
+__device__ __forceinline__ unsigned pack_window(int lo, int hi) {
+  if (hi < lo || hi < 0) return 65535u;
+  const unsigned l = (unsigned)min(max(lo, 0), 65535), h = (unsigned)min(hi, 65535);
+  return l | (h << 16);
+}
+__device__ __forceinline__ bool window_active(unsigned w, int iter) {
+  const int lo = (int)(w & 0xffffu), hi = (int)(w >> 16);
+  return lo <= iter && (iter <= hi || hi == 65535);
+}
+// does this lane's half keep list entry e?
+__device__ __forceinline__ bool half_keeps(int e, int lane) { return (e & (lane < 32 ? kKeepA : kKeepB)) != 0; }
 
 struct V3 { float x, y, z; };
 __device__ __forceinline__ V3 v3(float x, float y, float z) { return V3{x, y, z}; }
@@ -264,10 +288,10 @@ __device__ __forceinline__ V3 warp_sample(const float* __restrict__ wp, int WD, 
 __device__ __forceinline__ int build_hits(int K, const float* __restrict__ nodeaabb, const float* __restrict__ primpos,
                                           const float* __restrict__ primrot, const float* __restrict__ primscale,
                                           float stepsize, float tmin, float tmax, Ray& ray, int* __restrict__ s_list,
-                                          int* __restrict__ s_lo, int* __restrict__ s_hi) {
+                                          unsigned* __restrict__ s_win) {
   const V3 ird = v3(1.f / ray.dir.x, 1.f / ray.dir.y, 1.f / ray.dir.z);
   float rt0 = INFINITY, rt1 = -INFINITY;
-  int num = 0;
+  int num = 0, num_a = 0, num_b = 0;   // merged list / boxes kept by half A / by half B
   int node = K > 1 ? 1 : 0;  // the reference never tests the root box itself (utils.h:1016-1021)
   if (K == 1) node = 0;
   while (node != -1) {
@@ -276,8 +300,14 @@ __device__ __forceinline__ int build_hits(int K, const float* __restrict__ nodea
       float a, b;
       const bool hit = ray.live && box_hit(primpos, primrot, primscale, k, ray.pos, ray.dir, a, b);
       if (hit) { rt0 = fminf(rt0, a); rt1 = fmaxf(rt1, b); }
-      if (gol_ballot(hit) != 0ull && num < kMaxHits) {
-        if ((threadIdx.x & 63) == 0) s_list[num] = k;
+      // (the reference: hit = __any_sync over the 32-lane warp, appended while that warp's list has < 512 entries)
+      const unsigned long long hb = gol_ballot(hit);
+      const bool keep_a = (hb & 0xffffffffull) != 0ull && num_a < kMaxHits;
+      const bool keep_b = (hb >> 32) != 0ull && num_b < kMaxHits;
+      num_a += keep_a ? 1 : 0;
+      num_b += keep_b ? 1 : 0;
+      if ((keep_a || keep_b) && num < kListCap) {
+        if ((threadIdx.x & 63) == 0) s_list[num] = k | (keep_a ? kKeepA : 0) | (keep_b ? kKeepB : 0);
         ++num;
       }
       node = heap_next(node);
@@ -311,10 +341,11 @@ __device__ __forceinline__ int build_hits(int K, const float* __restrict__ nodea
                            fmaxf(fmaxf(fabsf(pe.y), fabsf(pe.z)), fmaxf(fabsf(ray.t), fabsf(ray.rt1))));
   const float drift = fmaxf(1e-4f, 4.8e-7f * pmax * inv_step);
   for (int s = 0; s < num; ++s) {
-    const int k = __builtin_amdgcn_readfirstlane(s_list[s]);
+    const int e = __builtin_amdgcn_readfirstlane(s_list[s]);
+    const int k = e & kBoxMask;
     float a, b;
     int lo = 2147483647, hi = -2147483647;
-    if (ray.live && box_hit(primpos, primrot, primscale, k, p0, ray.dir, a, b)) {
+    if (ray.live && half_keeps(e, threadIdx.x & 63) && box_hit(primpos, primrot, primscale, k, p0, ray.dir, a, b)) {
       const float xa = (a - ray.t) * inv_step, xb = (b - ray.t) * inv_step;
       const float m = 0.05f + drift * fmaxf(fabsf(xa), fabsf(xb));
       const float fl = floorf(xa - m), fh = ceilf(xb + m);
@@ -325,7 +356,7 @@ __device__ __forceinline__ int build_hits(int K, const float* __restrict__ nodea
     }
     lo = wave_min_i(lo);
     hi = wave_max_i(hi);
-    if ((threadIdx.x & 63) == 0) { s_lo[s] = lo; s_hi[s] = hi; }
+    if ((threadIdx.x & 63) == 0) s_win[s] = pack_window(lo, hi);
   }
   __builtin_amdgcn_wave_barrier();
   return num;
@@ -375,9 +406,8 @@ __device__ __forceinline__ float fade_pow_m1(float ax, float e, bool e8) {
 template <bool SHADOW, bool WARP>
 __global__ __launch_bounds__(256) void march_fwd_kernel(MarchArgs a, float* __restrict__ rayrgba,
                                                         float* __restrict__ raysat, float* __restrict__ shadow) {
-  __shared__ int s_list[4][kMaxHits];
-  __shared__ int s_lo[4][kMaxHits];
-  __shared__ int s_hi[4][kMaxHits];
+  __shared__ int s_list[4][kListCap];
+  __shared__ unsigned s_win[4][kListCap];
   const int n = blockIdx.z;
   const int lane = threadIdx.x & 63;
   Ray ray; float tmin, tmax; size_t r; int wave;
@@ -391,7 +421,7 @@ __global__ __launch_bounds__(256) void march_fwd_kernel(MarchArgs a, float* __re
   const float* tplate_a = a.tplate + (size_t)pn * a.K * vox;  // alpha-only layout
   float* shadow_n = SHADOW ? shadow + (size_t)n * a.K * vox * 2 : nullptr;
   const int num = build_hits(a.K, a.nodeaabb + (size_t)pn * (2 * a.K - 1) * 6, primpos, primrot, primscale, a.stepsize,
-                             tmin, tmax, ray, s_list[wave], s_lo[wave], s_hi[wave]);
+                             tmin, tmax, ray, s_list[wave], s_win[wave]);
 
   float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f, sat0 = -1.f, sat1 = -1.f, sat2 = -1.f;
   bool sat = false;
@@ -403,14 +433,16 @@ __global__ __launch_bounds__(256) void march_fwd_kernel(MarchArgs a, float* __re
     // length of the hit list
     for (int base = 0; base < num; base += 64) {
     const int s_me = base + lane;
-    unsigned long long active = gol_ballot(s_me < num && s_lo[wave][s_me] <= iter && iter <= s_hi[wave][s_me]);
+    unsigned long long active = gol_ballot(s_me < num && window_active(s_win[wave][s_me], iter));
     while (active) {
       const int s = base + __builtin_ctzll(active);
       active &= active - 1;
-      const int k = __builtin_amdgcn_readfirstlane(s_list[wave][s]);  // wave-uniform: the box transform comes through scalar loads
+      const int e = __builtin_amdgcn_readfirstlane(s_list[wave][s]);  // wave-uniform: the box transform comes through scalar loads
+      const int k = e & kBoxMask;
       Xform xf;
       const V3 y0 = xform_fwd(xf, primpos, primrot, primscale, k, ray.pos);
-      const bool ev = ray.live && valid_pos(y0) && !sat && ray.t < ray.rt1 + 1e-5f;
+      // (half_keeps: a lane only evaluates boxes of ITS half's list; below the cap that is implied by valid_pos)
+      const bool ev = ray.live && half_keeps(e, lane) && valid_pos(y0) && !sat && ray.t < ray.rt1 + 1e-5f;
       // shadow splat state of this lane (filled inside the branch, scattered wave-wide after it)
       int sh_idx[SHADOW ? 8 : 1], sh_key = -1;
       float sh_w[SHADOW ? 8 : 1], sh_vis = 0.f;
@@ -510,9 +542,8 @@ __global__ __launch_bounds__(256) void march_bwd_kernel(MarchArgs a, const float
                                                         float* __restrict__ grad_primscale,
                                                         float* __restrict__ grad_tplate,
                                                         float* __restrict__ grad_warp) {
-  __shared__ int s_list[4][kMaxHits];
-  __shared__ int s_lo[4][kMaxHits];
-  __shared__ int s_hi[4][kMaxHits];
+  __shared__ int s_list[4][kListCap];
+  __shared__ unsigned s_win[4][kListCap];
   // per-wave accumulators of the 15 transform-gradient sums of the first kTgSlots boxes of the hit list: every wave that
   // crosses a box adds to the SAME 15 global addresses, and memory-side float atomics to one address serialise -- so
   // they are issued once per (wave, box) at the end instead of once per (wave, box, step)
@@ -532,7 +563,7 @@ __global__ __launch_bounds__(256) void march_bwd_kernel(MarchArgs a, const float
   float* g_rot = grad_primrot + (size_t)n * a.K * 9;
   float* g_scale = grad_primscale + (size_t)n * a.K * 3;
   const int num = build_hits(a.K, a.nodeaabb + (size_t)n * (2 * a.K - 1) * 6, primpos, primrot, primscale, a.stepsize,
-                             tmin, tmax, ray, s_list[wave], s_lo[wave], s_hi[wave]);
+                             tmin, tmax, ray, s_list[wave], s_win[wave]);
 
   // PrimAccumAdditive::read (primaccum.h:58-61)
   const float4 dL = ray.live ? *reinterpret_cast<const float4*>(grad_rayrgba + 4 * r) : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -545,14 +576,15 @@ __global__ __launch_bounds__(256) void march_bwd_kernel(MarchArgs a, const float
   while (gol_ballot(ray.live && ray.t < ray.rt1 + 1e-5f && !sat) != 0ull) {
     for (int base = 0; base < num; base += 64) {  // (see the forward kernel)
     const int s_me = base + lane;
-    unsigned long long active = gol_ballot(s_me < num && s_lo[wave][s_me] <= iter && iter <= s_hi[wave][s_me]);
+    unsigned long long active = gol_ballot(s_me < num && window_active(s_win[wave][s_me], iter));
     while (active) {
       const int s = base + __builtin_ctzll(active);
       active &= active - 1;
-      const int k = __builtin_amdgcn_readfirstlane(s_list[wave][s]);
+      const int e = __builtin_amdgcn_readfirstlane(s_list[wave][s]);
+      const int k = e & kBoxMask;
       Xform xf;
       const V3 y0 = xform_fwd(xf, primpos, primrot, primscale, k, ray.pos);
-      const bool ev = ray.live && valid_pos(y0) && !sat && ray.t < ray.rt1 + 1e-5f;
+      const bool ev = ray.live && half_keeps(e, lane) && valid_pos(y0) && !sat && ray.t < ray.rt1 + 1e-5f;
       if (gol_ballot(ev) == 0ull) continue;
       V3 dLy = v3(0.f, 0.f, 0.f);
       float sd0 = 0.f, sd1 = 0.f, sd2 = 0.f, sd3 = 0.f;
@@ -711,7 +743,7 @@ __global__ __launch_bounds__(256) void march_bwd_kernel(MarchArgs a, const float
     if (s < nflush && i < 15) {
       const float v = s_tg[wave][s][i];
       if (v != 0.f) {
-        const int k = s_list[wave][s];
+        const int k = s_list[wave][s] & kBoxMask;
         float* dst = i < 3 ? g_scale + 3 * k + i : (i < 6 ? g_pos + 3 * k + (i - 3) : g_rot + 9 * k + (i - 6));
         atomicAdd(dst, v);
       }
@@ -720,7 +752,7 @@ __global__ __launch_bounds__(256) void march_bwd_kernel(MarchArgs a, const float
 }
 
 int check_march(int N, int H, int W, int K, int TD, int TH, int TW, float stepsize) {
-  GOL_REQUIRE(N >= 0 && H >= 0 && W >= 0 && K >= 1, "bad sizes");
+  GOL_REQUIRE(N >= 0 && H >= 0 && W >= 0 && K >= 1 && K <= kBoxMask, "bad sizes");
   GOL_REQUIRE(TD > 0 && TH > 0 && TW > 0, "bad template size");
   GOL_REQUIRE(stepsize > 0.f, "stepsize must be positive");
   GOL_REQUIRE(N <= 65535, "N > 65535");

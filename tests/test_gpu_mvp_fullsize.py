@@ -6,9 +6,10 @@
     with the kernels' exact hit-list semantics in BOTH geometries: 8x8 footprints (csrc/mvp.hip's wave64) and 8x4
     footprints (the reference's 32-lane warp); at this config no footprint reaches the 512 cap, so the two (and the
     per-ray, uncapped list) must give the same result -- asserted.
-(2) a scene whose footprints collect far more than 512 boxes: the list is truncated to the first 512 in DFS order,
-    exactly like RaySubsetFixedBVH<false,512,true> (utils.h:993-1012); HIP == oracle(8x8, 512); the difference to the
-    reference's 8x4 truncation is measured and printed (the union of a larger footprint fills the cap earlier)."""
+(2) a scene whose footprints collect far more than 512 boxes: every 8x4-pixel half of a wave keeps the first 512 boxes, in
+    DFS order, that any of ITS 32 rays hits -- exactly the list of the reference's warp, RaySubsetFixedBVH<false,512,true>
+    (utils.h:993-1012): HIP == oracle(8x4, 512) (round 4; rounds 1-3 truncated the union of the 8x8 wave footprint, 5 %
+    off the reference in this scene -- still measured and printed)."""
 import json
 import os
 import sys
@@ -89,9 +90,9 @@ def test_config5_ray_crops_match_oracle(y0, x0, h, w):
     print("\nMVP_CONFIG5_PARITY " + json.dumps(report))
     _record(f"config5_crop_{y0}_{x0}", report)
     assert report["oracle_8x8_vs_reference_8x4"] < 1e-6
-    assert report["out"] < 1e-4, report
+    assert report["out"] < 3e-6, report          # measured 3e-7 (profiles/r04_parity_ledger.json)
     for k in GRADS:
-        assert report[f"grad_{k}"] < 3e-4, report
+        assert report[f"grad_{k}"] < 3e-5, report    # measured <= 2.8e-6
 
 
 def test_footprint_over_the_512_hit_cap():
@@ -120,11 +121,12 @@ def test_footprint_over_the_512_hit_cap():
     ref88, g88 = _oracle((8, 8, 512), rp.cpu(), rd.cpu(), step, tm.cpu(), case, go, 6.5, 8.0)
     ref84, g84 = _oracle((8, 4, 512), rp.cpu(), rd.cpu(), step, tm.cpu(), case, go, 6.5, 8.0)
     full, _ = _oracle((0, 0, 0), rp.cpu(), rd.cpu(), step, tm.cpu(), case, go, 6.5, 8.0)
-    report = {"hip_vs_oracle_8x8_cap512": rel_l2(out, ref88), **{f"grad_{k}": rel_l2(gr[k], g88[k]) for k in GRADS},
-              "cap_effect_vs_uncapped": rel_l2(ref88, full), "oracle_8x8_vs_reference_8x4": rel_l2(ref88, ref84)}
+    report = {"hip_vs_reference_8x4_cap512": rel_l2(out, ref84), **{f"grad_{k}": rel_l2(gr[k], g84[k]) for k in GRADS},
+              "cap_effect_vs_uncapped": rel_l2(ref84, full), "oracle_8x8_vs_reference_8x4": rel_l2(ref88, ref84)}
     print("\nMVP_OVER_CAP " + json.dumps(report))
     _record("over_512_cap", report)
     assert report["cap_effect_vs_uncapped"] > 1e-3          # the cap really truncates in this scene
-    assert report["hip_vs_oracle_8x8_cap512"] < 1e-4, report
+    assert report["oracle_8x8_vs_reference_8x4"] > 1e-3     # ... and the two footprints truncate differently
+    assert report["hip_vs_reference_8x4_cap512"] < 1e-5, report
     for k in GRADS:
-        assert report[f"grad_{k}"] < 3e-4, report
+        assert report[f"grad_{k}"] < 3e-5, report
