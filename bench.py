@@ -254,7 +254,15 @@ def _stamped(name):
     return data
 
 
-def make_roofline(call, ms, views_per_launch, N, I, P, mip_bytes):
+# minimal VALU lane-operations per TAKEN (pixel, Gaussian) pair (the arithmetic the compositing
+# recurrence and its derivative need per pixel, nothing shared, no bookkeeping, perfect reductions):
+#   forward  17: sigma 5, exp 1, alpha 2, cut 1, alpha T 1, T update 1, stop test 1, colour + depth FMAs 4, live mask 1
+#   backward 35: sigma 5, exp 1, alpha 2, cut 1, 1 / (1 - alpha) 2, T 1, fac 1, <colour, v_out> 3, v_alpha 3, q 1, colour
+#                gradients 3, gop 1, moments of gop 5, + one add per pixel for each of the 9 sums 9 (a perfect tree), mask 1
+ALG_OPS_PER_PAIR = {"raster_fwd_kernel": 17, "raster_bwd_kernel": 35}
+
+
+def make_roofline(call, ms, views_per_launch, N, I, P, mip_bytes, pairs_taken=None):
     """Roofline of the dominant ABI call.  Time: HIP events around the call, measured live.  Algorithmic bytes: DESIGN.md
     section 4.  HBM traffic and instruction counts: rocprofv3 PMC passes recorded under profiles/ (tools/gpu_profile.sh +
     tools/make_profile_record.py), used only while their source digest matches this tree (else null)."""
@@ -269,8 +277,19 @@ def make_roofline(call, ms, views_per_launch, N, I, P, mip_bytes):
     # the rasterizer moves ~1/10 of what HBM could deliver in its run time and keeps the vector ALUs busy instead:
     # report the instruction-issue roofline (and the HBM numbers beside it)
     valu = _stamped("valu.json")
-    return dict(_valu_roofline(valu, VALU_BOUND_CALLS[call], ms, views_per_launch / 8.0), kernel=call, traffic=traffic,
+    roof = dict(_valu_roofline(valu, VALU_BOUND_CALLS[call], ms, views_per_launch / 8.0), kernel=call, traffic=traffic,
                 hbm=hbm)
+    if pairs_taken is not None:
+        # issued vs algorithmic: how much of the issue fraction above is arithmetic the compositing needs.  algorithmic_inst
+        # = taken (pixel, Gaussian) pairs of the launch x minimal lane-operations per pair / 64 lanes (wave-instructions)
+        alg = pairs_taken * views_per_launch * ALG_OPS_PER_PAIR[VALU_BOUND_CALLS[call]] / 64.0
+        roof["algorithmic_inst"] = alg
+        roof["taken_pixel_gaussian_pairs_per_view"] = pairs_taken
+        roof["lane_ops_per_taken_pair"] = ALG_OPS_PER_PAIR[VALU_BOUND_CALLS[call]]
+        insts = roof.get("valu_instructions_per_launch")
+        roof["issued_over_algorithmic"] = None if not insts else insts / alg
+        roof["algorithmic_frac_of_peak"] = alg / (ms * 1e-3) / 1e9 / VALU_PEAK_GINST
+    return roof
 
 
 def _valu_roofline(record, kernel_prefix, ms, scale=1.0):
@@ -973,6 +992,7 @@ def run_rgca(args, D, views, scaling, workload, overlap, micro=None, extras=True
     res["kernels_ms_per_call"] = kernels_ms
     views_per_launch = B // micro  # every ABI call processes one micro-batch
     I = 1.97e6   # stored list entries per view of the default scene (measured below when `extras`)
+    pairs_taken = None
     if extras:
         # measured intersection count (determines the raster/sort work)
         with torch.no_grad():
@@ -990,11 +1010,14 @@ def run_rgca(args, D, views, scaling, workload, overlap, micro=None, extras=True
             config["intersections_per_view"] = I
             config["list_slots_reserved_per_view"] = float(out["n_isect"].float().mean())
             config["mean_alpha"] = float(out["alpha"].mean())
+            pc = splat.raster_pair_counts(out).double().mean(0)
+            config["pixel_gaussian_pairs_tested_per_view"], pairs_taken = float(pc[0]), float(pc[1])
+            config["pixel_gaussian_pairs_taken_per_view"] = pairs_taken
             del preds, out, bins
     if kernels_ms:
         dom = max(kernels_ms, key=kernels_ms.get)
         mip_bytes = sum(m[0].numel() * 4 for m in t["micro"][0]["mips"])
-        res["roofline"] = make_roofline(dom, kernels_ms[dom], views_per_launch, N, I, P, mip_bytes)
+        res["roofline"] = make_roofline(dom, kernels_ms[dom], views_per_launch, N, I, P, mip_bytes, pairs_taken)
         # every streaming call beside it: algorithmic GB/s, fraction of the 8 TB/s spec, PMC traffic / algorithmic bytes
         per = {}
         tr = _stamped("traffic.json")

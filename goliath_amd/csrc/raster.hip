@@ -381,6 +381,26 @@ __global__ __launch_bounds__(64 * Pix<PPL>::kWaves) void raster_fwd_kernel(
   }
 }
 
+// loss value of the fused L1: l1_out[0] = scale * sum(l1_partial[0 .. n)), one workgroup, fixed summation order.  (Folding
+// this into the raster launch itself -- the last workgroup to finish adds the partial sums up -- was measured in round 4:
+// the device-scope fence every workgroup then needs before its ticket writes back / invalidates L2 and took the 8-view step
+// from 2.9 to 6.7 ms; a 3 us kernel of its own replaces the ATen reduction + multiply of rounds 1-3.)
+__global__ __launch_bounds__(1024) void l1_sum_kernel(int n, const float* __restrict__ l1_partial, float scale,
+                                                      float* __restrict__ l1_out) {
+  __shared__ float s_w[16];
+  float acc = 0.f;
+  for (int i = threadIdx.x; i < n; i += 1024) acc += l1_partial[i];
+  const float ws = gol_wave_sum_to_lane63(acc);
+  if ((threadIdx.x & 63) == 63) s_w[threadIdx.x >> 6] = ws;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float tot = 0.f;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) tot += s_w[w];
+    l1_out[0] = tot * scale;
+  }
+}
+
 constexpr int kBatchB = 64;   // backward batch (smaller: per-wave gradient slots live in LDS)
 constexpr int kAcc = 12;      // r g b v_opacity | Mx My Mxx Mxy | Myy extra - -   (M = moments of gop, see the loop)
 
@@ -401,7 +421,7 @@ __global__ __launch_bounds__(64 * Pix<PPL>::kWaves) void raster_bwd_kernel(
     const float* __restrict__ v_out_alpha, float* __restrict__ v_xy, float* __restrict__ v_conic,
     float* __restrict__ v_colors, float* __restrict__ v_extra, float* __restrict__ v_opacity,
     const uint8_t* __restrict__ v_sign, const float* __restrict__ v_sign_mask, int v_sign_mask_c,
-    const float* __restrict__ v_img_scale, int n_views) {
+    const float* __restrict__ v_img_scale, float v_img_scale_mul, int n_views) {
   typedef typename Pix<PPL>::fv fv;
   typedef typename Pix<PPL>::iv iv;
   constexpr int NW = Pix<PPL>::kWaves, NT = 64 * NW;
@@ -441,7 +461,7 @@ __global__ __launch_bounds__(64 * Pix<PPL>::kWaves) void raster_bwd_kernel(
   {
     // upstream image gradient = v_out_img (optional) + the fused L1's term: (sign code - 1) x mask x v_img_scale, with the
     // sign codes the forward epilogue left (one byte per pixel) and the scalar g / n as a device value (no sync)
-    const float vsc = v_img_scale ? v_img_scale[0] : 1.f;
+    const float vsc = (v_img_scale ? v_img_scale[0] : 1.f) * v_img_scale_mul;
     const size_t os = planar ? hw : 1;
 #pragma unroll
     for (int q = 0; q < PPL; ++q) {
@@ -658,6 +678,46 @@ __global__ __launch_bounds__(64 * Pix<PPL>::kWaves) void raster_bwd_kernel(
   }
 }
 
+// DIAGNOSTIC (bench.py's algorithmic roofline): per view, the number of (pixel, list entry) pairs up to the pixel's
+// final_idx ("tested": what any per-pixel compositor has to look at) and of those with alpha >= 1/255 ("taken": what is
+// composited and differentiated).  One thread per pixel, no staging: slow and simple.
+__global__ __launch_bounds__(256) void raster_count_pairs_kernel(int N, int img_h, int img_w, int tiles_x, int tiles_y,
+                                                                 const int2* __restrict__ tile_bins,
+                                                                 const int32_t* __restrict__ sorted_ids, int64_t capacity,
+                                                                 const float* __restrict__ records,
+                                                                 const int32_t* __restrict__ final_idx,
+                                                                 unsigned long long* __restrict__ counts) {
+  __shared__ unsigned long long s_cnt[2];
+  const int view = blockIdx.y, tile = blockIdx.x, T = tiles_x * tiles_y;
+  const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
+  const int j = tx * 16 + (threadIdx.x & 15), i = ty * 16 + (threadIdx.x >> 4);
+  if (threadIdx.x < 2) s_cnt[threadIdx.x] = 0ull;
+  __syncthreads();
+  const int2 range = tile_bins[(size_t)view * T + tile];
+  unsigned long long tested = 0, taken = 0;
+  if (i < img_h && j < img_w && range.y > range.x) {
+    const int last = min(range.y - 1, final_idx[((size_t)view * img_h + i) * img_w + j]);
+    const float px = (float)j + 0.5f, py = (float)i + 0.5f;
+    for (int li = range.x; li <= last; ++li) {
+      const float4* R = reinterpret_cast<const float4*>(records + ((size_t)view * N + sorted_ids[(size_t)view * capacity + li]) * GOL_SPLAT_RECORD);
+      const float4 q0 = R[0], q1 = R[1];
+      const float dx = q0.x - px, dy = q0.y - py;
+      const float sg = (q0.z * dx * dx + q1.x * dy * dy) + (q0.w * dx) * dy;
+#ifndef GOL_EXACT_MATH
+      const float alpha = fminf(GOL_ALPHA_CAP_FWD, q1.y * __builtin_amdgcn_exp2f(-sg));
+#else
+      const float alpha = fminf(GOL_ALPHA_CAP_FWD, q1.y * expf(-sg));
+#endif
+      ++tested;
+      taken += (!(sg < 0.f) && !(alpha < GOL_ALPHA_FLOOR)) ? 1 : 0;
+    }
+  }
+  atomicAdd(&s_cnt[0], tested);
+  atomicAdd(&s_cnt[1], taken);
+  __syncthreads();
+  if (threadIdx.x < 2 && s_cnt[threadIdx.x]) atomicAdd(counts + 2 * view + threadIdx.x, s_cnt[threadIdx.x]);
+}
+
 // gsplat-compatible operators hand over separate attribute arrays: pack them into records (the fused path's projection
 // writes the records itself)
 __global__ __launch_bounds__(256) void splat_pack_kernel(size_t n, const float* __restrict__ xys,
@@ -688,6 +748,25 @@ extern "C" int gol_raster_plan(int B, int* fwd_pixels_per_lane) {
   return GOL_OK;
 }
 
+extern "C" int gol_raster_count_pairs(int B, int N, int img_h, int img_w, const int32_t* tile_bins, const int32_t* sorted_ids,
+                                      int64_t capacity, const float* records, const int32_t* final_idx, uint64_t* counts,
+                                      void* stream) {
+  GOL_REQUIRE(B >= 0 && N >= 0 && img_h > 0 && img_w > 0, "bad size");
+  if (B == 0) return GOL_OK;
+  GOL_REQUIRE(tile_bins && final_idx && counts && (capacity == 0 || sorted_ids) && (N == 0 || records), "null pointer");
+  hipStream_t s = (hipStream_t)stream;
+  if (hipMemsetAsync(counts, 0, sizeof(uint64_t) * 2 * (size_t)B, s) != hipSuccess) {
+    gol_set_error("gol_raster_count_pairs: hipMemsetAsync failed");
+    return GOL_ERR_LAUNCH;
+  }
+  const int tiles_x = (img_w + 15) / 16, tiles_y = (img_h + 15) / 16;
+  raster_count_pairs_kernel<<<dim3(tiles_x * tiles_y, B), 256, 0, s>>>(
+      N, img_h, img_w, tiles_x, tiles_y, reinterpret_cast<const int2*>(tile_bins), sorted_ids, capacity, records, final_idx,
+      reinterpret_cast<unsigned long long*>(counts));
+  GOL_CHECK_LAUNCH();
+  return GOL_OK;
+}
+
 extern "C" int gol_splat_pack(int B, int N, const float* xys, const float* conics, const float* colors,
                               const float* extra, const float* opacities, float* records, void* stream) {
   GOL_REQUIRE(B >= 0 && N >= 0, "negative size");
@@ -705,8 +784,8 @@ extern "C" int gol_rasterize_fwd(int B, int N, int img_h, int img_w, int block, 
                                  const float* background, float* out_img,
                                  float* out_extra, float* final_Ts, int32_t* final_idx, float* out_alpha,
                                  float* out_extra_norm, float norm_lo, const float* l1_target, const float* l1_mask,
-                                 int l1_mask_c, uint8_t* l1_sign, float* l1_partial, int pixels_per_lane,
-                                 void* stream) {
+                                 int l1_mask_c, uint8_t* l1_sign, float* l1_partial, float* l1_out, float l1_scale,
+                                 int pixels_per_lane, void* stream) {
   GOL_REQUIRE(B >= 0 && N >= 0, "negative size");
   GOL_REQUIRE(block == 16, "only block_width == 16 is implemented (the reference's value, render_gsplat.py:28)");
   GOL_REQUIRE(img_h > 0 && img_w > 0, "empty image");
@@ -720,6 +799,7 @@ extern "C" int gol_rasterize_fwd(int B, int N, int img_h, int img_w, int block, 
   GOL_REQUIRE(!with_extra || out_extra || out_extra_norm, "extra without an output for it");
   GOL_REQUIRE(!l1_target || (planar && l1_sign && l1_partial), "the fused L1 needs planar images, l1_sign and l1_partial");
   GOL_REQUIRE(!l1_mask || (l1_target && (l1_mask_c == 1 || l1_mask_c == 3)), "l1_mask: 1 or 3 channels, with l1_target");
+  GOL_REQUIRE(!l1_out || l1_target, "l1_out needs l1_target");
   const int tiles_x = (img_w + 15) / 16, tiles_y = (img_h + 15) / 16;
   dim3 grid(8 * ((tiles_y + 7) / 8) * tiles_x * B);
   const int2* bins = reinterpret_cast<const int2*>(tile_bins);
@@ -749,6 +829,7 @@ extern "C" int gol_rasterize_fwd(int B, int N, int img_h, int img_w, int block, 
   else if (planar) GOL_LAUNCH_FWD(false, true);
   else GOL_LAUNCH_FWD(false, false);
 #undef GOL_LAUNCH_FWD
+  if (l1_out) l1_sum_kernel<<<1, 1024, 0, s>>>(B * tiles_x * tiles_y, l1_partial, l1_scale, l1_out);
   GOL_CHECK_LAUNCH();
   return GOL_OK;
 }
@@ -760,7 +841,7 @@ extern "C" int gol_rasterize_bwd(int B, int N, int img_h, int img_w, int block, 
                                  const float* v_out_alpha, float* v_xy, float* v_conic, float* v_colors,
                                  float* v_extra, float* v_opacity, int grad_stride, const uint8_t* v_sign,
                                  const float* v_sign_mask, int v_sign_mask_c, const float* v_img_scale,
-                                 int pixels_per_lane, void* stream) {
+                                 float v_img_scale_mul, int pixels_per_lane, void* stream) {
   GOL_REQUIRE(B >= 0 && N >= 0, "negative size");
   GOL_REQUIRE(block == 16, "only block_width == 16 is implemented (the reference's value, render_gsplat.py:28)");
   GOL_REQUIRE(img_h > 0 && img_w > 0, "empty image");
@@ -793,13 +874,13 @@ extern "C" int gol_rasterize_bwd(int B, int N, int img_h, int img_w, int block, 
                                                         capacity, records, background, final_Ts, final_idx, v_out_img, \
                                                         EX ? v_out_extra : nullptr, v_out_alpha, v_xy, v_conic,        \
                                                         v_colors, EX ? v_extra : nullptr, v_opacity, v_sign,           \
-                                                        v_sign_mask, v_sign_mask_c, v_img_scale, B);                   \
+                                                        v_sign_mask, v_sign_mask_c, v_img_scale, v_img_scale_mul, B);  \
     else                                                                                                                \
       raster_bwd_kernel<EX, PK, 1><<<grid, 256, 0, s>>>(N, img_h, img_w, planar, tiles_x, tiles_y, bins, sorted_ids,   \
                                                         capacity, records, background, final_Ts, final_idx, v_out_img, \
                                                         EX ? v_out_extra : nullptr, v_out_alpha, v_xy, v_conic,        \
                                                         v_colors, EX ? v_extra : nullptr, v_opacity, v_sign,           \
-                                                        v_sign_mask, v_sign_mask_c, v_img_scale, B);                   \
+                                                        v_sign_mask, v_sign_mask_c, v_img_scale, v_img_scale_mul, B);  \
   } while (0)
   if (ex && packed) GOL_LAUNCH_BWD(true, true);
   else if (ex) GOL_LAUNCH_BWD(true, false);

@@ -51,11 +51,13 @@ extern "C" int gol_render_fwd(int B, int N, int img_h, int img_w, float glob_sca
                               const float* viewmats, const float* intrins, const float* background, int with_depth,
                               float norm_lo, int64_t capacity, void* workspace, const gol_render_ws* L, float* out_img,
                               float* out_depth, float* out_alpha, float* out_depth_norm, const float* l1_target,
-                              const float* l1_mask, int l1_mask_c, float* l1_partial, void* stream) {
+                              const float* l1_mask, int l1_mask_c, float* l1_partial, float* l1_out, float l1_scale,
+                              void* stream) {
   GOL_REQUIRE(workspace != nullptr && L != nullptr, "null workspace / layout");
   GOL_REQUIRE(!l1_target || L->l1_sign >= 0, "layout was computed without the fused L1");
   if (B == 0) return GOL_OK;
   void* ws = workspace;
+  GOL_REQUIRE(!l1_out || l1_target, "l1_out needs l1_target");
   int rc = gol_project_fwd(B, N, means, scales, glob_scale, quats, viewmats, intrins, img_h, img_w, 16, clip_thresh,
                            nullptr, at<float>(ws, L->xys), at<float>(ws, L->depths),
                            at<int32_t>(ws, L->radii), at<float>(ws, L->conics), at<float>(ws, L->comp),
@@ -71,7 +73,8 @@ extern "C" int gol_render_fwd(int B, int N, int img_h, int img_w, float glob_sca
                            capacity, at<float>(ws, L->records), with_depth ? 1 : 0, background, out_img,
                            with_depth ? out_depth : nullptr, at<float>(ws, L->final_T), at<int32_t>(ws, L->final_idx),
                            out_alpha, with_depth ? out_depth_norm : nullptr, norm_lo, l1_target, l1_mask, l1_mask_c,
-                           l1_target ? at<uint8_t>(ws, L->l1_sign) : nullptr, l1_partial, 0, stream);
+                           l1_target ? at<uint8_t>(ws, L->l1_sign) : nullptr, l1_partial, l1_out, l1_scale, 0,
+                           stream);
 }
 
 extern "C" int gol_render_bwd(int B, int N, int img_h, int img_w, float glob_scale, const float* means,
@@ -79,7 +82,7 @@ extern "C" int gol_render_bwd(int B, int N, int img_h, int img_w, float glob_sca
                               const float* intrins, const float* background, int64_t capacity, void* workspace,
                               const gol_render_ws* L, const float* v_img, const float* v_depth, const float* v_alpha,
                               int use_l1_sign, const float* l1_mask, int l1_mask_c, const float* v_img_scale,
-                              float* grad_records, float* v_mean, float* v_scale, float* v_quat, float* v_opacity,
+                              float v_img_scale_mul, float* grad_records, float* v_mean, float* v_scale, float* v_quat, float* v_opacity,
                               float* v_colors, void* stream) {
   GOL_REQUIRE(workspace != nullptr && L != nullptr && grad_records != nullptr, "null workspace / layout / gradient records");
   GOL_REQUIRE(!use_l1_sign || L->l1_sign >= 0, "layout was computed without the fused L1");
@@ -98,7 +101,7 @@ extern "C" int gol_render_bwd(int B, int N, int img_h, int img_w, float glob_sca
                              at<float>(ws, L->final_T), at<int32_t>(ws, L->final_idx), v_img, v_depth, v_alpha, g + 4, g + 6,
                              g, use_depth ? g + 9 : nullptr, g + 3, GOL_GRAD_RECORD,
                              use_l1_sign ? at<uint8_t>(ws, L->l1_sign) : nullptr, use_l1_sign ? l1_mask : nullptr,
-                             use_l1_sign ? l1_mask_c : 0, v_img_scale, 0, stream);
+                             use_l1_sign ? l1_mask_c : 0, v_img_scale, v_img_scale_mul, 0, stream);
   if (rc != GOL_OK) return rc;
   return gol_project_bwd_records(B, N, means, scales, glob_scale, quats, viewmats, intrins, at<int32_t>(ws, L->radii),
                                  at<float>(ws, L->conics), at<float>(ws, L->comp), opacity, g, use_depth ? 1 : 0, v_mean,

@@ -323,8 +323,8 @@ class _RasterizeGaussians(torch.autograd.Function):
                           c_int(BLOCK), c_int(0), iptr(ws.tile_bins), iptr(ws.sorted_ids), c_i64(ws.capacity),
                           fptr(records), c_int(0), fptr(background),
                           fptr(out_img), fptr(None), fptr(final_Ts), iptr(final_idx), fptr(None), fptr(None),
-                          c_float(0.0), fptr(None), fptr(None), c_int(0), fptr(None), fptr(None), c_int(RASTER_PPL),
-                          stream_ptr())
+                          c_float(0.0), fptr(None), fptr(None), c_int(0), fptr(None), fptr(None), fptr(None),
+                          c_float(1.0), c_int(RASTER_PPL), stream_ptr())
             ctx.ws = ws
             ctx.save_for_backward(xys, conics, colors, opacity, background, final_Ts, final_idx, records)
             out_img, final_Ts = out_img[0], final_Ts[0]
@@ -353,7 +353,7 @@ class _RasterizeGaussians(torch.autograd.Function):
                           fptr(background), fptr(final_Ts),
                           iptr(final_idx), fptr(vo), fptr(None), fptr(va), fptr(v_xy),
                           fptr(v_conic), fptr(v_colors), fptr(None), fptr(v_opacity), c_int(0), fptr(None), fptr(None),
-                          c_int(0), fptr(None), c_int(RASTER_PPL), stream_ptr())
+                          c_int(0), fptr(None), c_float(1.0), c_int(RASTER_PPL), stream_ptr())
         # ctx.ws stays: a second backward through this node (retain_graph=True, per-loss backward calls) needs the tile
         # lists again; autograd frees them with the graph
         return (v_xy, None, None, v_conic, None, v_colors, v_opacity[:, None]) + (None,) * 5
@@ -422,7 +422,7 @@ def _ws_view(ws, off, dtype, shape):
 
 def _render_fwd_stages(B, N, img_h, img_w, glob_scale, clip, means, scales, quats, opacity, colors, viewmats, intrins,
                        background, with_depth, norm_lo, cap, ws, L, out_img, out_depth, alpha, depth_norm, l1_target,
-                       l1_mask, l1_mask_c, l1_partial):
+                       l1_mask, l1_mask_c, l1_partial, l1_out, l1_scale):
     """gol_render_fwd, stage by stage (what csrc/render.hip composes), for per-stage event timing."""
     p = lambda off: ctypes.c_void_p(ws.data_ptr() + off) if off >= 0 else ctypes.c_void_p(0)
     _lib.call("gol_project_fwd", c_int(B), c_int(N), fptr(means), fptr(scales), c_float(glob_scale), fptr(quats),
@@ -436,12 +436,13 @@ def _render_fwd_stages(B, N, img_h, img_w, glob_scale, clip, means, scales, quat
               p(L.tile_bins), p(L.sorted_ids), c_i64(cap), p(L.records), c_int(1 if with_depth else 0), fptr(background),
               fptr(out_img), fptr(out_depth), p(L.final_T), p(L.final_idx), fptr(alpha), fptr(depth_norm),
               c_float(norm_lo), fptr(l1_target), fptr(l1_mask), c_int(l1_mask_c),
-              p(L.l1_sign) if l1_target is not None else ctypes.c_void_p(0), fptr(l1_partial), c_int(RASTER_PPL),
-              stream_ptr())
+              p(L.l1_sign) if l1_target is not None else ctypes.c_void_p(0), fptr(l1_partial), fptr(l1_out),
+              c_float(l1_scale), c_int(RASTER_PPL), stream_ptr())
 
 
 def _render_bwd_stages(B, N, img_h, img_w, glob_scale, means, scales, quats, opacity, viewmats, intrins, background, cap,
-                       ws, L, v_img, v_depth, v_alpha, use_l1, l1_mask, v_scale, rec, v_mean, v_scale_g, v_quat, v_opacity):
+                       ws, L, v_img, v_depth, v_alpha, use_l1, l1_mask, v_scale, v_scale_mul, rec, v_mean, v_scale_g, v_quat,
+                       v_opacity):
     """gol_render_bwd, stage by stage, for per-stage event timing."""
     p = lambda off: ctypes.c_void_p(ws.data_ptr() + off) if off >= 0 else ctypes.c_void_p(0)
     field = lambda k: ctypes.c_void_p(rec.data_ptr() + 4 * k)
@@ -453,7 +454,7 @@ def _render_bwd_stages(B, N, img_h, img_w, glob_scale, means, scales, quats, opa
               p(L.final_T), p(L.final_idx), fptr(v_img), fptr(v_depth), fptr(v_alpha), field(4), field(6), field(0),
               field(9) if use_depth else null, field(3), c_int(GRAD_RECORD), p(L.l1_sign) if use_l1 else null,
               fptr(l1_mask) if use_l1 else null, c_int(0 if (l1_mask is None or not use_l1) else l1_mask.shape[1]),
-              fptr(v_scale), c_int(0), stream_ptr())
+              fptr(v_scale), c_float(v_scale_mul), c_int(0), stream_ptr())
     _lib.call("gol_project_bwd", c_int(B), c_int(N), fptr(means), fptr(scales), c_float(glob_scale), fptr(quats),
               fptr(viewmats), fptr(intrins), p(L.cov3d), p(L.radii), p(L.conics), p(L.comp), field(4),
               field(9) if use_depth else null, field(6), null, fptr(opacity), field(3), c_int(GRAD_RECORD), fptr(v_mean),
@@ -481,6 +482,9 @@ class _RenderViews(torch.autograd.Function):
         # optional fused L1 against a target image: per-tile sums here, the sign codes (the loss gradient up to mask x
         # scalar; one byte per pixel) in the workspace
         l1_partial = torch.empty(B, T, **f) if with_l1 else None
+        # the loss value itself: sum(l1_partial) / (B*3*H*W), added up by the last workgroup of the raster launch
+        l1_out = torch.empty(1, **f) if with_l1 else None
+        l1_inv_n = 1.0 / max(B * 3 * img_h * img_w, 1)
         l1_mask_c = 0 if l1_mask is None else l1_mask.shape[1]
 
         def run(cap):
@@ -490,14 +494,14 @@ class _RenderViews(torch.autograd.Function):
                 # instrumented pass (bench.py): the same work as three ABI calls, so that events bracket each stage
                 _render_fwd_stages(B, N, img_h, img_w, glob_scale, clip_thresh, means, scales, quats, opacity, colors,
                                    viewmats, intrins, background, with_depth, depth_norm_lo, cap, ws, L, out_img,
-                                   out_depth, alpha, depth_norm, l1_target, l1_mask, l1_mask_c, l1_partial)
+                                   out_depth, alpha, depth_norm, l1_target, l1_mask, l1_mask_c, l1_partial, l1_out, l1_inv_n)
             else:
                 _lib.call("gol_render_fwd", c_int(B), c_int(N), c_int(img_h), c_int(img_w), c_float(glob_scale),
                           c_float(clip_thresh), fptr(means), fptr(scales), fptr(quats), fptr(opacity), fptr(colors),
                           fptr(viewmats), fptr(intrins), fptr(background), c_int(1 if with_depth else 0),
                           c_float(depth_norm_lo), c_i64(cap), ctypes.c_void_p(ws.data_ptr()), ctypes.byref(L),
                           fptr(out_img), fptr(out_depth), fptr(alpha), fptr(depth_norm), fptr(l1_target), fptr(l1_mask),
-                          c_int(l1_mask_c), fptr(l1_partial), stream_ptr())
+                          c_int(l1_mask_c), fptr(l1_partial), fptr(l1_out), c_float(l1_inv_n), stream_ptr())
             n_isect = _ws_view(ws, L.n_isect, torch.int32, (B,))
             pending = PLANNER.fetch(n_isect) if plan_key is not None and B > 0 else None
             return ws, L, n_isect, pending
@@ -520,8 +524,8 @@ class _RenderViews(torch.autograd.Function):
                 PLANNER.passed(plan_key)
         ctx.L, ctx.capacity = L, capacity
         ctx.cfg = (img_h, img_w, glob_scale, with_depth, depth_norm_lo, with_l1)
-        ctx.l1_inv_n = 1.0 / max(B * 3 * img_h * img_w, 1)
-        l1 = l1_partial.sum() * ctx.l1_inv_n if with_l1 else None  # == mean(|(rgb - target) * mask|)
+        ctx.l1_inv_n = l1_inv_n
+        l1 = l1_out.reshape(()) if with_l1 else None  # == mean(|(rgb - target) * mask|)
         ctx.save_for_backward(means, scales, quats, opacity, viewmats, intrins, background, ws, l1_mask)
         ctx.mark_non_differentiable(ws, n_isect)
         ctx.set_materialize_grads(False)
@@ -545,9 +549,10 @@ class _RenderViews(torch.autograd.Function):
         # fused L1: d loss / d rgb = (sign code - 1) * mask * (v_l1 / n).  The raster backward decodes the sign bytes itself
         # and adds the term to v_img (if the image has another consumer); the scalar goes in as a device value: no sync,
         # no pass over the image
+        # d loss / d l1 goes in as it is (a device scalar), 1 / n as a host scalar beside it: no kernel of its own
         v_scale = None
         if v_l1 is not None:
-            v_scale = (v_l1.to(torch.float32) * ctx.l1_inv_n).reshape(1).contiguous()
+            v_scale = v_l1.to(torch.float32).reshape(1).contiguous()
         if v_img is None and v_l1 is None:
             v_img = torch.zeros(B, 3, img_h, img_w, device=dev)
         use_depth = with_depth and v_depth is not None
@@ -567,7 +572,7 @@ class _RenderViews(torch.autograd.Function):
             with _lib.device_guard(dev):
                 _render_bwd_stages(B, N, img_h, img_w, glob_scale, means, scales, quats, opacity, viewmats, intrins,
                                    background, ctx.capacity, ws, L, v_img_c, v_depth_c, v_alpha_c, v_l1 is not None,
-                                   use_mask, v_scale, rec, v_mean, v_scale_g, v_quat, v_opacity)
+                                   use_mask, v_scale, ctx.l1_inv_n, rec, v_mean, v_scale_g, v_quat, v_opacity)
             return (v_mean, v_scale_g, v_quat, v_opacity, rec[..., :3]) + (None,) * 14
         v_color = torch.empty(B, N, 3, device=dev)  # dense copy of the records' colour gradient (written by the projection backward)
         with _lib.device_guard(dev):
@@ -575,10 +580,14 @@ class _RenderViews(torch.autograd.Function):
                       fptr(scales), fptr(quats), fptr(opacity), fptr(viewmats), fptr(intrins), fptr(background),
                       c_i64(ctx.capacity), ctypes.c_void_p(ws.data_ptr()), ctypes.byref(L), fptr(v_img_c),
                       fptr(v_depth_c), fptr(v_alpha_c), c_int(1 if v_l1 is not None else 0), fptr(use_mask),
-                      c_int(0 if use_mask is None else use_mask.shape[1]), fptr(v_scale), fptr(rec), fptr(v_mean),
+                      c_int(0 if use_mask is None else use_mask.shape[1]), fptr(v_scale), c_float(ctx.l1_inv_n), fptr(rec),
+                      fptr(v_mean),
                       fptr(v_scale_g), fptr(v_quat), fptr(v_opacity), fptr(v_color), stream_ptr())
         # (the workspace stays alive with the node: retain_graph / a second backward re-reads the tile lists)
         return (v_mean, v_scale_g, v_quat, v_opacity, v_color) + (None,) * 14
+
+
+_BLACK = {}
 
 
 class _LazyRender(dict):
@@ -608,6 +617,19 @@ class _LazyRender(dict):
         return v
 
 
+def raster_pair_counts(res):
+    """Diagnostic: [B,2] int64 = per view the (pixel, list entry) pairs a render_views result tested (entries up to each
+    pixel's final_idx) and took (alpha >= 1/255) -- gol_raster_count_pairs on the call's workspace."""
+    B, N, H, W, T = res._dims
+    ws, L = res._ws, res._L
+    counts = torch.empty(B, 2, dtype=torch.int64, device=ws.device)
+    p = lambda off: ctypes.c_void_p(ws.data_ptr() + off)
+    with _lib.device_guard(ws.device):
+        _lib.call("gol_raster_count_pairs", c_int(B), c_int(N), c_int(H), c_int(W), p(L.tile_bins), p(L.sorted_ids),
+                  c_i64(res._cap), p(L.records), p(L.final_idx), ptr(counts, torch.int64), stream_ptr())
+    return counts
+
+
 def render_views(means, scales, quats, opacity, colors, viewmats, intrins, img_h, img_w,
                  background=None, glob_scale=1.0, clip_thresh=0.1, with_depth=True, capacity=None, depth_norm_lo=0.05,
                  l1_target=None, l1_mask=None, raw_depth=True):
@@ -635,7 +657,9 @@ def render_views(means, scales, quats, opacity, colors, viewmats, intrins, img_h
     viewmats = _f32c(viewmats).reshape(B, viewmats[0].numel() if B else 12)[:, :12].contiguous()
     intrins = _f32c(intrins).reshape(B, 4)
     if background is None:
-        background = torch.zeros(3, device=dev)  # render_gsplat.py:38-39
+        background = _BLACK.get(dev)   # render_gsplat.py:38-39 (one constant per device: no fill kernel per call)
+        if background is None:
+            background = _BLACK[dev] = torch.zeros(3, device=dev)
     background = _f32c(background)
     T = _tiles(img_h, img_w)
     key = (B, N, img_h, img_w, dev.index)

@@ -154,9 +154,12 @@ int gol_bin_sort(int B, int N, const float* xys, const float* depths, const int3
  *   (l1_mask[B,l1_mask_c,H,W], l1_mask_c = 1 or 3, or NULL) the forward also writes l1_sign[B,H,W], ONE BYTE per pixel
  *   holding sign((rgb_c - target_c) * mask_c) + 1 of channel c in bits 2c..2c+1, and l1_partial[B, tiles] = per-tile sums
  *   of |(rgb - target) * mask| (tiles = ceil(W/16) * ceil(H/16); loss = sum(l1_partial) / (B*3*H*W)).
+ *   l1_out (NULL = the caller adds l1_partial up): l1_out[0] = l1_scale * sum(l1_partial), by a one-workgroup kernel
+ *   enqueued behind the raster launch (fixed summation order: deterministic).
  *   The backward's upstream image gradient is  v_out_img (NULL = 0)  +  (code_c - 1) * mask_c * v_img_scale[0]  of
- *   v_sign[B,H,W] (NULL = none; v_sign_mask[B,v_sign_mask_c,H,W] or NULL = 1; v_img_scale device scalar, NULL = 1), so
- *   passing v_sign = l1_sign, v_sign_mask = l1_mask, v_img_scale = d loss_total / d l1 / (B*3*H*W) back-propagates the
+ *   v_sign[B,H,W] (NULL = none; v_sign_mask[B,v_sign_mask_c,H,W] or NULL = 1; v_img_scale device scalar, NULL = 1, times the
+ *   host scalar v_img_scale_mul), so passing v_sign = l1_sign, v_sign_mask = l1_mask, v_img_scale = d loss_total / d l1
+ *   (the autograd gradient of the loss value, as it is) and v_img_scale_mul = 1 / (B*3*H*W) back-propagates the
  *   loss without the two extra passes over the image a separate loss kernel needs; at least one of v_out_img / v_sign.
  * pixels_per_lane (fwd and bwd): the wave footprint.  2 = two waves per 16x16 tile, 16x8 pixels each, two pixels per lane
  *   (fewest instructions per pixel: launches that fill the chip); 1 = four waves per tile, 8x8 pixels each (~9-17 % more
@@ -176,14 +179,21 @@ int gol_rasterize_fwd(int B, int N, int img_h, int img_w, int block, int planar,
                       const float* background, float* out_img,
                       float* out_extra, float* final_Ts, int32_t* final_idx, float* out_alpha,
                       float* out_extra_norm, float norm_lo, const float* l1_target, const float* l1_mask, int l1_mask_c,
-                      uint8_t* l1_sign, float* l1_partial, int pixels_per_lane, void* stream);
+                      uint8_t* l1_sign, float* l1_partial, float* l1_out, float l1_scale, int pixels_per_lane,
+                      void* stream);
 int gol_rasterize_bwd(int B, int N, int img_h, int img_w, int block, int planar, const int32_t* tile_bins,
                       const int32_t* sorted_ids, int64_t capacity, const float* records, int with_extra,
                       const float* background, const float* final_Ts,
                       const int32_t* final_idx, const float* v_out_img, const float* v_out_extra,
                       const float* v_out_alpha, float* v_xy, float* v_conic, float* v_colors,
                       float* v_extra, float* v_opacity, int grad_stride, const uint8_t* v_sign, const float* v_sign_mask,
-                      int v_sign_mask_c, const float* v_img_scale, int pixels_per_lane, void* stream);
+                      int v_sign_mask_c, const float* v_img_scale, float v_img_scale_mul, int pixels_per_lane,
+                      void* stream);
+/* Diagnostic (bench.py's algorithmic roofline of the raster kernels): counts[B,2] (uint64) = per view the number of
+ * (pixel, list entry) pairs up to the pixel's final_idx ("tested") and of those with alpha >= 1/255 ("taken" = composited),
+ * from the state a planar gol_rasterize_fwd left (tile_bins, sorted_ids, records, final_idx). */
+int gol_raster_count_pairs(int B, int N, int img_h, int img_w, const int32_t* tile_bins, const int32_t* sorted_ids,
+                           int64_t capacity, const float* records, const int32_t* final_idx, uint64_t* counts, void* stream);
 /* What pixels_per_lane = 0 means for the forward of a launch of B views (1 for B <= 2, else 2). */
 int gol_raster_plan(int B, int* fwd_pixels_per_lane);
 
@@ -198,9 +208,10 @@ int gol_raster_plan(int B, int* fwd_pixels_per_lane);
  * gol_bin_sort), radii[B,N], final_T / final_idx[B,H,W], sorted_ids[B,capacity], tile_bins[B,T,2] there.
  * The forward leaves everything the backward needs in the workspace: keep it (and the inputs) until gol_render_bwd.
  *   out_img[B,3,H,W]; out_alpha[B,H,W] = 1 - final_T; with_depth: out_depth_norm[B,H,W] = depth / clamp(alpha, norm_lo, 1)
- *   and optionally out_depth[B,H,W] (NULL = skip); l1_target / l1_mask / l1_partial[B,T] as for gol_rasterize_fwd.
+ *   and optionally out_depth[B,H,W] (NULL = skip); l1_target / l1_mask / l1_partial[B,T] / l1_out (NULL = partial sums
+ *   only) / l1_scale as for gol_rasterize_fwd.
  *   bwd: v_img[B,3,H,W] / v_depth[B,H,W] (w.r.t. the UN-normalised depth image) / v_alpha[B,H,W] may be NULL;
- *   use_l1_sign != 0 adds the fused L1's gradient (v_img_scale = device scalar d loss / d l1 / (B*3*H*W));
+ *   use_l1_sign != 0 adds the fused L1's gradient (v_img_scale = device scalar d loss / d l1, v_img_scale_mul = 1 / (B*3*H*W));
  *   grad_records[B,N,GOL_GRAD_RECORD] scratch; v_colors[B,N,3] (may be NULL): d loss / d colour as a dense array (it is
  *   also the first three floats of every record).
  * ---------------------------------------------------------------------------------------- */
@@ -214,13 +225,13 @@ int gol_render_fwd(int B, int N, int img_h, int img_w, float glob_scale, float c
                    const float* viewmats, const float* intrins, const float* background, int with_depth, float norm_lo,
                    int64_t capacity, void* workspace, const gol_render_ws* layout, float* out_img, float* out_depth,
                    float* out_alpha, float* out_depth_norm, const float* l1_target, const float* l1_mask, int l1_mask_c,
-                   float* l1_partial, void* stream);
+                   float* l1_partial, float* l1_out, float l1_scale, void* stream);
 int gol_render_bwd(int B, int N, int img_h, int img_w, float glob_scale, const float* means, const float* scales,
                    const float* quats, const float* opacity, const float* viewmats, const float* intrins,
                    const float* background, int64_t capacity, void* workspace, const gol_render_ws* layout,
                    const float* v_img, const float* v_depth, const float* v_alpha, int use_l1_sign, const float* l1_mask,
-                   int l1_mask_c, const float* v_img_scale, float* grad_records, float* v_mean, float* v_scale,
-                   float* v_quat, float* v_opacity, float* v_colors, void* stream);
+                   int l1_mask_c, const float* v_img_scale, float v_img_scale_mul, float* grad_records, float* v_mean,
+                   float* v_scale, float* v_quat, float* v_opacity, float* v_colors, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Fused RGCA shading tail.  Replaces the chain of ATen kernels in PrimDecoder.forward after the

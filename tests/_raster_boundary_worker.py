@@ -86,7 +86,7 @@ def main(n_views):
                       iptr(ws.tile_bins), iptr(ws.sorted_ids), c_i64(ws.capacity), fptr(records), c_int(1),
                       fptr(bgd), fptr(out_img), fptr(None), fptr(fT), iptr(fidx), fptr(alpha),
                       fptr(dnorm), c_float(0.05), fptr(d_tgt), fptr(None), c_int(0), ptr(sign, torch.uint8), fptr(part),
-                      c_int(PPL), stream_ptr())
+                      fptr(None), c_float(1.0), c_int(PPL), stream_ptr())
             rec = torch.zeros(1, N, 16, device=dev)
             field = lambda k: ctypes.c_void_p(rec.data_ptr() + 4 * k)
             vsc = torch.full((1,), scale, device=dev)
@@ -94,7 +94,7 @@ def main(n_views):
                       iptr(ws.tile_bins), iptr(ws.sorted_ids), c_i64(ws.capacity), fptr(records), c_int(0),
                       fptr(bgd), fptr(fT), iptr(fidx), fptr(None), fptr(None), fptr(None),
                       field(4), field(6), field(0), fptr(None), field(3), c_int(16), ptr(sign, torch.uint8), fptr(None),
-                      c_int(0), fptr(vsc), c_int(PPL), stream_ptr())
+                      c_int(0), fptr(vsc), c_float(1.0), c_int(PPL), stream_ptr())
             torch.cuda.synchronize()
             n_isect_hip += int(ws.n_isect[0])
             Th = fT[0].cpu()
