@@ -388,9 +388,19 @@ __global__ __launch_bounds__(64 * Pix<PPL>::kWaves) void raster_fwd_kernel(
 __global__ __launch_bounds__(1024) void l1_sum_kernel(int n, const float* __restrict__ l1_partial, float scale,
                                                       float* __restrict__ l1_out) {
   __shared__ float s_w[16];
-  float acc = 0.f;
-  for (int i = threadIdx.x; i < n; i += 1024) acc += l1_partial[i];
-  const float ws = gol_wave_sum_to_lane63(acc);
+  // 16-byte loads, four of them in flight per lane (a plain strided loop waits for every load: 33 us for 86 k floats)
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  const int n4 = n >> 2;
+  const float4* p4 = reinterpret_cast<const float4*>(l1_partial);
+  int i = threadIdx.x;
+  for (; i + 3 * 1024 < n4; i += 4 * 1024) {
+    const float4 v0 = p4[i], v1 = p4[i + 1024], v2 = p4[i + 2048], v3 = p4[i + 3072];
+    a0 += (v0.x + v0.y) + (v0.z + v0.w); a1 += (v1.x + v1.y) + (v1.z + v1.w);
+    a2 += (v2.x + v2.y) + (v2.z + v2.w); a3 += (v3.x + v3.y) + (v3.z + v3.w);
+  }
+  for (; i < n4; i += 1024) { const float4 v = p4[i]; a0 += (v.x + v.y) + (v.z + v.w); }
+  if ((int)threadIdx.x < (n & 3)) a1 += l1_partial[4 * n4 + threadIdx.x];
+  const float ws = gol_wave_sum_to_lane63((a0 + a1) + (a2 + a3));
   if ((threadIdx.x & 63) == 63) s_w[threadIdx.x >> 6] = ws;
   __syncthreads();
   if (threadIdx.x == 0) {

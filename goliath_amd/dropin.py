@@ -75,9 +75,10 @@ def patch_urhand(urhand_module=None, mesh_render_layer=False):
 
     The module-level name `RenderLayer` (urhand.py:43) is LEFT ALONE by default: AutoEncoder.__init__ resolves the same name
     for the model's final, differentiable textured render (`self.renderer`, urhand.py:684, called with
-    edge_grad=self.training), which needs drtk's edge-gradient estimator -- gol_mesh_raster is forward-only.
-    mesh_render_layer=True rebinds it to goliath_amd.meshraster.RenderLayer anyway (a stack without drtk: inference /
-    visualisation only; a call whose vertices require a gradient raises).  Returns the patched module."""
+    edge_grad=self.training) -- with drtk installed that stays drtk's.  mesh_render_layer=True rebinds it to
+    goliath_amd.meshraster.RenderLayer (a stack without drtk): same constructor / forward / output dict, differentiable
+    w.r.t. texture and vertices incl. an edge-gradient estimator (round 4) whose conventions are stated and checked against
+    a supersampled render, not against drtk (absent: parity unpinned).  Returns the patched module."""
     from . import meshraster, shadowmap, urhand
 
     if urhand_module is None:
