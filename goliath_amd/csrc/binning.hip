@@ -483,32 +483,40 @@ __device__ __forceinline__ void sort_tile_regs(const uint64_t* __restrict__ keys
 // depth is not a positive finite float: the caller falls back to the compare-exchange network.
 constexpr int kBucketMaxB = 1024, kBucketFull = 48;
 
-template <int MAXN>
+// IN_REGS: the keys stay in registers between the phases (KPT x 2 VGPRs; the tile kernel's 8 keys per lane); !IN_REGS: every
+// phase re-reads them from global memory (L2) in a rolled loop -- the long-list kernel's 16 keys per lane of a 1024-thread
+// workgroup (128-VGPR budget) spilled 1.5 KB per lane when unrolled and held.
+template <int MAXN, int NT = 256, int NB = kBucketMaxB, bool IN_REGS = true>
 __device__ __forceinline__ bool bucket_sort_tile(const uint64_t* __restrict__ keys, int32_t* __restrict__ out, int n,
                                                  uint64_t* __restrict__ lds, int tid) {
-  constexpr int KPT = MAXN / 256;
+  constexpr int KPT = MAXN / NT, BPT = NB / NT;   // keys / buckets per thread
+  static_assert(MAXN % NT == 0 && NB % NT == 0 && NT % 64 == 0, "bucket_sort_tile: sizes must divide");
   uint64_t* s_bk = lds;
-  uint32_t* s_start = reinterpret_cast<uint32_t*>(lds + MAXN);                // [kBucketMaxB + 1]
-  uint32_t* s_mmu = s_start + kBucketMaxB + 1;                                // depth bits: [0] = min, [1] = max
-  uint32_t* s_full = s_start + kBucketMaxB + 3;
+  uint32_t* s_start = reinterpret_cast<uint32_t*>(lds + MAXN);                // [NB + 1]
+  uint32_t* s_mmu = s_start + NB + 1;                                         // depth bits: [0] = min, [1] = max
+  uint32_t* s_full = s_start + NB + 3;
+  uint32_t* s_wave = s_start + NB + 4;                                        // [NT / 64]
   const int lane = tid & 63;
   int nb = n < 32 ? 32 : n;
-  if (nb > kBucketMaxB) nb = kBucketMaxB;
+  if (nb > NB) nb = NB;
   // ---- load, depth range (positive finite floats order like their bit patterns) ----
-  uint64_t k[KPT];
+  constexpr int UNR = IN_REGS ? KPT : 1;
+  uint64_t k[IN_REGS ? KPT : 1];
+  auto key_at = [&](int r) -> uint64_t { if constexpr (IN_REGS) return k[r]; else return keys[tid + NT * r]; };
   uint32_t bmin = 0xffffffffu, bmax = 0u;
-#pragma unroll
+#pragma unroll UNR
   for (int r = 0; r < KPT; ++r) {
-    const int i = tid + 256 * r;
-    k[r] = 0;
+    const int i = tid + NT * r;
+    if (IN_REGS) k[IN_REGS ? r : 0] = 0;
     if (i < n) {
-      k[r] = keys[i];
-      const uint32_t db = (uint32_t)(k[r] >> 32);
+      const uint64_t kk = keys[i];
+      if (IN_REGS) k[IN_REGS ? r : 0] = kk;
+      const uint32_t db = (uint32_t)(kk >> 32);
       bmin = min(bmin, db); bmax = max(bmax, db);
     }
   }
   if (tid == 0) { s_mmu[0] = 0xffffffffu; s_mmu[1] = 0u; *s_full = 0u; }
-  for (int t = tid; t <= nb; t += 256) s_start[t] = 0u;
+  for (int t = tid; t <= nb; t += NT) s_start[t] = 0u;
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) {
     bmin = min(bmin, (uint32_t)__shfl_xor((int)bmin, off, 64));
@@ -527,17 +535,17 @@ __device__ __forceinline__ bool bucket_sort_tile(const uint64_t* __restrict__ ke
     const int b = (int)((d - lo) * scale);
     return b < 0 ? 0 : (b > nb - 1 ? nb - 1 : b);
   };
-#pragma unroll
+#pragma unroll UNR
   for (int r = 0; r < KPT; ++r)
-    if (tid + 256 * r < n) atomicAdd(&s_start[bucket_of(k[r])], 1u);
+    if (tid + NT * r < n) atomicAdd(&s_start[bucket_of(key_at(r))], 1u);
   __syncthreads();
-  // ---- exclusive scan of the nb bucket counts (4 consecutive buckets per thread), in place ----
+  // ---- exclusive scan of the nb bucket counts (BPT consecutive buckets per thread), in place ----
   {
-    uint32_t c[4];
+    uint32_t c[BPT];
     uint32_t sum = 0, worst = 0;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int t = tid * 4 + q;
+    for (int q = 0; q < BPT; ++q) {
+      const int t = tid * BPT + q;
       c[q] = t < nb ? s_start[t] : 0u;
       sum += c[q];
       worst = max(worst, c[q]);
@@ -549,38 +557,40 @@ __device__ __forceinline__ bool bucket_sort_tile(const uint64_t* __restrict__ ke
       const uint32_t u = __shfl_up(incl, off, 64);
       if (lane >= off) incl += u;
     }
-    __shared__ uint32_t s_wave[4];
     if (lane == 63) s_wave[tid >> 6] = incl;
     __syncthreads();
     if (*s_full) return false;
     uint32_t base = incl - sum;
     for (int w = 0; w < (tid >> 6); ++w) base += s_wave[w];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int t = tid * 4 + q;
+    for (int q = 0; q < BPT; ++q) {
+      const int t = tid * BPT + q;
       if (t < nb) s_start[t] = base;
       base += c[q];
     }
   }
   __syncthreads();
   // ---- place the keys in bucket order: the bucket's start is its cursor; afterwards start[b] = END of bucket b ----
-#pragma unroll
+#pragma unroll UNR
   for (int r = 0; r < KPT; ++r)
-    if (tid + 256 * r < n) s_bk[atomicAdd(&s_start[bucket_of(k[r])], 1u)] = k[r];
+    if (tid + NT * r < n) { const uint64_t kk = key_at(r); s_bk[atomicAdd(&s_start[bucket_of(kk)], 1u)] = kk; }
   __syncthreads();
   // ---- rank inside the bucket: the number of smaller keys there (ids are distinct: no equal keys) ----
-#pragma unroll
+#pragma unroll UNR
   for (int r = 0; r < KPT; ++r) {
-    if (tid + 256 * r < n) {
-      const int b = bucket_of(k[r]);
+    if (tid + NT * r < n) {
+      const uint64_t kk = key_at(r);
+      const int b = bucket_of(kk);
       const int p0 = b ? (int)s_start[b - 1] : 0, p1 = (int)s_start[b];
       int rank = 0;
-      for (int p = p0; p < p1; ++p) rank += s_bk[p] < k[r] ? 1 : 0;
-      out[p0 + rank] = (int32_t)(uint32_t)k[r];
+      for (int p = p0; p < p1; ++p) rank += s_bk[p] < kk ? 1 : 0;
+      out[p0 + rank] = (int32_t)(uint32_t)kk;
     }
   }
   return true;
 }
+// 64-bit words of LDS bucket_sort_tile<MAXN, NT, NB> needs
+constexpr int bucket_sort_lds_words(int maxn, int nt, int nb) { return maxn + (nb + 4 + nt / 64 + 1) / 2 + 1; }
 
 
 // pass 4a: one workgroup per tile; lists of up to kSmallN entries are sorted here (20 KB of LDS, 93 registers),
@@ -614,7 +624,7 @@ __device__ __forceinline__ bool tile_range(int T, int64_t capacity, int32_t* __r
 __global__ __launch_bounds__(256) void sort_kernel(int T, int64_t capacity, int32_t* __restrict__ tile_bins,
                                                    uint64_t* __restrict__ isect_keys,
                                                    int32_t* __restrict__ sorted_ids, int32_t* __restrict__ queue) {
-  __shared__ uint64_t lds_keys[kSmallN + kBucketMaxB / 2 + 8];
+  __shared__ uint64_t lds_keys[bucket_sort_lds_words(kSmallN, 256, kBucketMaxB)];
   const int b = blockIdx.y, t = blockIdx.x, tid = threadIdx.x;
   int start, n;
   if (!tile_range(T, capacity, tile_bins, b, t, tid, true, start, n)) return;
@@ -656,39 +666,36 @@ __global__ __launch_bounds__(256) void sort_kernel(int T, int64_t capacity, int3
   }
 }
 
-// pass 4b / 4c: the queued lists (a fixed grid of workgroups per view walks its queue).  BIG = false: kSmallN < n <=
-// kMidN; BIG = true: everything longer.
-template <bool BIG>
-__global__ __launch_bounds__(256) void sort_queue_kernel(int T, int64_t capacity, int32_t* __restrict__ tile_bins,
-                                                         uint64_t* __restrict__ isect_keys,
-                                                         int32_t* __restrict__ sorted_ids,
-                                                         const int32_t* __restrict__ queue) {
-  constexpr int MAXN = BIG ? kSortLds : kMidN;
-  __shared__ uint64_t lds_keys[MAXN + kBucketMaxB / 2 + 8];   // the keys + the bucket offsets
+// pass 4b: the queued long lists (a fixed grid of workgroups per view walks the view's queue).  Round 4: 1024 threads and
+// up to 16384 keys in LDS (128 KB + 4096 buckets: one workgroup per CU) -- at 1 M Gaussians a third of the tiles hold more than
+// 2048 entries and many more than 4096; the 256-thread / 4096-key version with its 16-keys-per-lane network fallback in
+// the same kernel (468 VGPRs: one wave per SIMD) took 0.52 ms per 8 views there, as long as the scatter pass.  The fallback
+// for what the bucket sort declines (a bucket of > 48 entries, a non-positive depth) or cannot hold (> 16384 entries) is
+// the network straight on global memory: slow, rare.
+constexpr int kBigN = 16384, kBigThreads = 1024, kBigBuckets = 4096;
+
+__global__ __launch_bounds__(kBigThreads) void sort_big_kernel(int T, int64_t capacity, int32_t* __restrict__ tile_bins,
+                                                               uint64_t* __restrict__ isect_keys,
+                                                               int32_t* __restrict__ sorted_ids,
+                                                               const int32_t* __restrict__ queue) {
+  extern __shared__ uint64_t lds_big[];
   const int b = blockIdx.y, tid = threadIdx.x;
   const int32_t* q = queue + (size_t)b * T;
-  const int count = min(q[BIG ? 1 : 0], queue_cap(T, BIG ? 1 : 0));
+  const int count = min(q[1], queue_cap(T, 1));
   for (int w = blockIdx.x; w < count; w += gridDim.x) {
-    const int t = q[BIG ? T - 1 - w : 2 + w];
+    const int t = q[T - 1 - w];
     int start, n;
     __syncthreads();  // the previous list is done with the LDS
     if (!tile_range(T, capacity, tile_bins, b, t, tid, false, start, n)) continue;
     uint64_t* keys = isect_keys + (size_t)b * capacity + start;
     int32_t* out = sorted_ids + (size_t)b * capacity + start;
-    if (n <= MAXN) {
-      if (bucket_sort_tile<MAXN>(keys, out, n, lds_keys, tid)) continue;
+    if (n <= kBigN) {
+      if (bucket_sort_tile<kBigN, kBigThreads, kBigBuckets, false>(keys, out, n, lds_big, tid)) continue;
       __syncthreads();
     }
-    if (!BIG) {
-      sort_tile_regs<8>(keys, out, n, lds_keys, tid);
-    } else if (n <= 4096) {
-      sort_tile_regs<16>(keys, out, n, lds_keys, tid);
-    } else {
-      // rare: a tile covered by > 4096 Gaussians; the network straight on global memory
-      // (one workgroup = one CU, so __syncthreads() orders its own global stores and loads)
-      bitonic_sort(keys, n, tid, 256);
-      for (int i = tid; i < n; i += 256) out[i] = (int32_t)(uint32_t)keys[i];
-    }
+    // (one workgroup = one CU, so __syncthreads() orders its own global stores and loads)
+    bitonic_sort(keys, n, tid, kBigThreads);
+    for (int i = tid; i < n; i += kBigThreads) out[i] = (int32_t)(uint32_t)keys[i];
   }
 }
 
@@ -698,7 +705,7 @@ __global__ __launch_bounds__(256) void sort_queue_kernel(int T, int64_t capacity
 // never sees a limit that is not in effect yet -- at worst it repeats the idempotent call.  Returns false on failure.
 bool ensure_lds_limit(int which, const void* fn, size_t bytes) {
   constexpr int kMaxDev = 64;
-  static std::atomic<size_t> granted[2][kMaxDev];
+  static std::atomic<size_t> granted[3][kMaxDev];
   int dev = 0;
   const bool cached = hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < kMaxDev;
   if (cached) {
@@ -783,7 +790,11 @@ extern "C" int gol_bin_sort(int B, int N, const float* xys, const float* depths,
       scatter_kernel<<<dim3(gol_cdiv(N, 256), B), 256, 0, s>>>(a, capacity, tile_bins, isect_keys);
     }
     sort_kernel<<<dim3(T, B), 256, 0, s>>>(T, capacity, tile_bins, isect_keys, sorted_ids, tile_count);
-    sort_queue_kernel<true><<<dim3(256, B), 256, 0, s>>>(T, capacity, tile_bins, isect_keys, sorted_ids, tile_count);
+    {
+      const size_t lds = sizeof(uint64_t) * (size_t)bucket_sort_lds_words(kBigN, kBigThreads, kBigBuckets);
+      GOL_REQUIRE(ensure_lds_limit(2, (const void*)sort_big_kernel, lds), "cannot raise the dynamic LDS limit");
+      sort_big_kernel<<<dim3(256, B), kBigThreads, lds, s>>>(T, capacity, tile_bins, isect_keys, sorted_ids, tile_count);
+    }
   }
   GOL_CHECK_LAUNCH();
   return GOL_OK;

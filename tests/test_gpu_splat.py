@@ -103,10 +103,12 @@ def test_bin_sort_matches_oracle_exactly():
         assert all(g in it for g in sub), t  # order-preserving subsequence
 
 
-@pytest.mark.parametrize("N", [2, 63, 200, 256, 257, 500, 513, 1000, 1024, 1025, 2000, 2048, 2049, 3500, 4096, 6000])
+@pytest.mark.parametrize("N", [2, 63, 200, 256, 257, 500, 513, 1000, 1024, 1025, 2000, 2048, 2049, 3500, 4096, 4097, 6000,
+                               12000, 16384, 16385, 20000])
 def test_bin_sort_one_tile_every_size_class(N):
-    """All Gaussians on one tile: every size class of the per-tile sort (1/2/4/8 keys per thread in registers,
-    the LDS network up to 4096 keys, the global-memory path beyond), including lengths around the class borders."""
+    """All Gaussians on one tile: every size class of the per-tile sort (1/2/4/8 keys per thread in registers, the bucket
+    sorts of the tile kernel (<= 2048) and of the long-list kernel (<= 16384 keys in LDS, round 4), the global-memory
+    network beyond, and -- through the 100 equal depths -- the decline-and-fall-back path), incl. the class borders."""
     from goliath_amd import splat
     from oracle import cref
 
