@@ -1020,7 +1020,8 @@ def run_rgca(args, D, views, scaling, workload, overlap, micro=None, extras=True
         res["roofline"] = make_roofline(dom, kernels_ms[dom], views_per_launch, N, I, P, mip_bytes, pairs_taken)
         # every streaming call beside it: algorithmic GB/s, fraction of the 8 TB/s spec, PMC traffic / algorithmic bytes
         per = {}
-        tr = _stamped("traffic.json")
+        # PMC traffic of the layout that was run (the default random-permutation slab, or the coherent / smooth one)
+        tr = _stamped("traffic_coherent_smooth.json" if (args.coherent_uv and args.smooth_normals) else "traffic.json")
         for k, ms in kernels_ms.items():
             try:
                 alg = views_per_launch * algorithmic_bytes(k, N, I, P, mip_bytes)
@@ -1045,7 +1046,7 @@ def _release():
         torch.cuda.empty_cache()
 
 
-def _brief(res, keys=("value", "unit", "ms_per_step", "scaling", "kernels_ms_per_call", "roofline", "windows")):
+def _brief(res, keys=("value", "unit", "ms_per_step", "scaling", "kernels_ms_per_call", "roofline", "hbm_per_call", "windows")):
     """A secondary entry of the main line: the measurement without the boiler-plate fields."""
     out = {k: res[k] for k in keys if k in res}
     out["metric"] = res.get("metric")

@@ -18,8 +18,8 @@ CALLS = {  # kernel-name prefix -> ABI call
     "shade_fwd_kernel": "gol_shade_fwd", "shade_bwd_kernel": "gol_shade_bwd", "sum_views_kernel": "gol_shade_bwd", "project_fwd_kernel": "gol_project_fwd",
     "project_bwd_kernel": "gol_project_bwd", "count_lds_kernel": "gol_bin_sort", "count_kernel": "gol_bin_sort",
     "scan_kernel": "gol_bin_sort", "scatter_lds_kernel": "gol_bin_sort", "scatter_kernel": "gol_bin_sort",
-    "sort_kernel": "gol_bin_sort", "sort_queue_kernel": "gol_bin_sort", "bin_": "gol_bin_sort",
-    "raster_fwd_kernel": "gol_rasterize_fwd", "splat_pack_kernel": "gol_splat_pack",
+    "sort_kernel": "gol_bin_sort", "sort_queue_kernel": "gol_bin_sort", "sort_big_kernel": "gol_bin_sort", "bin_": "gol_bin_sort",
+    "raster_fwd_kernel": "gol_rasterize_fwd", "l1_sum_kernel": "gol_rasterize_fwd", "splat_pack_kernel": "gol_splat_pack",
     "raster_bwd_kernel": "gol_rasterize_bwd", "l1_kernel<false>": "gol_l1_fwd", "l1_kernel<true>": "gol_l1_bwd",
 }
 
@@ -28,7 +28,7 @@ def call_of(kernel):
     return next((c for p, c in CALLS.items() if kernel.startswith(p)), None)
 
 
-def main(tag):
+def main(tag, traffic_name="traffic.json", only_traffic=False):
     src = os.path.join(ROOT, "gpurun_out", tag)
     dst = os.path.join(ROOT, "profiles")
     sha = open(os.path.join(src, "csrc_sha16.txt")).read().strip()
@@ -48,9 +48,9 @@ def main(tag):
                 traffic[c] = traffic.get(c, 0.0) + 1024.0 * (2.0 * float(r["FETCH_SIZE"]) + float(r["WRITE_SIZE"]))
         traffic["_stamp"] = dict(stamp, note="bytes per 8-view launch = 2*FETCH_SIZE + WRITE_SIZE (KiB counters); counts "
                                               "L2->fabric requests, i.e. includes Infinity-Cache hits and memory-side atomics")
-        json.dump(traffic, open(os.path.join(dst, "traffic.json"), "w"), indent=1)
+        json.dump(traffic, open(os.path.join(dst, traffic_name), "w"), indent=1)
     spath = os.path.join(src, "pmc_sq.csv")
-    if os.path.exists(spath):
+    if os.path.exists(spath) and not only_traffic:
         valu = {}
         for r in csv.DictReader(open(spath)):
             valu[r["kernel"]] = {k: float(v) for k, v in r.items()
@@ -92,5 +92,7 @@ def secondary(tag):
 if __name__ == "__main__":
     if sys.argv[1] == "--secondary":
         secondary(sys.argv[2])
+    elif sys.argv[1] == "--coherent-smooth":   # FETCH / WRITE of the micro1 command with --coherent-uv --smooth-normals
+        main(sys.argv[2], traffic_name="traffic_coherent_smooth.json", only_traffic=True)
     else:
         main(sys.argv[1])
