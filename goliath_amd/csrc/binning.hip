@@ -20,7 +20,9 @@
 //     finds its place inside its bucket by counting the smaller keys there (1-3 compares on average) -- ~50
 //     instructions per key instead of the ~330 of the 55-step bitonic network of a 1024-key list, whose 2 x 55
 //     ds_bpermute exchanges per key kept the LDS crossbar busy for 0.32 ms per 8 views.  Lists with pathological
-//     depth clustering (a bucket of more than 48 entries) and lists of more than 2048 entries fall back to the network.
+//     depth clustering (a bucket of more than 48 entries) fall back to the network;
+//   * round 4: the tile scan is one pass (counts staged in LDS); lists of more than 2048 entries are queued for a 1024-thread
+//     kernel that bucket-sorts up to 16384 keys in LDS (a third of the tiles at 1 M Gaussians).
 // Traffic: 8 B written + 8 B read + 4 B written per intersection, everything else stays in LDS.
 #include <atomic>
 #include <cstdlib>
@@ -334,14 +336,13 @@ __global__ __launch_bounds__(1024) void scan_kernel(int T, const int32_t* __rest
     if (tid == 0) n_isect[b] = carry_s;
   }
   __syncthreads();   // (everyone is done with the counts)
-  // the counts are consumed: their buffer becomes the view's two queues of long tile lists (sort_kernel); words 0, 1 = lengths
-  if (tid < 2 && tid < T) const_cast<int32_t*>(cnt)[tid] = 0;
+  // the counts are consumed: their buffer becomes the view's queue of long tile lists (sort_kernel); word 0 = its length
+  if (tid == 0) const_cast<int32_t*>(cnt)[0] = 0;
 }
 
 // pass 4: one workgroup per tile sorts its list.  Bitonic network in the "all-ascending" form
 // (first sub-step of each stage pairs i with i ^ (2k-1)), so lists of any length work without
 // padding: a partner index >= n stands for +inf and the exchange is skipped.
-constexpr int kSortLds = 4096;  // keys staged in LDS (32 KiB); longer lists sort in global memory
 
 template <typename KeyPtr>
 __device__ __forceinline__ void bitonic_sort(KeyPtr keys, int n, int tid, int nthreads) {
@@ -593,16 +594,13 @@ __device__ __forceinline__ bool bucket_sort_tile(const uint64_t* __restrict__ ke
 constexpr int bucket_sort_lds_words(int maxn, int nt, int nb) { return maxn + (nb + 4 + nt / 64 + 1) / 2 + 1; }
 
 
-// pass 4a: one workgroup per tile; lists of up to kSmallN entries are sorted here (20 KB of LDS, 93 registers),
-// longer ones are queued for the queue kernel below (16+ keys per lane: 256 registers).  The queues live in the tile-count buffer, which is free once the scan has consumed it:
-//   q[0] = number of mid lists (ids at q[2 + i]), q[1] = number of big lists (ids at q[T - 1 - i]); scan_kernel zeroes
-//   both; each queue owns half of the T - 2 slots, a list that finds its queue full is sorted in place in global memory.
-constexpr int kSmallN = 2048, kMidN = 2048;   // (a middle class of its own -- 1024 < n <= 2048 queued -- measured slower)
+// pass 4a: one workgroup per tile; lists of up to kSmallN entries are sorted here (20 KB of LDS, 46 registers), longer ones
+// are queued for sort_big_kernel below.  The queue of a view lives in its tile-count buffer, which is free once the scan has
+// consumed it: q[0] = number of queued tiles (scan_kernel zeroes it), their indices at q[1 ...]; a list that finds the queue
+// full (only when all but one tile of a view are long) is sorted in place in global memory.
+constexpr int kSmallN = 2048;   // (a middle class of its own -- 1024 < n <= 2048 queued -- measured slower)
 
-__device__ __forceinline__ int queue_cap(int T, int big) {
-  const int total = T > 2 ? T - 2 : 0;
-  return big ? total - total / 2 : total / 2;
-}
+__device__ __forceinline__ int queue_cap(int T) { return T > 1 ? T - 1 : 0; }
 
 __device__ __forceinline__ bool tile_range(int T, int64_t capacity, int32_t* __restrict__ tile_bins, int b, int t, int tid,
                                            bool clamp, int& start, int& n) {
@@ -636,12 +634,11 @@ __global__ __launch_bounds__(256) void sort_kernel(int T, int64_t capacity, int3
   }
   if (n > kSmallN) {
     __shared__ int32_t s_ok;
-    const int big = n > kMidN ? 1 : 0;
     if (tid == 0) {
       int32_t* q = queue + (size_t)b * T;
-      const int cap = queue_cap(T, big);
-      const int slot = cap > 0 ? atomicAdd(q + big, 1) : 0;
-      if (slot < cap) q[big ? T - 1 - slot : 2 + slot] = t;
+      const int cap = queue_cap(T);
+      const int slot = cap > 0 ? atomicAdd(q, 1) : 0;
+      if (slot < cap) q[1 + slot] = t;
       s_ok = slot < cap;
     }
     __syncthreads();
@@ -681,9 +678,9 @@ __global__ __launch_bounds__(kBigThreads) void sort_big_kernel(int T, int64_t ca
   extern __shared__ uint64_t lds_big[];
   const int b = blockIdx.y, tid = threadIdx.x;
   const int32_t* q = queue + (size_t)b * T;
-  const int count = min(q[1], queue_cap(T, 1));
+  const int count = min(q[0], queue_cap(T));
   for (int w = blockIdx.x; w < count; w += gridDim.x) {
-    const int t = q[T - 1 - w];
+    const int t = q[1 + w];
     int start, n;
     __syncthreads();  // the previous list is done with the LDS
     if (!tile_range(T, capacity, tile_bins, b, t, tid, false, start, n)) continue;

@@ -318,3 +318,53 @@ def global_grad_norm(params: Iterable[torch.nn.Parameter]) -> torch.Tensor:
     """L2 norm of the (already synchronised) gradients -- identical on every rank."""
     sq = [p.grad.detach().float().pow(2).sum() for p in params if p.grad is not None]
     return torch.stack(sq).sum().sqrt() if sq else torch.zeros(())
+
+
+class ExplosionGuard:
+    """The loss-explosion test of the reference's training loop (ca_code/utils/train.py:170-204) for view-parallel ranks:
+    the same 32-step loss history and the same rule -- exploded = loss > 10 x mean(history) or non-finite -- evaluated on the
+    ALL-REDUCED mean of the ranks' losses, so every rank takes the same decision (reload the checkpoint and skip the step, or
+    go on) and no rank enters a collective the others skip.  One `.item()` per step, like the reference.
+
+        guard = ExplosionGuard()
+        ...
+        if guard.exploded(loss):      # all ranks together
+            load_checkpoint(...); guard.reset(); continue
+    """
+
+    def __init__(self, history: int = 32, factor: float = 10.0):
+        from collections import deque
+
+        self.history = deque(maxlen=history)
+        self.history.append(float("inf"))
+        self.factor = factor
+
+    def reset(self):
+        self.history.clear()
+        self.history.append(float("inf"))
+
+    def exploded(self, loss: torch.Tensor) -> bool:
+        value = float(sync_mean(loss.detach().float().reshape(())))
+        prev = sum(self.history) / len(self.history)
+        bad = value > self.factor * prev or value != value or value in (float("inf"), float("-inf"))
+        if not bad:
+            self.history.append(value)
+        return bad
+
+
+def finish_scrub_and_clip(sync: "GradSync", params: Iterable[torch.nn.Parameter], max_norm: float = 1.0) -> torch.Tensor:
+    """What follows `loss.backward()` in the reference's loop (train.py:206-214), view-parallel: finish the gradient
+    exchange, zero non-finite gradient entries, clip to `max_norm` by the GLOBAL norm.  After the exchange every rank holds
+    the same averaged gradients, so the scrub and the norm are computed locally and are identical everywhere (a norm taken
+    before the exchange would differ per rank).  Returns the norm before clipping."""
+    params = list(params)
+    if sync is not None:
+        sync.finish()
+    params = [p for p in params if p.grad is not None]
+    for p in params:
+        torch.nan_to_num_(p.grad, nan=0.0, posinf=0.0, neginf=0.0)
+    norm = global_grad_norm(params)
+    scale = (max_norm / (norm + 1e-6)).clamp(max=1.0)     # torch.nn.utils.clip_grad_norm_'s rule
+    for p in params:
+        p.grad.mul_(scale.to(p.grad.device))
+    return norm

@@ -118,6 +118,25 @@ def main():
     assert all(torch.equal(gathered[0], t) for t in gathered)
     m = parallel.sync_mean(torch.tensor(float(rank)))
     assert abs(float(m) - (world - 1) / 2) < 1e-6
+    # (8) the reference loop's explosion rollback + NaN scrub + clip (train.py:170-214), view-parallel: every rank takes the
+    # same decision from the all-reduced loss, and the clip uses the norm of the AVERAGED gradients
+    guard = parallel.ExplosionGuard()
+    assert not guard.exploded(torch.tensor(1.0 + rank))                 # first step: the history starts at inf
+    assert not guard.exploded(torch.tensor(1.0e4 if rank == 0 else 1.0))   # ... and, as in the reference, the 10x rule only
+    for _ in range(32):                                                    # bites once 32 losses have pushed the inf out
+        assert not guard.exploded(torch.tensor(1.2))
+    # only ONE rank sees a huge loss: the mean is > 10 x the history on every rank -> all roll back together
+    assert guard.exploded(torch.tensor(1.0e4 if rank == 0 else 1.0))
+    assert guard.exploded(torch.tensor(float("nan") if rank == world - 1 else 1.0))
+    assert not guard.exploded(torch.tensor(1.3))                        # the history was not polluted by the exploded steps
+    sync3.zero_grad()
+    (((model(mine["x"]) - mine["y"]) ** 2).sum() * world / B * 50.0).backward()
+    norm = parallel.finish_scrub_and_clip(sync3, list(model.parameters()), max_norm=1.0)
+    after = parallel.global_grad_norm(model.parameters())
+    gathered = [torch.zeros(()) for _ in range(world)]
+    dist.all_gather(gathered, norm)
+    assert all(torch.equal(gathered[0], t) for t in gathered) and float(norm) > 1.0
+    assert abs(float(after) - 1.0) < 1e-4, float(after)
     dist.barrier()
     if rank == 0:
         print("DIST_OK")
