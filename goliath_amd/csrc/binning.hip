@@ -81,18 +81,42 @@ __device__ __forceinline__ bool tile_reached(const Reach& r, int x, int y, float
   return gol_min_sigma_rect(r.gx, r.gy, r.a, r.b, r.c, r.ia, r.ic, x0, x0 + block - 1.f, y0, y0 + block - 1.f) <= r.tau;
 }
 
+// The tiles of ONE tile row that the alpha >= 1/255 region E = {sigma <= tau} of a Gaussian reaches, in closed form (round 4:
+// the scatter pass is VALU-bound -- PMC: 0.83 VALU-busy, 100 M wave-instructions per 8 views at 45 % useful lanes -- and ~80 % of
+// them were the per-TILE ellipse-vs-rectangle test inside the divergent box walk, ~55 instructions for each of up to 49 tiles
+// per lane).  E is convex, so E intersected with the row's strip of pixel-centre ordinates [y0, y1] projects onto an x-INTERVAL
+// [xl, xr], and a tile of the row is reached iff its pixel-centre abscissae [x0, x1] meet it: two square roots per row instead
+// of a test per tile.  With d = y - gy in [d0, d1] clipped to the ellipse's extent |d| <= hy: the line y = gy + d cuts E in
+// x - gx in [(-b d - sqrt(D)) / a, (-b d + sqrt(D)) / a], D = 2 a tau - det d^2; the right end is largest at the ellipse's
+// rightmost point (d = -b hx / c) if the strip contains it, else at one of the strip's two lines (same for the left end).
+// 0.01 px of margin on either side against rounding (tau itself is inflated by gol_alpha_tau).  Returns false = row not reached.
+struct RowSpan { float hx, hy, dr, det, two_a_tau, ia; };   // per Gaussian: half extents, d of the rightmost point, ...
+__device__ __forceinline__ RowSpan row_span_setup(const Reach& r) {
+  RowSpan s;
+  s.det = r.a * r.c - r.b * r.b;
+  const float tau2 = 2.f * r.tau;
+  s.hx = sqrtf(tau2 * r.c / s.det); s.hy = sqrtf(tau2 * r.a / s.det);
+  s.dr = -r.b * s.hx * r.ic;
+  s.two_a_tau = tau2 * r.a; s.ia = r.ia;
+  return s;
+}
+__device__ __forceinline__ bool row_span(const Reach& r, const RowSpan& s, float y0, float y1, float& xl, float& xr) {
+  const float dlo = fmaxf(y0 - r.gy, -s.hy), dhi = fminf(y1 - r.gy, s.hy);
+  if (!(dlo <= dhi)) return false;
+  const float s0 = sqrtf(fmaxf(s.two_a_tau - s.det * dlo * dlo, 0.f)), s1 = sqrtf(fmaxf(s.two_a_tau - s.det * dhi * dhi, 0.f));
+  const float r0 = (-r.b * dlo + s0) * s.ia, r1 = (-r.b * dhi + s1) * s.ia;
+  const float l0 = (-r.b * dlo - s0) * s.ia, l1 = (-r.b * dhi - s1) * s.ia;
+  const float right = (s.dr >= dlo && s.dr <= dhi) ? s.hx : fmaxf(r0, r1);
+  const float left = (-s.dr >= dlo && -s.dr <= dhi) ? -s.hx : fminf(l0, l1);
+  xl = r.gx + left - 0.01f; xr = r.gx + right + 0.01f;
+  return true;
+}
+
 struct BinArgs {
   int N, tiles_x, tiles_y, chunk;
   float inv_block, block;
   const float* xys; const float* depths; const int32_t* radii; const float* conics; const float* opacities;
 };
-
-// reached(x, y) from the mask of the scatter pass's first walk (bit (y-y0)*w + (x-x0) of the tile box), or the exact test
-__device__ __forceinline__ bool reached_cached(const Reach& rc, const TileBox& tb, bool have_mask, uint64_t mask, int x,
-                                               int y, float block) {
-  if (have_mask) return (mask >> ((y - tb.y0) * (tb.x1 - tb.x0) + (x - tb.x0))) & 1ull;
-  return tile_reached(rc, x, y, block);
-}
 
 __device__ __forceinline__ TileBox box_of(const BinArgs& a, size_t e, Reach& rc) {
   const int r = a.radii[e];
@@ -156,9 +180,11 @@ __global__ __launch_bounds__(1024) void scatter_lds_kernel(BinArgs a, int64_t ca
                                                            uint64_t* __restrict__ isect_keys) {
   // LDS: per-tile counters packed two to a word (a workgroup sees at most `chunk` <= 4096 Gaussians, so 16 bits
   // hold any count) + per-tile 32-bit base offsets: 6 bytes per tile instead of 8, i.e. 64.5 KB at 2048x1334 -- two
-  // workgroups per CU instead of one.  What bounds the kernel (0.20 ms per 8 views of 2 M stored entries each) is not its
-  // instruction count: its 8-byte key stores land in runs of ~2.7 entries per (workgroup, tile) -- 425 MB written for
-  // 126 MB of keys (PMC) -- behind two workgroups per CU that are phase-locked by their barriers.  Measured and dropped
+  // workgroups per CU instead of one.  What bounds the kernel (0.19 ms per 8 views of 2 M stored entries each) is neither its
+  // instruction count (round 4: the per-tile test replaced by per-row intervals, 100 M -> 65 M VALU wave-instructions:
+  // 196 -> 189 us, VALU-busy 0.83 -> 0.57) nor its reservation atomics / key runs (a cell-ordered variant with 20x fewer
+  // atomics and 50-key runs: 187 us + 22 us of ordering) nor the reservation loop's round trips (all atomics of a lane in
+  // flight at once: no change): two workgroups per CU, phase-locked by their four barriers, wait.  Measured and dropped
   // in round 3: keeping the boxes and depths of the first walk in registers for the second (68 -> 102 VGPRs = one
   // workgroup per CU: +8 %), the same under a 64-register cap (spills: +3 %), four reservation atomics in flight per
   // lane (no change); a PAIR-balanced walk (the wave numbers its (Gaussian, tile) pairs with a scan, every lane tests
@@ -183,13 +209,24 @@ __global__ __launch_bounds__(1024) void scatter_lds_kernel(BinArgs a, int64_t ca
     const TileBox tb = box_of(a, (size_t)b * a.N + i, rc);
     const int bw = tb.x1 - tb.x0;
     uint64_t mask = 0;
-    for (int y = tb.y0; y < tb.y1; ++y)
-      for (int x = tb.x0; x < tb.x1; ++x)
-        if (tile_reached(rc, x, y, a.block)) {
-          const int t = y * a.tiles_x + x;
-          atomicAdd(&s_cnt[t >> 1], 1u << ((t & 1) << 4));
-          mask |= 1ull << (((y - tb.y0) * bw + (x - tb.x0)) & 63);
-        }
+    RowSpan rs;
+    if (rc.exact) rs = row_span_setup(rc);
+    for (int y = tb.y0; y < tb.y1; ++y) {
+      int xa = tb.x0, xb = tb.x1 - 1;
+      if (rc.exact) {   // the reached tiles of this row: an interval (row_span)
+        const float y0 = (float)y * a.block + 0.5f;
+        float xl, xr;
+        if (!row_span(rc, rs, y0, y0 + a.block - 1.f, xl, xr)) continue;
+        // tile x holds pixel centres [block x + 0.5, block x + block - 0.5]
+        xa = max(xa, (int)ceilf((xl - (a.block - 0.5f)) * a.inv_block));
+        xb = min(xb, (int)floorf((xr - 0.5f) * a.inv_block));
+      }
+      for (int x = xa; x <= xb; ++x) {
+        const int t = y * a.tiles_x + x;
+        atomicAdd(&s_cnt[t >> 1], 1u << ((t & 1) << 4));
+        mask |= 1ull << (((y - tb.y0) * bw + (x - tb.x0)) & 63);
+      }
+    }
     masks[k] = mask;
   }
   __syncthreads();
@@ -199,8 +236,7 @@ __global__ __launch_bounds__(1024) void scatter_lds_kernel(BinArgs a, int64_t ca
     if (c) s_base[t] = atomicAdd(bins + 2 * t + 1, c);
   }
   __syncthreads();
-  for (int t = threadIdx.x; t < Tw; t += 1024) s_cnt[t] = 0u;
-  __syncthreads();
+  // (the second walk hands out slots by advancing the tile's base itself: no second pass over the counters)
   uint64_t* keys = isect_keys + (size_t)b * capacity;
 #pragma unroll
   for (int k = 0; k < kMaskPerLane; ++k) {
@@ -211,15 +247,26 @@ __global__ __launch_bounds__(1024) void scatter_lds_kernel(BinArgs a, int64_t ca
     const TileBox tb = box_of(a, e, rc);
     if (tb.x1 <= tb.x0 || tb.y1 <= tb.y0) continue;
     const uint64_t key = ((uint64_t)__float_as_uint(a.depths[e]) << 32) | (uint32_t)i;
-    const bool hm = (tb.x1 - tb.x0) * (tb.y1 - tb.y0) <= 64;   // larger boxes are re-tested (their mask wrapped around)
+    const int bw = tb.x1 - tb.x0;
+    const bool hm = bw * (tb.y1 - tb.y0) <= 64;   // larger boxes are re-tested the same way (their mask wrapped around)
     const uint64_t mask = masks[k];
-    for (int y = tb.y0; y < tb.y1; ++y)
-      for (int x = tb.x0; x < tb.x1; ++x) {
-        if (!reached_cached(rc, tb, hm, mask, x, y, a.block)) continue;
-        const int t = y * a.tiles_x + x, sh = (t & 1) << 4;
-        const int slot = s_base[t] + (int)((atomicAdd(&s_cnt[t >> 1], 1u << sh) >> sh) & 0xffffu);
+    RowSpan rs;
+    if (!hm && rc.exact) rs = row_span_setup(rc);
+    for (int y = tb.y0; y < tb.y1; ++y) {
+      int xa = tb.x0, xb = tb.x1 - 1;
+      if (!hm && rc.exact) {
+        const float y0 = (float)y * a.block + 0.5f;
+        float xl, xr;
+        if (!row_span(rc, rs, y0, y0 + a.block - 1.f, xl, xr)) continue;
+        xa = max(xa, (int)ceilf((xl - (a.block - 0.5f)) * a.inv_block));
+        xb = min(xb, (int)floorf((xr - 0.5f) * a.inv_block));
+      }
+      for (int x = xa; x <= xb; ++x) {
+        if (hm && !((mask >> ((y - tb.y0) * bw + (x - tb.x0))) & 1ull)) continue;
+        const int slot = atomicAdd(&s_base[y * a.tiles_x + x], 1);
         if (slot < capacity) keys[slot] = key;
       }
+    }
   }
 }
 
