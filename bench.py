@@ -6,13 +6,15 @@ Workload = BASELINE config 2: RGCA head, 250,000 Gaussians, 8 vie
 GPU, single env-map relight.  One "step" = one batch of 8 views (issued as 2 micro-batches of 4 views on 2
 HIP streams, --micro) through the whole hot path with the decoder outputs already resident in HBM
 (SURVEY 8d mode A):
-    fused shading tail (SH diffuse + activations + env-map specular)      gol_shade_fwd
-    EWA projection (+ tile counts)                                        gol_project_fwd
+    fused shading tail (SH diffuse + activations + env-map specular) + EWA projection of the Gaussians it produces
+                                                                          gol_shade_project_fwd
     tile binning + per-tile depth sort                                    gol_bin_sort
     colour + depth tile raster, L1 loss vs a fixed random target image    gol_rasterize_fwd (loss fused into its epilogue)
-    raster / projection / shading backward                                gol_*_bwd
-Multi-GPU: views are independent units -> each rank renders its own 8 views (weak scaling); the only
-parameter on this path, the albedo map, has its gradient all-reduced over RCCL every step.
+    raster backward -> per-Gaussian gradient records                      gol_rasterize_bwd
+    projection backward + shading backward                                gol_shade_project_bwd
+(--unfused-projection: gol_shade_fwd / gol_project_fwd ... gol_project_bwd / gol_shade_bwd, rounds 1-3.)
+Multi-GPU (--gpus N): BASELINE config 3 -- the 8 views of the batch sharded 8 / N per GPU (strong scaling), the 60 M-float
+gradient exchange of the decoder's parameter set inside the step; --weak keeps 8 views per rank.
 
 Prints ONE JSON line (rank 0).  Per-ABI-call durations come from HIP events recorded on the launch
 stream inside the timed region; `roofline` describes the longest one.
@@ -150,27 +152,58 @@ def _uv_coherent_order(pos, S):
     return out
 
 
+def _join_streams(streams, hub):
+    """Every stream waits for what all the others have been given so far: joined on `hub`, forked again (GPU-side event
+    waits, nothing blocks the host; the join / fork form is what a HIP graph capture digests -- mutual event waits between
+    the side streams crash hipStreamEndCapture on ROCm 7.0)."""
+    for s in streams:
+        hub.wait_stream(s)
+    for s in streams:
+        s.wait_stream(hub)
+
+
 def step(t, cfg, world):
-    """One step = all views of this GPU's batch, as `len(t["micro"])` micro-batches on separate HIP
-    streams (the views are independent; two half-batches in flight keep the chip busy while one of
-    them is in a small-grid kernel such as the tile scan or the tail of the per-tile sort)."""
+    """One step = all views of this GPU's batch, as `len(t["micro"])` micro-batches on separate HIP streams (the views
+    are independent; two half-batches in flight keep the chip busy while one of them is in a small-grid kernel such as
+    the tile scan or the tail of the per-tile sort).
+    cfg["align_micro_batches"]: all shading calls are issued first and the streams joined ONCE before the renders.  The
+    first-issued shading kernel gets the chip's workgroup slots first and ends ~0.1 ms before the other; unjoined, its
+    stream reaches the raster kernels (43 k small workgroups) that much earlier and the other stream's binning crawls
+    behind them (profiles/r04_two_stream_timeline.txt: 0.6 ms for a 4 us kernel)."""
     from goliath_amd import losses, render_gs, shade
 
     main = torch.cuda.current_stream()
-    loss = None
-    for mb, stream in zip(t["micro"], t["streams"]):
+    micro, streams = t["micro"], t["streams"]
+    align = cfg.get("align_micro_batches", False) and len(set(streams)) > 1
+    for stream in streams:
         stream.wait_stream(main)
+
+    def render_and_backward(mb, p):
+        # loss == (rgb - target).abs().mean() (loss/__init__.py:411), evaluated in the raster epilogue and
+        # back-propagated by the raster backward itself (losses.l1_image is the stand-alone form of the same op)
+        loss = render_gs.render_batch(mb["K"], mb["Rt"], p, cfg["height"], cfg["width"], l1_target=mb["target"])[3]
+        loss.backward()
+        return loss
+
+    preds, loss = [], None
+    for mb, stream in zip(micro, streams):
         with torch.cuda.stream(stream):
             for k in ("f_vn", "f_vc", "postex", "tn", "albedo"):
                 mb[k].grad = None
-            preds = shade.shading_tail(mb["f_vn"], mb["f_vc"], mb["postex"], mb["tn"], mb["albedo"], mb["light_sh"],
-                                       mb["campos"], preconv_envmap=mb["mips"], lightrot=mb["lightrot"])
-            # loss == (rgb - target).abs().mean() (loss/__init__.py:411), evaluated in the raster epilogue and
-            # back-propagated by the raster backward itself (losses.l1_image is the stand-alone form of the same op)
-            rgb, alpha, depth, loss = render_gs.render_batch(mb["K"], mb["Rt"], preds, cfg["height"], cfg["width"],
-                                                             l1_target=mb["target"])
-            loss.backward()
-    for stream in t["streams"]:
+            # the cameras go into the shading call: its kernel projects the Gaussians it produces, the render starts at the
+            # tile count and hands its gradient records back to the shading backward (what AutoEncoder.forward does,
+            # goliath_amd/rgca.py); --unfused-projection: gol_project_fwd / bwd as kernels of their own (rounds 1-3)
+            vs = render_gs.view_set(mb["K"], mb["Rt"], cfg["height"], cfg["width"]) if cfg.get("fused_projection", True) else None
+            preds.append(shade.shading_tail(mb["f_vn"], mb["f_vc"], mb["postex"], mb["tn"], mb["albedo"], mb["light_sh"],
+                                            mb["campos"], preconv_envmap=mb["mips"], lightrot=mb["lightrot"], views=vs))
+            if not align:
+                loss = render_and_backward(mb, preds[-1])
+    if align:
+        _join_streams(streams, main)
+        for mb, stream, p in zip(micro, streams, preds):
+            with torch.cuda.stream(stream):
+                loss = render_and_backward(mb, p)
+    for stream in streams:
         main.wait_stream(stream)
     # the path's only parameter (albedo, rgca.py:462-464) is shared by all views: sum the micro-batch grads
     grads = [mb["albedo"].grad for mb in t["micro"]]
@@ -223,6 +256,11 @@ def algorithmic_bytes(name, N, I, P, n_mips_bytes):
     return {
         "gol_shade_fwd": (129 * 4 + 24 + 12) * N + 148 * N,
         "gol_shade_bwd": (16 * 4 + 24 + 12 + 12) * N + 56 * N + (129 * 4 + 24 + 12) * N,
+        # with the projection fused in: + its outputs (xy 8, depth 4, radius 4, conic 12, compensation 4, effective opacity 4,
+        # raster record 64) / + the gradient record 64, radius 4, conic 12, compensation 4 instead of the 56 B of upstream
+        # gradients of colour / opacity / position / quaternion / scale
+        "gol_shade_project_fwd": (129 * 4 + 24 + 12) * N + 148 * N + 100 * N,
+        "gol_shade_project_bwd": (16 * 4 + 24 + 12 + 12) * N + 84 * N + (129 * 4 + 24 + 12) * N,
         # in: means 12, scales 12, quats 16, opacity 4, colour 12; out: xy 8, depth 4, radius 4, conic 12, compensation 4,
         # effective opacity 4, raster record 64
         "gol_project_fwd": 56 * N + 100 * N,
@@ -650,18 +688,20 @@ def e2e_main(args, emit_line=True):
         else:
             opt.zero_grad(set_to_none=True)
         ev[0].record()
+        # (the cameras go into the shading call, as in AutoEncoder.forward: projection inside the shading kernels)
+        vs = None if args.unfused_projection else render_gs.view_set(t["K"], t["Rt"], H, W)
         if args.fused_tail:
             from goliath_amd import tail
 
             x_vn, x_vc = dec.trunk(t["embs"], t["campos"])
             ev[1].record()
             preds = tail.fused_tail(dec.vnocond_mod[-1], dec.vcond_mod[-1], x_vn, x_vc, t["postex"], t["tn"], albedo, t["light_sh"], t["campos"],
-                                    preconv_envmap=t["mips"], lightrot=t["lightrot"])
+                                    preconv_envmap=t["mips"], lightrot=t["lightrot"], views=vs)
         else:
             f_vn, f_vc = dec(t["embs"], t["campos"])
             ev[1].record()
             preds = shade.shading_tail(f_vn, f_vc, t["postex"], t["tn"], albedo, t["light_sh"], t["campos"],
-                                       preconv_envmap=t["mips"], lightrot=t["lightrot"])
+                                       preconv_envmap=t["mips"], lightrot=t["lightrot"], views=vs)
         rgb, alpha, depth, l1 = render_gs.render_batch(t["K"], t["Rt"], preds, H, W, l1_target=t["target"])
         loss = 10.0 * l1                                         # rgca_example.yml:43-47  rgb_l1 weight 1e1
         if not args.no_ssim:
@@ -733,6 +773,7 @@ def e2e_main(args, emit_line=True):
         # roofline of the longest call of the hot path at this size: algorithmic bytes with the list
         # entries of the FINAL state of the fit (one extra forward) over the live event time
         hot = {k: v for k, v in ms.items() if k in ("gol_shade_fwd", "gol_shade_bwd", "gol_project_fwd", "gol_project_bwd",
+                                                    "gol_shade_project_fwd", "gol_shade_project_bwd",
                                                     "gol_bin_sort", "gol_rasterize_fwd", "gol_rasterize_bwd")}
         if hot:
             with torch.no_grad():
@@ -807,6 +848,11 @@ def parse_args(argv=None):
                          "cannot be taken inside a graph: they come from an eager pass right after the timed replays")
     ap.add_argument("--workload", choices=["rgca", "mvp", "urhand", "sg", "e2e"], default="rgca",
                     help="rgca = the BASELINE metric (default); mvp = secondary BASELINE config 5 line")
+    ap.add_argument("--no-align", action="store_true",
+                    help="rgca: do not join the micro-batch streams after the shading calls (see step())")
+    ap.add_argument("--unfused-projection", action="store_true",
+                    help="rgca: run the EWA projection and its backward as kernels of their own (gol_project_fwd / bwd inside "
+                         "gol_render_fwd / bwd, rounds 1-3) instead of inside the shading kernels (gol_shade_project_fwd / bwd)")
     ap.add_argument("--no-secondary", action="store_true",
                     help="rgca, N = 1: skip the secondary workloads (one camera per GPU, e2e at 1 M Gaussians, MVP config 5, "
                          "URHand config 4, the coherent / smooth env-map case) that the default line carries under `secondary`")
@@ -837,7 +883,11 @@ def run_rgca(args, D, views, scaling, workload, overlap, micro=None, extras=True
     """Warm up, capture and time the rgca step for `views` views per rank; returns the result dict (rank 0; None on the
     other ranks).  overlap: exchange mode for N > 1 (see run_step).  extras: intersection counts, per-call HBM table."""
     cfg = dict(CFG, workload=workload, views_per_gpu=views, coherent_uv=bool(args.coherent_uv),
-               smooth_normals=bool(args.smooth_normals))
+               smooth_normals=bool(args.smooth_normals), fused_projection=not args.unfused_projection)
+    # with the projection fused in, micro-batches of >= 4 views are joined once after their shading kernels (see step();
+    # measured: 8 views 2803 -> 2855 views/s; 2 + 2 and 1 + 1 views are faster left alone, and so is the unfused path)
+    cfg["align_micro_batches"] = (cfg["fused_projection"] and views // max(1, min(args.micro if micro is None else micro, views)) >= 4
+                                  and not args.no_align)
     micro = args.micro if micro is None else micro
     micro = max(1, min(micro, views))
     while views % micro:  # micro-batches must divide the views of a rank
@@ -941,7 +991,9 @@ def run_rgca(args, D, views, scaling, workload, overlap, micro=None, extras=True
         # what the product path issues).  The micro-batches go on ONE stream here, so a call's events bracket that kernel
         # sequence alone and the durations agree with rocprofv3's per-kernel trace; with two streams in flight they would
         # include time-sharing.
-        streams, t["streams"] = t["streams"], [torch.cuda.current_stream()] * len(t["streams"])
+        streams = t["streams"]
+        if os.environ.get("GOL_TIMING_STREAMS", "0") != "1":   # (=1, diagnostics: keep the streams, durations include time-sharing)
+            t["streams"] = [torch.cuda.current_stream()] * len(t["streams"])
         _lib.TIMING = []
         sync_keep, t["_sync"] = t.get("_sync"), None   # compute only
         for _ in range(args.steps):
@@ -956,6 +1008,13 @@ def run_rgca(args, D, views, scaling, workload, overlap, micro=None, extras=True
     for name, e0, e1 in timing:
         per_call.setdefault(name, []).append(e0.elapsed_time(e1))
     kernels_ms = {k: sum(v) / len(v) for k, v in per_call.items()}
+    if os.environ.get("GOL_TIMING_STREAMS", "0") == "1" and timing and rank == 0:
+        # diagnostics: the last step's calls on a common clock (start, end in us since the step's first call)
+        per_step = len(timing) // args.steps
+        last = timing[-per_step:]
+        base = last[0][1]
+        for name, e0, e1 in sorted(last, key=lambda x: base.elapsed_time(x[1])):
+            print("  %8.1f %8.1f  %s" % (1e3 * base.elapsed_time(e0), 1e3 * base.elapsed_time(e1), name), file=sys.stderr)
     stub_ok = None
     if args.stub:
         # every rank's "gradient" was albedo * (rank + 1): the average is albedo * (world + 1) / 2

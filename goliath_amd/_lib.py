@@ -18,7 +18,8 @@ _lib = None
 _SYMBOLS = [
     "gol_version", "gol_last_error", "gol_sg_eval_fwd", "gol_sg_eval_bwd", "gol_project_fwd",
     "gol_project_bwd", "gol_project_bwd_records", "gol_bin_sort", "gol_splat_pack", "gol_render_layout", "gol_render_fwd", "gol_render_bwd", "gol_rasterize_fwd", "gol_rasterize_bwd", "gol_raster_plan", "gol_raster_count_pairs", "gol_shade_fwd",
-    "gol_shade_bwd", "gol_selftest_wave_sum4", "gol_raydirs_fwd", "gol_mvp_aabb", "gol_mvp_march_fwd",
+    "gol_shade_bwd", "gol_shade_project_fwd", "gol_shade_project_bwd", "gol_render_layout_projected", "gol_render_fwd_projected",
+    "gol_render_bwd_projected", "gol_selftest_wave_sum4", "gol_raydirs_fwd", "gol_mvp_aabb", "gol_mvp_march_fwd",
     "gol_mvp_march_bwd", "gol_mvp_march_warp_fwd", "gol_mvp_march_warp_bwd", "gol_envmap_pack", "gol_uvlight_phong_fwd", "gol_uvlight_phong_bwd",
     "gol_uvlight_ggx_fwd", "gol_uvlight_ggx_bwd", "gol_l1_blocks", "gol_l1_fwd", "gol_l1_bwd",
     "gol_tail_conv_fwd", "gol_tail_conv_bwd", "gol_tail_conv_bwd_scratch_floats", "gol_ssim_blocks", "gol_ssim_fwd", "gol_ssim_bwd",

@@ -131,6 +131,7 @@ __device__ __forceinline__ float gol_readlane63(float v) {
 //   op * exp(-sigma(p)) >= 1/255  <=>  sigma(p) = 0.5 d^T C d <= ln(255 op) =: tau     
 // gol_alpha_tau returns a slightly inflated tau (conservative against rounding; < 0 means "never").
 __device__ __forceinline__ float gol_alpha_tau(float op) {
+  _Pragma("clang fp contract(on)")
   const float k = 255.f * op;
   return (k > 1.f) ? __logf(k) * 1.001f + 1e-3f : -1.f;
 }
@@ -178,6 +179,7 @@ __device__ __forceinline__ float gol_min_sigma_rect(float gx, float gy, float a,
 
 __device__ __forceinline__ void gol_record_write(float* __restrict__ rec, float x, float y, float ca, float cb, float cc,
                                                  float op, float r, float g, float b, float extra) {
+  _Pragma("clang fp contract(on)")   // written from two kernels (projection, shading epilogue): same bits from both
   const bool exact = (ca * cc - cb * cb > 0.f) && ca > 0.f && cc > 0.f;
   float4* R = reinterpret_cast<float4*>(rec);
   R[0] = make_float4(x, y, ca * GOL_SC_A, cb * GOL_SC_B);

@@ -6,57 +6,11 @@
 // from device memory through scalar loads, so a batch of B views is ONE launch with no host
 // sync (the reference reads K with 4 .item() calls per view, rgca.py:123-126).
 // Streaming kernel: 40 B in, ~88 B out per Gaussian -> HBM-bound.
-#include "gol_common.h"
+#include "gol_project.h"
 
 namespace {
 
-struct M3 { float m[9]; };  // row-major
-
-__device__ __forceinline__ M3 mul(const M3& a, const M3& b) {
-  M3 o;
-#pragma unroll
-  for (int r = 0; r < 3; ++r)
-#pragma unroll
-    for (int c = 0; c < 3; ++c)
-      o.m[r * 3 + c] = a.m[r * 3] * b.m[c] + a.m[r * 3 + 1] * b.m[3 + c] + a.m[r * 3 + 2] * b.m[6 + c];
-  return o;
-}
-__device__ __forceinline__ M3 transpose(const M3& a) {
-  return M3{{a.m[0], a.m[3], a.m[6], a.m[1], a.m[4], a.m[7], a.m[2], a.m[5], a.m[8]}};
-}
-
-__device__ __forceinline__ M3 quat_to_rotmat(float qw, float qx, float qy, float qz) {
-  const float s = rsqrtf(qw * qw + qx * qx + qy * qy + qz * qz);
-  const float w = qw * s, x = qx * s, y = qy * s, z = qz * s;
-  return M3{{1.f - 2.f * (y * y + z * z), 2.f * (x * y - w * z), 2.f * (x * z + w * y),
-             2.f * (x * y + w * z), 1.f - 2.f * (x * x + z * z), 2.f * (y * z - w * x),
-             2.f * (x * z - w * y), 2.f * (y * z + w * x), 1.f - 2.f * (x * x + y * y)}};
-}
-
-__device__ __forceinline__ int clampi(int v, int lo, int hi) { return min(max(v, lo), hi); }
-
-// upper triangle of Sigma = M M^T, M = R(q) diag(glob_scale * scale)   
-__device__ __forceinline__ void cov3d_of(const float* __restrict__ quats, const float* __restrict__ scales,
-                                         float glob_scale, size_t e, float (&o_cov)[6]) {
-  const float4 q = *reinterpret_cast<const float4*>(quats + 4 * e);
-  const M3 R = quat_to_rotmat(q.x, q.y, q.z, q.w);
-  const float s0 = glob_scale * scales[3 * e], s1 = glob_scale * scales[3 * e + 1], s2 = glob_scale * scales[3 * e + 2];
-  M3 M;
-#pragma unroll
-  for (int r = 0; r < 3; ++r) { M.m[r * 3] = R.m[r * 3] * s0; M.m[r * 3 + 1] = R.m[r * 3 + 1] * s1; M.m[r * 3 + 2] = R.m[r * 3 + 2] * s2; }
-  const M3 S3 = mul(M, transpose(M));
-  o_cov[0] = S3.m[0]; o_cov[1] = S3.m[1]; o_cov[2] = S3.m[2]; o_cov[3] = S3.m[4]; o_cov[4] = S3.m[5]; o_cov[5] = S3.m[8];
-}
-
-// SURVEY A.1 tile bbox with C (int) truncation; [x0,x1) x [y0,y1) in tile units.
-__device__ __forceinline__ void tile_bbox(float cx, float cy, float radius, int tiles_x, int tiles_y,
-                                          float inv_block, int& x0, int& x1, int& y0, int& y1) {
-  const float tcx = cx * inv_block, tcy = cy * inv_block, tr = radius * inv_block;
-  x0 = clampi((int)(tcx - tr), 0, tiles_x);
-  x1 = clampi((int)(tcx + tr + 1.f), 0, tiles_x);
-  y0 = clampi((int)(tcy - tr), 0, tiles_y);
-  y1 = clampi((int)(tcy + tr + 1.f), 0, tiles_y);
-}
+using namespace gol_proj;
 
 __global__ __launch_bounds__(256) void project_fwd_kernel(
     int N, const float* __restrict__ means3d, const float* __restrict__ scales, float glob_scale,
@@ -70,72 +24,30 @@ __global__ __launch_bounds__(256) void project_fwd_kernel(
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= N) return;
   const size_t e = (size_t)b * N + i;
-  const float* V = viewmats + 12 * b;
-  const float fx = intrins[4 * b], fy = intrins[4 * b + 1], cx = intrins[4 * b + 2], cy = intrins[4 * b + 3];
-  const int tiles_x = (img_w + block - 1) / block, tiles_y = (img_h + block - 1) / block;
-
-  // defaults for culled Gaussians (gsplat allocates zeros)
-  float o_cov[6] = {0, 0, 0, 0, 0, 0}, o_xy[2] = {0, 0}, o_depth = 0.f, o_con[3] = {0, 0, 0}, o_comp = 0.f;
-  int o_rad = 0, o_tiles = 0;
-  int bx0 = 0, bx1 = 0, by0 = 0, by1 = 0;
-
-  const float p0 = means3d[3 * e], p1 = means3d[3 * e + 1], p2 = means3d[3 * e + 2];
-  const float tx = V[0] * p0 + V[1] * p1 + V[2] * p2 + V[3];
-  const float ty = V[4] * p0 + V[5] * p1 + V[6] * p2 + V[7];
-  const float tz = V[8] * p0 + V[9] * p1 + V[10] * p2 + V[11];
-  if (tz > clip_thresh) {
-    cov3d_of(quats, scales, glob_scale, e, o_cov);
-
-    const float lim_x = GOL_FOV_CLAMP * (0.5f * (float)img_w / fx), lim_y = GOL_FOV_CLAMP * (0.5f * (float)img_h / fy);
-    const float ex = tz * fminf(lim_x, fmaxf(-lim_x, tx / tz));
-    const float ey = tz * fminf(lim_y, fmaxf(-lim_y, ty / tz));
-    const float rz = 1.f / tz, rz2 = rz * rz;
-    const M3 J{{fx * rz, 0.f, -fx * ex * rz2, 0.f, fy * rz, -fy * ey * rz2, 0.f, 0.f, 0.f}};
-    const M3 W{{V[0], V[1], V[2], V[4], V[5], V[6], V[8], V[9], V[10]}};
-    const M3 T = mul(J, W);
-    const M3 Vc{{o_cov[0], o_cov[1], o_cov[2], o_cov[1], o_cov[3], o_cov[4], o_cov[2], o_cov[4], o_cov[5]}};
-    const M3 cov = mul(mul(T, Vc), transpose(T));
-    const float c00 = cov.m[0], c01 = cov.m[1], c11 = cov.m[4];
-    const float det_orig = c00 * c11 - c01 * c01;
-    const float a = c00 + GOL_BLUR, bq = c01, c = c11 + GOL_BLUR;
-    const float det = a * c - bq * bq;
-    if (det != 0.f) {
-      const float inv_det = 1.f / det;
-      const float bb = 0.5f * (a + c);
-      const float sq = sqrtf(fmaxf(GOL_EIG_FLOOR, bb * bb - det));
-      const float radius = ceilf(GOL_RADIUS_SIGMAS * sqrtf(fmaxf(bb + sq, bb - sq)));
-      const float rw = 1.f / (tz + GOL_Z_EPS);
-      const float px = fx * (tx * rw) + cx, py = fy * (ty * rw) + cy;
-      tile_bbox(px, py, radius, tiles_x, tiles_y, 1.f / (float)block, bx0, bx1, by0, by1);
-      const int area = (bx1 - bx0) * (by1 - by0);
-      // gsplat writes conics before the tile-area test (forward.cu order): keep that
-      o_con[0] = c * inv_det; o_con[1] = -bq * inv_det; o_con[2] = a * inv_det;
-      if (area > 0) {
-        o_tiles = area; o_depth = tz; o_rad = (int)radius; o_xy[0] = px; o_xy[1] = py;
-        o_comp = sqrtf(fmaxf(0.f, det_orig / det));
-      }
-    }
-  } else {
-    o_cov[0] = o_cov[1] = o_cov[2] = o_cov[3] = o_cov[4] = o_cov[5] = 0.f;
-  }
+  const View cam = view_of(viewmats, intrins, b, img_h, img_w, block, clip_thresh);
+  const float p[3] = {means3d[3 * e], means3d[3 * e + 1], means3d[3 * e + 2]};
+  const float4 qv = *reinterpret_cast<const float4*>(quats + 4 * e);
+  const float q[4] = {qv.x, qv.y, qv.z, qv.w};
+  const float s[3] = {glob_scale * scales[3 * e], glob_scale * scales[3 * e + 1], glob_scale * scales[3 * e + 2]};
+  const Projected o = project_point(p, q, s, cam);
 
   if (cov3d) {   // (NULL in the fused path: the backward recomputes it from the scales and the quaternion it reads anyway)
 #pragma unroll
-    for (int k = 0; k < 6; ++k) cov3d[6 * e + k] = o_cov[k];
+    for (int k = 0; k < 6; ++k) cov3d[6 * e + k] = o.cov[k];
   }
-  *reinterpret_cast<float2*>(xys + 2 * e) = make_float2(o_xy[0], o_xy[1]);
-  depths[e] = o_depth;
-  radii[e] = o_rad;
-  conics[3 * e] = o_con[0]; conics[3 * e + 1] = o_con[1]; conics[3 * e + 2] = o_con[2];
-  compensation[e] = o_comp;
-  if (num_tiles_hit) num_tiles_hit[e] = o_tiles;
-  const float op_eff = opacities ? opacities[e] * o_comp : 0.f;
+  *reinterpret_cast<float2*>(xys + 2 * e) = make_float2(o.xy[0], o.xy[1]);
+  depths[e] = o.depth;
+  radii[e] = o.radius;
+  conics[3 * e] = o.conic[0]; conics[3 * e + 1] = o.conic[1]; conics[3 * e + 2] = o.conic[2];
+  compensation[e] = o.comp;
+  if (num_tiles_hit) num_tiles_hit[e] = o.tiles;
+  const float op_eff = opacities ? opacities[e] * o.comp : 0.f;
   if (opac_eff) opac_eff[e] = op_eff;
   // the rasterizer's 64-byte record of this Gaussian (gol_common.h): screen position, scaled conic, effective opacity,
   // colour, depth as the 4th channel, and the per-Gaussian part of the alpha >= 1/255 reach test
   if (records)
-    gol_record_write(records + e * GOL_SPLAT_RECORD, o_xy[0], o_xy[1], o_con[0], o_con[1], o_con[2], op_eff,
-                     colors[3 * e], colors[3 * e + 1], colors[3 * e + 2], o_depth);
+    gol_record_write(records + e * GOL_SPLAT_RECORD, o.xy[0], o.xy[1], o.conic[0], o.conic[1], o.conic[2], op_eff,
+                     colors[3 * e], colors[3 * e + 1], colors[3 * e + 2], o.depth);
 }
 
 __global__ __launch_bounds__(256) void project_bwd_kernel(
@@ -159,111 +71,30 @@ __global__ __launch_bounds__(256) void project_bwd_kernel(
   }
   // upstream gradients: dense arrays (gs == 0) or fields of per-Gaussian records of gs floats (rasterize_bwd)
   const size_t e1 = gs ? e * gs : e, e2 = gs ? e * gs : 2 * e, e3 = gs ? e * gs : 3 * e;
-  float vm[3] = {0, 0, 0}, vs[3] = {0, 0, 0}, vq[4] = {0, 0, 0, 0}, vo = 0.f;
+  ProjGrad g;
+  g.mean[0] = g.mean[1] = g.mean[2] = 0.f; g.scale[0] = g.scale[1] = g.scale[2] = 0.f;
+  g.quat[0] = g.quat[1] = g.quat[2] = g.quat[3] = 0.f; g.opacity = 0.f;
   if (radii[e] > 0) {
-    const float* V = viewmats + 12 * b;
-    const float fx = intrins[4 * b], fy = intrins[4 * b + 1];
-    const float p0 = means3d[3 * e], p1 = means3d[3 * e + 1], p2 = means3d[3 * e + 2];
-    const float tx = V[0] * p0 + V[1] * p1 + V[2] * p2 + V[3];
-    const float ty = V[4] * p0 + V[5] * p1 + V[6] * p2 + V[7];
-    const float tz = V[8] * p0 + V[9] * p1 + V[10] * p2 + V[11];
-    const float comp = compensation[e];
-    float v_comp = v_compensation ? v_compensation[e] : 0.f;
-    if (opacities) {  // opac_eff = opacity * comp  (render_gsplat.py:72)
-      const float g = v_opac_eff ? v_opac_eff[e1] : 0.f;
-      v_comp += g * opacities[e];
-      vo = g * comp;
-    }
-    // project_pix vjp
-    const float rw = 1.f / (tz + GOL_Z_EPS);
-    const float vpx = v_xy ? fx * v_xy[e2] : 0.f, vpy = v_xy ? fy * v_xy[e2 + 1] : 0.f;
-    const float vv0 = vpx * rw, vv1 = vpy * rw, vv2 = -(vpx * tx + vpy * ty) * rw * rw;
-#pragma unroll
-    for (int c = 0; c < 3; ++c) vm[c] = V[c] * vv0 + V[4 + c] * vv1 + V[8 + c] * vv2;
-    const float vz = v_depth ? v_depth[e1] : 0.f;
-    vm[0] += V[8] * vz; vm[1] += V[9] * vz; vm[2] += V[10] * vz;
-
-    // conic (inverse cov2d) vjp: v_Sigma = -X G X
-    const float X0 = conics[3 * e], X1 = conics[3 * e + 1], X2 = conics[3 * e + 2];
-    const float G0 = v_conic ? v_conic[e3] : 0.f, G1 = v_conic ? 0.5f * v_conic[e3 + 1] : 0.f,
-                G2 = v_conic ? v_conic[e3 + 2] : 0.f;
-    const float a00 = X0 * G0 + X1 * G1, a01 = X0 * G1 + X1 * G2;
-    const float a10 = X1 * G0 + X2 * G1, a11 = X1 * G1 + X2 * G2;
-    float vc0 = -(a00 * X0 + a01 * X1);
-    float vc1 = -(a00 * X1 + a01 * X2) - (a10 * X0 + a11 * X1);
-    float vc2 = -(a10 * X1 + a11 * X2);
-    {  // compensation vjp (upstream ignores the max(0,.) clamp and uses comp + 1e-6)
-      const float inv_det = X0 * X2 - X1 * X1;
-      const float om = 1.f - comp * comp;
-      const float vsq = v_comp * 0.5f / (comp + GOL_COMP_EPS);
-      vc0 += vsq * (om * X0 - GOL_BLUR * inv_det);
-      vc1 += 2.f * vsq * (om * X1);
-      vc2 += vsq * (om * X2 - GOL_BLUR * inv_det);
-    }
-    // EWA vjp with the UNCLAMPED camera-space point, as upstream
-    const float rz = 1.f / tz, rz2 = rz * rz, rz3 = rz2 * rz;
-    const M3 J{{fx * rz, 0.f, -fx * tx * rz2, 0.f, fy * rz, -fy * ty * rz2, 0.f, 0.f, 0.f}};
-    const M3 W{{V[0], V[1], V[2], V[4], V[5], V[6], V[8], V[9], V[10]}};
-    const M3 T = mul(J, W);
-    float c3[6];
-    if (cov3d) {
-#pragma unroll
-      for (int k = 0; k < 6; ++k) c3[k] = cov3d[6 * e + k];
-    } else {
-      cov3d_of(quats, scales, glob_scale, e, c3);   // the forward's own arithmetic: identical values
-    }
-    const M3 Vc{{c3[0], c3[1], c3[2], c3[1], c3[3], c3[4], c3[2], c3[4], c3[5]}};
-    const M3 Gc{{vc0, 0.5f * vc1, 0.f, 0.5f * vc1, vc2, 0.f, 0.f, 0.f, 0.f}};
-    const M3 vV = mul(mul(transpose(T), Gc), T);
-    M3 vT = mul(mul(Gc, T), Vc);
-#pragma unroll
-    for (int k = 0; k < 9; ++k) vT.m[k] *= 2.f;
-    const float vc3[6] = {vV.m[0], vV.m[1] + vV.m[3], vV.m[2] + vV.m[6], vV.m[4], vV.m[5] + vV.m[7], vV.m[8]};
-    const M3 vJ = mul(vT, transpose(W));
-    const float vt0 = -fx * rz2 * vJ.m[2], vt1 = -fy * rz2 * vJ.m[5];
-    const float vt2 = -fx * rz2 * vJ.m[0] + 2.f * fx * tx * rz3 * vJ.m[2] - fy * rz2 * vJ.m[4] +
-                      2.f * fy * ty * rz3 * vJ.m[5];
-#pragma unroll
-    for (int c = 0; c < 3; ++c) vm[c] += vt0 * V[c] + vt1 * V[4 + c] + vt2 * V[8 + c];
-
-    // cov3d = M M^T, M = R(q) diag(s): vjp to scale and (normalised) quaternion
-    const M3 vVs{{vc3[0], 0.5f * vc3[1], 0.5f * vc3[2], 0.5f * vc3[1], vc3[3], 0.5f * vc3[4],
-                  0.5f * vc3[2], 0.5f * vc3[4], vc3[5]}};
-    const float4 q = *reinterpret_cast<const float4*>(quats + 4 * e);
-    const M3 R = quat_to_rotmat(q.x, q.y, q.z, q.w);
-    const float sc[3] = {glob_scale * scales[3 * e], glob_scale * scales[3 * e + 1], glob_scale * scales[3 * e + 2]};
-    M3 M;
-#pragma unroll
-    for (int r = 0; r < 3; ++r)
-#pragma unroll
-      for (int c = 0; c < 3; ++c) M.m[r * 3 + c] = R.m[r * 3 + c] * sc[c];
-    M3 vM = mul(vVs, M);
-#pragma unroll
-    for (int k = 0; k < 9; ++k) vM.m[k] *= 2.f;
-#pragma unroll
-    for (int c = 0; c < 3; ++c)
-      vs[c] = (R.m[c] * vM.m[c] + R.m[3 + c] * vM.m[3 + c] + R.m[6 + c] * vM.m[6 + c]) * glob_scale;
-    float vR[9];
-#pragma unroll
-    for (int r = 0; r < 3; ++r)
-#pragma unroll
-      for (int c = 0; c < 3; ++c) vR[r * 3 + c] = vM.m[r * 3 + c] * sc[c];
-    const float s = rsqrtf(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w);
-    const float w = q.x * s, x = q.y * s, y = q.z * s, z = q.w * s;
-#define VR(r, c) vR[(r) * 3 + (c)]
-    vq[0] = 2.f * (x * (VR(2, 1) - VR(1, 2)) + y * (VR(0, 2) - VR(2, 0)) + z * (VR(1, 0) - VR(0, 1)));
-    vq[1] = 2.f * (-2.f * x * (VR(1, 1) + VR(2, 2)) + y * (VR(1, 0) + VR(0, 1)) + z * (VR(2, 0) + VR(0, 2)) +
-                   w * (VR(2, 1) - VR(1, 2)));
-    vq[2] = 2.f * (x * (VR(1, 0) + VR(0, 1)) - 2.f * y * (VR(0, 0) + VR(2, 2)) + z * (VR(2, 1) + VR(1, 2)) +
-                   w * (VR(0, 2) - VR(2, 0)));
-    vq[3] = 2.f * (x * (VR(2, 0) + VR(0, 2)) + y * (VR(2, 1) + VR(1, 2)) - 2.f * z * (VR(0, 0) + VR(1, 1)) +
-                   w * (VR(1, 0) - VR(0, 1)));
-#undef VR
+    const View cam = view_of(viewmats, intrins, b, 0, 0, 16, 0.f);
+    const float p[3] = {means3d[3 * e], means3d[3 * e + 1], means3d[3 * e + 2]};
+    const float4 qv = *reinterpret_cast<const float4*>(quats + 4 * e);
+    const float q[4] = {qv.x, qv.y, qv.z, qv.w};
+    const float s[3] = {glob_scale * scales[3 * e], glob_scale * scales[3 * e + 1], glob_scale * scales[3 * e + 2]};
+    const float X[3] = {conics[3 * e], conics[3 * e + 1], conics[3 * e + 2]};
+    ProjUp up;
+    up.xy[0] = v_xy ? v_xy[e2] : 0.f; up.xy[1] = v_xy ? v_xy[e2 + 1] : 0.f;
+    up.depth = v_depth ? v_depth[e1] : 0.f;
+    up.conic[0] = v_conic ? v_conic[e3] : 0.f; up.conic[1] = v_conic ? v_conic[e3 + 1] : 0.f;
+    up.conic[2] = v_conic ? v_conic[e3 + 2] : 0.f;
+    up.comp = v_compensation ? v_compensation[e] : 0.f;
+    up.opac_eff = (opacities && v_opac_eff) ? v_opac_eff[e1] : 0.f;
+    g = project_vjp(p, q, s, glob_scale, cam, X, compensation[e], up, opacities != nullptr,
+                    opacities ? opacities[e] : 0.f, cov3d ? cov3d + 6 * e : nullptr);
   }
-  v_mean3d[3 * e] = vm[0]; v_mean3d[3 * e + 1] = vm[1]; v_mean3d[3 * e + 2] = vm[2];
-  v_scale[3 * e] = vs[0]; v_scale[3 * e + 1] = vs[1]; v_scale[3 * e + 2] = vs[2];
-  *reinterpret_cast<float4*>(v_quat + 4 * e) = make_float4(vq[0], vq[1], vq[2], vq[3]);
-  if (v_opacity) v_opacity[e] = vo;
+  v_mean3d[3 * e] = g.mean[0]; v_mean3d[3 * e + 1] = g.mean[1]; v_mean3d[3 * e + 2] = g.mean[2];
+  v_scale[3 * e] = g.scale[0]; v_scale[3 * e + 1] = g.scale[1]; v_scale[3 * e + 2] = g.scale[2];
+  *reinterpret_cast<float4*>(v_quat + 4 * e) = make_float4(g.quat[0], g.quat[1], g.quat[2], g.quat[3]);
+  if (v_opacity) v_opacity[e] = g.opacity;
 }
 
 }  // namespace

@@ -14,7 +14,9 @@
 //   * backward never re-reads the 113 SH channels: d(loss)/d(f_vnocond) of an SH channel is just
 //     upstream x light coefficient, so it is write-only (452 B) -- the re-read the PyTorch graph
 //     would do (another 452 B) is gone.  Only the 12 geometry channels + f_vcond are re-read.
-#include "gol_common.h"
+#include <cstring>
+
+#include "gol_project.h"
 
 namespace {
 
@@ -280,8 +282,14 @@ __device__ __forceinline__ void spec_forward(const gol_shade_in& in, int b, cons
   }
 }
 
-template <int V, bool ENV, bool RAND>
-__global__ __launch_bounds__(256) void shade_fwd_kernel(const gol_shade_in in, const gol_shade_out out) {
+// PROJ: the EWA projection of the Gaussians just shaded runs as the kernel's epilogue (gol_project.h: the arithmetic of
+// gol_project_fwd on the position / quaternion / clamped scale / opacity / colour still in registers) and writes what
+// binning and the rasterizer read -- the 64-byte raster record, screen position, depth, radius, conic, compensation,
+// effective opacity -- so the render direction starts at the tile count (gol_render_fwd_projected) and the 56 bytes per
+// Gaussian the projection kernel would read back are never fetched.
+template <int V, bool ENV, bool RAND, bool PROJ>
+__global__ __launch_bounds__(256) void shade_fwd_kernel(const gol_shade_in in, const gol_shade_out out,
+                                                        const gol_shade_proj pj) {
   const int b = blockIdx.y;
   const int i0 = (blockIdx.x * 256 + threadIdx.x) * V;
   const int N = in.N;
@@ -394,6 +402,32 @@ __global__ __launch_bounds__(256) void shade_fwd_kernel(const gol_shade_in in, c
     if (out.env_saved) st_aos<V, 9>(out.env_saved, g0, o_env);
   }
   if (RAND) st_aos<V, 3>(out.color_rand, g0, o_rand);
+  if constexpr (PROJ) {
+    const gol_proj::View view = gol_proj::view_of(pj.viewmats, pj.intrins, b, pj.img_h, pj.img_w, 16, pj.clip_thresh);
+    float p_xy[2][V], p_depth[1][V], p_rad[1][V], p_con[3][V], p_comp[1][V], p_oe[1][V];
+#pragma unroll
+    for (int v = 0; v < V; ++v) {
+      const float p[3] = {o_pos[0][v], o_pos[1][v], o_pos[2][v]};
+      const float q[4] = {o_q[0][v], o_q[1][v], o_q[2][v], o_q[3][v]};
+      const float sc[3] = {pj.glob_scale * o_sc[0][v], pj.glob_scale * o_sc[1][v], pj.glob_scale * o_sc[2][v]};
+      const gol_proj::Projected o = gol_proj::project_point(p, q, sc, view);
+      const float op_eff = o_op[0][v] * o.comp;
+      gol_record_write(pj.records + (g0 + v) * GOL_SPLAT_RECORD, o.xy[0], o.xy[1], o.conic[0], o.conic[1], o.conic[2],
+                       op_eff, o_color[0][v], o_color[1][v], o_color[2][v], o.depth);
+      p_xy[0][v] = o.xy[0]; p_xy[1][v] = o.xy[1];
+      p_depth[0][v] = o.depth;
+      p_rad[0][v] = __int_as_float(o.radius);
+      p_con[0][v] = o.conic[0]; p_con[1][v] = o.conic[1]; p_con[2][v] = o.conic[2];
+      p_comp[0][v] = o.comp;
+      p_oe[0][v] = op_eff;
+    }
+    st_aos<V, 2>(pj.xys, g0, p_xy);
+    st_aos<V, 1>(pj.depths, g0, p_depth);
+    st_aos<V, 1>(reinterpret_cast<float*>(pj.radii), g0, p_rad);
+    st_aos<V, 3>(pj.conics, g0, p_con);
+    st_aos<V, 1>(pj.comp, g0, p_comp);
+    st_aos<V, 1>(pj.opac_eff, g0, p_oe);
+  }
 }
 
 // Backward, two phases per 256-Gaussian workgroup:
@@ -403,9 +437,16 @@ __global__ __launch_bounds__(256) void shade_fwd_kernel(const gol_shade_in in, c
 //   phase 2  wave w owns SH channels w, w+4, ...: every lane turns 4 consecutive Gaussians' parked
 //            sums into one 16-byte store per channel plane (1 KiB contiguous per wave-instruction).
 // Phase 2 is 452 of the ~650 B written per Gaussian, so the bulk of the traffic is full-width.
-template <bool ENV, bool RAND, bool VEC4>
+// PROJ: the projection backward runs as the prologue of phase 1 -- the Gaussian's 64-byte gradient record out of the raster
+// backward (GOL_GRAD_RECORD: rgb | opacity | xy | conic | depth) is pushed through gol_proj::project_vjp on the recomputed
+// position / quaternion / scale / opacity and ADDED to the upstream gradients of color / opacity / primpos / primqvec /
+// primscale (which other consumers of those outputs may also feed): gol_project_bwd's 56 B written + 56 B re-read per
+// Gaussian and its launch are gone.
+template <bool ENV, bool RAND, bool VEC4, bool PROJ>
 __global__ __launch_bounds__(256) void shade_bwd_kernel(const gol_shade_in in, const gol_shade_out saved,
-                                                        const gol_shade_out_grad up, const gol_shade_in_grad gin) {
+                                                        const gol_shade_out_grad up, const gol_shade_in_grad gin,
+                                                        const gol_shade_proj pj, const float* __restrict__ grad_records,
+                                                        int with_depth) {
   constexpr int V = 1;
   __shared__ __attribute__((aligned(16))) float s_g[6][256];  // gD[3], gDr[3] per Gaussian of the block
   const int b = blockIdx.y;
@@ -465,6 +506,30 @@ __global__ __launch_bounds__(256) void shade_bwd_kernel(const gol_shade_in in, c
 #pragma unroll
       for (int j = 0; j < 3; ++j) { p3[j] = pb[j][v]; n3[j] = nb[j][v]; }
       const Geo s = make_geo(g1, f1, p3, n3, cam);
+      if constexpr (PROJ) {
+        const float4* R = reinterpret_cast<const float4*>(grad_records + g0 * GOL_GRAD_RECORD);
+        const float4 r0 = R[0];
+        u_color[0][v] += r0.x; u_color[1][v] += r0.y; u_color[2][v] += r0.z;
+        if (pj.radii[g0] > 0) {
+          const float4 r1 = R[1], r2 = R[2];
+          gol_proj::ProjUp pu;
+          pu.opac_eff = r0.w; pu.xy[0] = r1.x; pu.xy[1] = r1.y; pu.conic[0] = r1.z; pu.conic[1] = r1.w; pu.conic[2] = r2.x;
+          pu.depth = with_depth ? r2.y : 0.f;
+          pu.comp = 0.f;
+          const gol_proj::View view = gol_proj::view_of(pj.viewmats, pj.intrins, b, pj.img_h, pj.img_w, 16, pj.clip_thresh);
+          const float sc[3] = {pj.glob_scale * fminf(fmaxf(s.sp[0], in.primscale_min), in.primscale_max),
+                               pj.glob_scale * fminf(fmaxf(s.sp[1], in.primscale_min), in.primscale_max),
+                               pj.glob_scale * fminf(fmaxf(s.sp[2], in.primscale_min), in.primscale_max)};
+          const float X[3] = {pj.conics[3 * g0], pj.conics[3 * g0 + 1], pj.conics[3 * g0 + 2]};
+          const gol_proj::ProjGrad pg = gol_proj::project_vjp(s.pos, s.q, sc, pj.glob_scale, view, X, pj.comp[g0], pu, true,
+                                                              s.opac, nullptr);
+#pragma unroll
+          for (int k = 0; k < 3; ++k) { u_pos[k][v] += pg.mean[k]; u_sc[k][v] += pg.scale[k]; }
+#pragma unroll
+          for (int k = 0; k < 4; ++k) u_q[k][v] += pg.quat[k];
+          u_op[0][v] += pg.opacity;
+        }
+      }
       float spec[3];
       EnvSample e;
       bool have_env = false;
@@ -716,33 +781,47 @@ extern "C" int gol_envmap_pack(int B, int h, int w, const float* src, float* dst
   return GOL_OK;
 }
 
-#define GOL_SHADE_FWD_V(V, ...)                                                                   \
+#define GOL_SHADE_FWD_V(V, P, ...)                                                                \
   do {                                                                                           \
     dim3 grid(gol_cdiv(in->N / V, 256), in->B);                                                  \
-    if (env && rnd) shade_fwd_kernel<V, true, true><<<grid, 256, 0, s>>>(__VA_ARGS__);           \
-    else if (env) shade_fwd_kernel<V, true, false><<<grid, 256, 0, s>>>(__VA_ARGS__);            \
-    else if (rnd) shade_fwd_kernel<V, false, true><<<grid, 256, 0, s>>>(__VA_ARGS__);            \
-    else shade_fwd_kernel<V, false, false><<<grid, 256, 0, s>>>(__VA_ARGS__);                    \
+    if (env && rnd) shade_fwd_kernel<V, true, true, P><<<grid, 256, 0, s>>>(__VA_ARGS__);        \
+    else if (env) shade_fwd_kernel<V, true, false, P><<<grid, 256, 0, s>>>(__VA_ARGS__);         \
+    else if (rnd) shade_fwd_kernel<V, false, true, P><<<grid, 256, 0, s>>>(__VA_ARGS__);         \
+    else shade_fwd_kernel<V, false, false, P><<<grid, 256, 0, s>>>(__VA_ARGS__);                 \
   } while (0)
 
-// 4 Gaussians per lane (16-byte plane loads) when N allows, else 2 (8-byte), else 1
-#define GOL_SHADE_FWD_DISPATCH(...)                                                              \
+// 4 Gaussians per lane (16-byte plane loads) when N allows, else 2 (8-byte), else 1 (with the projection epilogue: 4 or 1)
+#define GOL_SHADE_FWD_DISPATCH(P, ...)                                                           \
   do {                                                                                           \
     const bool env = in->n_mips > 0, rnd = in->light_sh_rand != nullptr;                         \
-    if (in->N % 4 == 0) GOL_SHADE_FWD_V(4, __VA_ARGS__);                                         \
-    else if (in->N % 2 == 0) GOL_SHADE_FWD_V(2, __VA_ARGS__);                                    \
-    else GOL_SHADE_FWD_V(1, __VA_ARGS__);                                                        \
+    if (in->N % 4 == 0) GOL_SHADE_FWD_V(4, P, __VA_ARGS__);                                      \
+    else if (!P && in->N % 2 == 0) GOL_SHADE_FWD_V(2, false, __VA_ARGS__);                       \
+    else GOL_SHADE_FWD_V(1, P, __VA_ARGS__);                                                     \
   } while (0)
 
-#define GOL_SHADE_BWD_CASE(E, R)                                                                 \
+#define GOL_SHADE_BWD_CASE(E, R, P)                                                              \
   do {                                                                                           \
-    if (in->N % 4 == 0) shade_bwd_kernel<E, R, true><<<grid, 256, 0, s>>>(*in, *saved, *g, *gin); \
-    else shade_bwd_kernel<E, R, false><<<grid, 256, 0, s>>>(*in, *saved, *g, *gin);              \
+    if (in->N % 4 == 0) shade_bwd_kernel<E, R, true, P><<<grid, 256, 0, s>>>(*in, *saved, *g, *gin, pj, grad_records, with_depth); \
+    else shade_bwd_kernel<E, R, false, P><<<grid, 256, 0, s>>>(*in, *saved, *g, *gin, pj, grad_records, with_depth); \
   } while (0)
 
-extern "C" int gol_shade_fwd(const gol_shade_in* in, const gol_shade_out* out, void* stream) {
+namespace {
+
+int check_proj(const gol_shade_in* in, const gol_shade_proj* pj, bool outputs_only_read) {
+  (void)outputs_only_read;
+  GOL_REQUIRE(pj != nullptr, "null gol_shade_proj");
+  GOL_REQUIRE(pj->img_h > 0 && pj->img_w > 0, "empty image");
+  if (in->B == 0 || in->N == 0) return GOL_OK;
+  GOL_REQUIRE(pj->viewmats && pj->intrins, "null camera");
+  GOL_REQUIRE(pj->xys && pj->depths && pj->radii && pj->conics && pj->comp && pj->opac_eff && pj->records,
+              "null projection buffer");
+  return GOL_OK;
+}
+
+int shade_fwd_launch(const gol_shade_in* in, const gol_shade_out* out, const gol_shade_proj* proj, void* stream) {
   int rc = check_in(in);
   if (rc != GOL_OK) return rc;
+  if (proj && (rc = check_proj(in, proj, false)) != GOL_OK) return rc;
   if (in->B == 0 || in->N == 0) return GOL_OK;
   GOL_REQUIRE(out != nullptr, "null gol_shade_out");
   GOL_REQUIRE(out->color && out->opacity && out->primpos && out->primqvec && out->primscale &&
@@ -751,27 +830,47 @@ extern "C" int gol_shade_fwd(const gol_shade_in* in, const gol_shade_out* out, v
               "null output");
   GOL_REQUIRE((in->light_sh_rand == nullptr) || out->color_rand, "color_rand output missing");
   hipStream_t s = (hipStream_t)stream;
-  GOL_SHADE_FWD_DISPATCH(*in, *out);
+  gol_shade_proj pj;
+  memset(&pj, 0, sizeof(pj));
+  if (proj) {
+    pj = *proj;
+    GOL_SHADE_FWD_DISPATCH(true, *in, *out, pj);
+  } else {
+    GOL_SHADE_FWD_DISPATCH(false, *in, *out, pj);
+  }
   GOL_CHECK_LAUNCH();
   return GOL_OK;
 }
 
-extern "C" int gol_shade_bwd(const gol_shade_in* in, const gol_shade_out* saved, const gol_shade_out_grad* g,
-                             const gol_shade_in_grad* gin, void* stream) {
+int shade_bwd_launch(const gol_shade_in* in, const gol_shade_out* saved, const gol_shade_out_grad* g,
+                     const gol_shade_proj* proj, const float* grad_records, int with_depth, const gol_shade_in_grad* gin,
+                     void* stream) {
   int rc = check_in(in);
   if (rc != GOL_OK) return rc;
+  if (proj && (rc = check_proj(in, proj, true)) != GOL_OK) return rc;
   if (in->B == 0 || in->N == 0) return GOL_OK;
   GOL_REQUIRE(saved && g && gin, "null struct");
   GOL_REQUIRE(saved->diff_sum != nullptr, "saved diff_sum missing");
   GOL_REQUIRE((in->light_sh_rand == nullptr) || saved->color_rand, "saved color_rand missing");
   GOL_REQUIRE(gin->f_vnocond && gin->f_vcond && gin->postex && gin->tn && gin->albedo_per_view, "null gradient output");
+  GOL_REQUIRE(!proj || grad_records, "null gradient records");
   hipStream_t s = (hipStream_t)stream;
   dim3 grid(gol_cdiv(in->N, 256), in->B);
   const bool env = in->n_mips > 0, rnd = in->light_sh_rand != nullptr;
-  if (env && rnd) GOL_SHADE_BWD_CASE(true, true);
-  else if (env) GOL_SHADE_BWD_CASE(true, false);
-  else if (rnd) GOL_SHADE_BWD_CASE(false, true);
-  else GOL_SHADE_BWD_CASE(false, false);
+  gol_shade_proj pj;
+  memset(&pj, 0, sizeof(pj));
+  if (proj) {
+    pj = *proj;
+    if (env && rnd) GOL_SHADE_BWD_CASE(true, true, true);
+    else if (env) GOL_SHADE_BWD_CASE(true, false, true);
+    else if (rnd) GOL_SHADE_BWD_CASE(false, true, true);
+    else GOL_SHADE_BWD_CASE(false, false, true);
+  } else {
+    if (env && rnd) GOL_SHADE_BWD_CASE(true, true, false);
+    else if (env) GOL_SHADE_BWD_CASE(true, false, false);
+    else if (rnd) GOL_SHADE_BWD_CASE(false, true, false);
+    else GOL_SHADE_BWD_CASE(false, false, false);
+  }
   GOL_CHECK_LAUNCH();
   if (gin->albedo) {  // gradient of the albedo shared by the views = sum over B of the per-view gradients
     const size_t M = (size_t)in->N * 3;
@@ -779,4 +878,28 @@ extern "C" int gol_shade_bwd(const gol_shade_in* in, const gol_shade_out* saved,
     GOL_CHECK_LAUNCH();
   }
   return GOL_OK;
+}
+
+}  // namespace
+
+extern "C" int gol_shade_fwd(const gol_shade_in* in, const gol_shade_out* out, void* stream) {
+  return shade_fwd_launch(in, out, nullptr, stream);
+}
+
+extern "C" int gol_shade_project_fwd(const gol_shade_in* in, const gol_shade_out* out, const gol_shade_proj* proj,
+                                     void* stream) {
+  GOL_REQUIRE(proj != nullptr, "null gol_shade_proj");
+  return shade_fwd_launch(in, out, proj, stream);
+}
+
+extern "C" int gol_shade_bwd(const gol_shade_in* in, const gol_shade_out* saved, const gol_shade_out_grad* g,
+                             const gol_shade_in_grad* gin, void* stream) {
+  return shade_bwd_launch(in, saved, g, nullptr, nullptr, 0, gin, stream);
+}
+
+extern "C" int gol_shade_project_bwd(const gol_shade_in* in, const gol_shade_out* saved, const gol_shade_out_grad* g,
+                                     const gol_shade_proj* proj, const float* grad_records, int with_depth,
+                                     const gol_shade_in_grad* gin, void* stream) {
+  GOL_REQUIRE(proj != nullptr, "null gol_shade_proj");
+  return shade_bwd_launch(in, saved, g, proj, grad_records, with_depth, gin, stream);
 }

@@ -9,6 +9,13 @@ from typing import Any, Dict, Optional
 import torch as th
 
 from .splat import render_views
+from .views import ViewSet
+
+
+def view_set(K: th.Tensor, Rt: th.Tensor, height: int, width: int) -> ViewSet:
+    """The cameras AutoEncoder.render will be called with, for shading_tail(..., views=...): the projection then runs
+    inside the shading kernel (K[B,3,3], Rt[B,3,4]; pass the SAME tensors to render_batch)."""
+    return ViewSet(K, Rt, height, width)
 
 
 def render(cam_img_w: int, cam_img_h: int, fx: float, fy: float, cx: float, cy: float, Rt: th.Tensor,
@@ -38,10 +45,17 @@ def render_batch(K: th.Tensor, Rt: th.Tensor, preds: Dict[str, Any], height: int
     depth / alpha.clamp(0.05, 1).  K[B,3,3] and Rt[B,3,4] stay on the device.
     With l1_target (and optionally l1_mask) a fourth value is returned: the masked L1 loss of rgb against it
     (rgb_l1, ca_code/loss/__init__.py:391-411), fused into the raster passes."""
-    intr = th.stack([K[:, 0, 0], K[:, 1, 1], K[:, 0, 2], K[:, 1, 2]], dim=-1)
-    out = render_views(preds["primpos"], preds["primscale"], preds["primqvec"], preds["opacity"],
-                       preds["color"], Rt, intr, height, width, with_depth=True, l1_target=l1_target, l1_mask=l1_mask,
-                       raw_depth=False)  # only depth / alpha.clamp(0.05, 1) leaves AutoEncoder.render
+    pr = preds.get("projected")
+    if pr is not None and pr.valid_for(preds, K, Rt, height, width) and (pr.views.glob_scale, pr.views.clip_thresh) == (1.0, 0.1):
+        # the shading kernel already projected these Gaussians onto these cameras (shading_tail(..., views=...)): start at
+        # the tile count; the backward hands its gradient records to the shading backward
+        out = render_views(None, None, None, None, None, None, None, height, width, with_depth=True, l1_target=l1_target,
+                           l1_mask=l1_mask, raw_depth=False, projected=pr)
+    else:
+        intr = th.stack([K[:, 0, 0], K[:, 1, 1], K[:, 0, 2], K[:, 1, 2]], dim=-1)
+        out = render_views(preds["primpos"], preds["primscale"], preds["primqvec"], preds["opacity"],
+                           preds["color"], Rt, intr, height, width, with_depth=True, l1_target=l1_target, l1_mask=l1_mask,
+                           raw_depth=False)  # only depth / alpha.clamp(0.05, 1) leaves AutoEncoder.render
     # alpha = 1 - T.detach() and depth / alpha.clamp(0.05, 1) are written by the raster kernel's epilogue
     if l1_target is not None:
         return out["render"], out["alpha"].detach(), out["depth_norm"], out["l1_loss"]

@@ -17,6 +17,12 @@ import os
 from .render_gs import render_batch
 from .shade import shading_tail
 from .tail import fused_tail
+from .views import ViewSet
+
+
+def _fuse_projection() -> bool:
+    """GOLIATH_FUSED_PROJECTION=0: shade and project as separate kernels (rounds 1-3)."""
+    return os.environ.get("GOLIATH_FUSED_PROJECTION", "1") != "0"
 
 
 def autoencoder_forward(
@@ -63,10 +69,17 @@ def autoencoder_forward(
     enc_preds = self.encoder(registration_vertices, color)
     embs = enc_preds["embs"]
     geom = self.geomdecoder(embs)["face_geom"]
-    dec_preds = self.decoder(embs, geom, headrel_campos, light_intensity, headrel_light_pos, headrel_light_sh,
-                             n_lights, preconv_envmap, lightrot)
+    # the cameras are known before the decoder runs: its shading kernel projects the Gaussians it produces (views.py), and
+    # self.render below starts at the tile count.  Handed over as an attribute: PrimDecoder.forward keeps its signature.
+    self.decoder._goliath_view_set = ViewSet(K, headrel_Rt, self.height, self.width) if _fuse_projection() else None
+    try:
+        dec_preds = self.decoder(embs, geom, headrel_campos, light_intensity, headrel_light_pos, headrel_light_sh,
+                                 n_lights, preconv_envmap, lightrot)
+    finally:
+        self.decoder._goliath_view_set = None
     preds = {"geom": geom, "headrel_light_sh": headrel_light_sh, **enc_preds, **dec_preds}
     rgb, alpha, depth = self.render(K, headrel_Rt, preds)
+    preds.pop("projected", None)   # (consumed by the render; the returned dict has the reference's keys)
     if preconv_envmap is not None and "envbg" in kwargs:
         # visualisation-only branch (run_vis_relight.py): calibrate / composite like the reference, then the env-map
         # background and the diffuse / specular breakdown renders (rgca.py:232-245) with the reference's own helper
@@ -162,7 +175,8 @@ def prim_decoder_forward(self, embs: th.Tensor, geom: th.Tensor, headrel_campos:
                                                    headrel_light_pos.dtype)
     kw = dict(light_intensity=light_intensity, headrel_light_pos=headrel_light_pos, n_lights=n_lights,
               preconv_envmap=preconv_envmap, lightrot=lightrot, light_sh_rand=light_sh_rand,
-              n_color_sh=self.color_sh_degree, n_diff_sh=self.diff_sh_degree)
+              n_color_sh=self.color_sh_degree, n_diff_sh=self.diff_sh_degree,
+              views=getattr(self, "_goliath_view_set", None))
     if fuse:  # the 125-channel activation is never materialised (goliath_amd/tail.py)
         preds = fused_tail(self.vnocond_mod[-1], self.vcond_mod[-1], self.vnocond_mod[:-1](z), self.vcond_mod[:-1](zv),
                            postex, tn, self.albedo, headrel_light_sh, headrel_campos, **kw)

@@ -11,7 +11,7 @@ import os
 
 import torch
 
-from . import _lib
+from . import _lib, views as _views
 from ._lib import stream_ptr
 
 MAX_MIPS = 8
@@ -128,7 +128,7 @@ def _make_in(f_vnocond, f_vcond, postex, tn, albedo, light_sh, light_sh_rand, ca
 class _Shade(torch.autograd.Function):
     @staticmethod
     def forward(ctx, f_vnocond, f_vcond, postex, tn, albedo, light_sh, light_sh_rand, campos, light_intensity,
-                light_pos, n_lights, lightrot, ncol, nmono, *mips):
+                light_pos, n_lights, lightrot, ncol, nmono, view_set, *mips):
         B = f_vnocond.shape[0]
         N = f_vnocond[0, 0].numel()
         dev = f_vnocond.device
@@ -143,16 +143,29 @@ class _Shade(torch.autograd.Function):
         sout = ShadeOut()
         for n, t in outs.items():
             setattr(sout, n, _p(t))
-        with _lib.device_guard(dev):
-            _lib.call("gol_shade_fwd", ctypes.byref(sin), ctypes.byref(sout), stream_ptr())
+        records = pack = None
+        if view_set is not None:
+            # the projection of these Gaussians onto the views' cameras runs as the kernel's epilogue (views.py)
+            records = torch.empty(B, N, _views.SPLAT_RECORD, device=dev)
+            pack = torch.empty(_views.PACK_FLOATS, B * N, device=dev)
+            pj = _views.proj_struct(view_set, records, pack)
+            with _lib.device_guard(dev):
+                _lib.call("gol_shade_project_fwd", ctypes.byref(sin), ctypes.byref(sout), ctypes.byref(pj), stream_ptr())
+        else:
+            with _lib.device_guard(dev):
+                _lib.call("gol_shade_fwd", ctypes.byref(sin), ctypes.byref(sout), stream_ptr())
+        ctx.view_set = view_set
         ctx.cfg = (ncol, nmono, len(mips), rand)
         ctx.packed = packed  # not an input/output of the node: plain attribute
         ctx.save_for_backward(f_vnocond, f_vcond, postex, tn, albedo, light_sh, light_sh_rand, campos,
                               light_intensity, light_pos, n_lights, lightrot, outs["diff_sum"],
-                              outs.get("color_rand"), outs.get("env_saved"), *mips)
+                              outs.get("color_rand"), outs.get("env_saved"), pack, *mips)
         ctx.set_materialize_grads(False)
         names = [n for n in GRAD_FIELDS if n in outs]
         ctx.names = names
+        if view_set is not None:
+            ctx.mark_non_differentiable(pack)
+            return tuple(outs[n] for n in names) + (records, pack)
         return tuple(outs[n] for n in names)
 
     @staticmethod
@@ -160,8 +173,8 @@ class _Shade(torch.autograd.Function):
         ncol, nmono, n_mips, rand = ctx.cfg
         sv = ctx.saved_tensors
         (f_vnocond, f_vcond, postex, tn, albedo, light_sh, light_sh_rand, campos, light_intensity, light_pos,
-         n_lights, lightrot, diff_sum, color_rand, env_saved) = sv[:15]
-        mips = list(sv[15:])
+         n_lights, lightrot, diff_sum, color_rand, env_saved, pack) = sv[:16]
+        mips = list(sv[16:])
         B = f_vnocond.shape[0]
         N = f_vnocond[0, 0].numel()
         dev = f_vnocond.device
@@ -187,29 +200,39 @@ class _Shade(torch.autograd.Function):
         # the shared albedo's gradient = the sum of the per-view ones, by a second small kernel of the same call
         g_albedo = torch.empty(N, 3, device=dev) if ctx.needs_input_grad[4] else None
         gin.albedo = _p(g_albedo)
+        g_rec = grads[len(ctx.names)] if ctx.view_set is not None else None
         with _lib.device_guard(dev):
-            _lib.call("gol_shade_bwd", ctypes.byref(sin), ctypes.byref(saved), ctypes.byref(up), ctypes.byref(gin),
-                      stream_ptr())
+            if g_rec is not None:
+                # the raster backward's gradient records go through the projection's vjp in the kernel's prologue
+                g_rec = g_rec.to(torch.float32).contiguous()
+                pj = _views.proj_struct(ctx.view_set, g_rec, pack)   # (the records pointer is not read by the backward)
+                _lib.call("gol_shade_project_bwd", ctypes.byref(sin), ctypes.byref(saved), ctypes.byref(up),
+                          ctypes.byref(pj), _lib.fptr(g_rec), _lib.c_int(1), ctypes.byref(gin), stream_ptr())
+            else:
+                _lib.call("gol_shade_bwd", ctypes.byref(sin), ctypes.byref(saved), ctypes.byref(up), ctypes.byref(gin),
+                          stream_ptr())
         if g_albedo is not None:
             g_albedo = g_albedo.reshape(albedo.shape)
-        return (g_vn, g_vc, g_pt, g_tn, g_albedo) + (None,) * (9 + n_mips)
+        return (g_vn, g_vc, g_pt, g_tn, g_albedo) + (None,) * (10 + n_mips)
 
 
 def shading_tail(f_vnocond, f_vcond, postex, tn, albedo, headrel_light_sh, headrel_campos,
                  light_intensity=None, headrel_light_pos=None, n_lights=None, preconv_envmap=None,
-                 lightrot=None, light_sh_rand=None, n_color_sh=3, n_diff_sh=8):
+                 lightrot=None, light_sh_rand=None, n_color_sh=3, n_diff_sh=8, views=None):
     """f_vnocond[B,125,S,S], f_vcond[B,4,S,S] (decoder outputs, NCHW), postex[B,3,S,S]
     (geo_fn.to_uv(geom)), tn[B,3,S,S] (normalised uv normal map), albedo[1,N,3] -> dict with the keys
-    and [B,N,k] shapes of rgca.py:574-588 (+ "color_rand" when light_sh_rand[B,3,81] is given)."""
+    and [B,N,k] shapes of rgca.py:574-588 (+ "color_rand" when light_sh_rand[B,3,81] is given).
+    views (a goliath_amd.views.ViewSet): the cameras the result will be rendered with -- the kernel then also projects the
+    Gaussians (preds["projected"]), and render_gs.render_batch called with the same K / Rt starts at the tile count."""
     ncol = (n_color_sh + 1) ** 2
     return shading_tail_coefs(f_vnocond, f_vcond, postex, tn, albedo, headrel_light_sh, headrel_campos, ncol,
                               (n_diff_sh + 1) ** 2 - ncol, light_intensity, headrel_light_pos, n_lights,
-                              preconv_envmap, lightrot, light_sh_rand)
+                              preconv_envmap, lightrot, light_sh_rand, views)
 
 
 def shading_tail_coefs(f_vnocond, f_vcond, postex, tn, albedo, headrel_light_sh, headrel_campos, ncol, nmono,
                        light_intensity=None, headrel_light_pos=None, n_lights=None, preconv_envmap=None,
-                       lightrot=None, light_sh_rand=None):
+                       lightrot=None, light_sh_rand=None, views=None):
     """shading_tail with the SH layout given as coefficient counts: f_vnocond has 3*ncol colour-SH
     channels, nmono monochrome ones and the 12 Gaussian-parameter channels; light_sh is [B,3,ncol+nmono]."""
     if not f_vnocond.is_cuda:
@@ -232,8 +255,12 @@ def shading_tail_coefs(f_vnocond, f_vcond, postex, tn, albedo, headrel_light_sh,
         lightrot = None
     outs = _Shade.apply(c(f_vnocond), c(f_vcond), c(postex), c(tn), c(albedo).reshape(N, 3),
                         c(headrel_light_sh), c(light_sh_rand), c(headrel_campos), li, lp, nl, lightrot,
-                        ncol, nmono, *mips)
+                        ncol, nmono, views, *mips)
     names = [n for n in GRAD_FIELDS if light_sh_rand is not None or n != "color_rand"]
     preds = dict(zip(names, outs))
+    if views is not None:
+        if views.K.shape[0] != B:
+            raise ValueError(f"the ViewSet holds {views.K.shape[0]} cameras, the batch {B} views")
+        preds["projected"] = _views.Projected(views, outs[len(names)], outs[len(names) + 1], preds)
     preds["sigma"] = preds["sigma"][..., 0]  # [B,N] like rgca.py:526
     return preds

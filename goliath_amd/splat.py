@@ -17,7 +17,7 @@ import os
 
 import torch
 
-from . import _lib
+from . import _lib, views as _views
 from ._lib import c_float, c_i64, c_int, fptr, iptr, ptr, stream_ptr
 
 BLOCK = 16  # tile width; the reference's only value (render_gsplat.py:28)
@@ -399,13 +399,14 @@ class RenderLayout(ctypes.Structure):
 _LAYOUTS = {}
 
 
-def _layout(B, N, img_h, img_w, capacity, with_l1):
-    key = (B, N, img_h, img_w, capacity, with_l1)
+def _layout(B, N, img_h, img_w, capacity, with_l1, projected=False):
+    """projected: the projection's outputs live in a views.Projected (written by the shading kernel), not in the workspace."""
+    key = (B, N, img_h, img_w, capacity, with_l1, projected)
     L = _LAYOUTS.get(key)
     if L is None:
         L = RenderLayout()
-        _lib.call("gol_render_layout", c_int(B), c_int(N), c_int(img_h), c_int(img_w), c_i64(capacity), c_int(with_l1),
-                  ctypes.byref(L))
+        _lib.call("gol_render_layout_projected" if projected else "gol_render_layout", c_int(B), c_int(N), c_int(img_h),
+                  c_int(img_w), c_i64(capacity), c_int(with_l1), ctypes.byref(L))
         if len(_LAYOUTS) > 256:
             _LAYOUTS.clear()
         _LAYOUTS[key] = L
@@ -461,6 +462,38 @@ def _render_bwd_stages(B, N, img_h, img_w, glob_scale, means, scales, quats, opa
               fptr(v_scale_g), fptr(v_quat), fptr(v_opacity), stream_ptr())
 
 
+def _render_fwd_stages_projected(B, N, img_h, img_w, pj, background, with_depth, norm_lo, cap, ws, L, out_img, out_depth,
+                                 alpha, depth_norm, l1_target, l1_mask, l1_mask_c, l1_partial, l1_out, l1_scale):
+    """gol_render_fwd_projected, stage by stage (per-stage event timing)."""
+    p = lambda off: ctypes.c_void_p(ws.data_ptr() + off) if off >= 0 else ctypes.c_void_p(0)
+    v = ctypes.c_void_p
+    _lib.call("gol_bin_sort", c_int(B), c_int(N), v(pj.xys), v(pj.depths), v(pj.radii), v(pj.conics), v(pj.opac_eff),
+              c_int(img_h), c_int(img_w), c_int(BLOCK), c_i64(cap), p(L.tile_count), p(L.tile_bins), p(L.keys),
+              p(L.sorted_ids), p(L.n_isect), ctypes.c_void_p(0), stream_ptr())
+    _lib.call("gol_rasterize_fwd", c_int(B), c_int(N), c_int(img_h), c_int(img_w), c_int(BLOCK), c_int(1),
+              p(L.tile_bins), p(L.sorted_ids), c_i64(cap), v(pj.records), c_int(1 if with_depth else 0), fptr(background),
+              fptr(out_img), fptr(out_depth), p(L.final_T), p(L.final_idx), fptr(alpha), fptr(depth_norm),
+              c_float(norm_lo), fptr(l1_target), fptr(l1_mask), c_int(l1_mask_c),
+              p(L.l1_sign) if l1_target is not None else ctypes.c_void_p(0), fptr(l1_partial), fptr(l1_out),
+              c_float(l1_scale), c_int(RASTER_PPL), stream_ptr())
+
+
+def _render_bwd_stages_projected(B, N, img_h, img_w, pj, background, cap, ws, L, v_img, v_depth, v_alpha, use_l1, l1_mask,
+                                 v_scale, v_scale_mul, rec):
+    """gol_render_bwd_projected, stage by stage."""
+    p = lambda off: ctypes.c_void_p(ws.data_ptr() + off) if off >= 0 else ctypes.c_void_p(0)
+    field = lambda k: ctypes.c_void_p(rec.data_ptr() + 4 * k)
+    null = ctypes.c_void_p(0)
+    use_depth = v_depth is not None
+    rec.zero_()
+    _lib.call("gol_rasterize_bwd", c_int(B), c_int(N), c_int(img_h), c_int(img_w), c_int(BLOCK), c_int(1),
+              p(L.tile_bins), p(L.sorted_ids), c_i64(cap), ctypes.c_void_p(pj.records), c_int(1 if use_depth else 0),
+              fptr(background), p(L.final_T), p(L.final_idx), fptr(v_img), fptr(v_depth), fptr(v_alpha), field(4), field(6),
+              field(0), field(9) if use_depth else null, field(3), c_int(GRAD_RECORD), p(L.l1_sign) if use_l1 else null,
+              fptr(l1_mask) if use_l1 else null, c_int(0 if (l1_mask is None or not use_l1) else l1_mask.shape[1]),
+              fptr(v_scale), c_float(v_scale_mul), c_int(0), stream_ptr())
+
+
 class _RenderViews(torch.autograd.Function):
     """The fused path: ONE C-ABI call per direction (gol_render_fwd / gol_render_bwd, csrc/render.hip) out of one
     workspace allocation; the host work of a direction is that call plus the allocation of its outputs."""
@@ -468,9 +501,14 @@ class _RenderViews(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means, scales, quats, opacity, colors, viewmats, intrins, background, img_h, img_w,
                 glob_scale, clip_thresh, with_depth, capacity, depth_norm_lo, plan_key, l1_target, l1_mask,
-                raw_depth=True):
-        B, N = means.shape[:2]
-        dev = means.device
+                raw_depth=True, records=None, pack=None, view_set=None):
+        # records / pack / view_set given (a views.Projected): the Gaussians were projected by the shading kernel -- means ...
+        # colors are None, the call starts at the tile count and its backward ends at the gradient records (= the gradient of
+        # `records`, which the shading backward pushes through the projection's vjp)
+        projected = records is not None
+        B, N = (records if projected else means).shape[:2]
+        dev = (records if projected else means).device
+        pj = _views.proj_struct(view_set, records, pack) if projected else None
         T = _tiles(img_h, img_w)
         with_l1 = 1 if l1_target is not None else 0
         f = dict(dtype=torch.float32, device=dev)
@@ -488,9 +526,19 @@ class _RenderViews(torch.autograd.Function):
         l1_mask_c = 0 if l1_mask is None else l1_mask.shape[1]
 
         def run(cap):
-            L = _layout(B, N, img_h, img_w, cap, with_l1)
+            L = _layout(B, N, img_h, img_w, cap, with_l1, projected)
             ws = torch.empty(max(L.total, 1), dtype=torch.uint8, device=dev)
-            if _lib.TIMING is not None:
+            if projected and _lib.TIMING is not None:
+                _render_fwd_stages_projected(B, N, img_h, img_w, pj, background, with_depth, depth_norm_lo, cap, ws, L,
+                                             out_img, out_depth, alpha, depth_norm, l1_target, l1_mask, l1_mask_c,
+                                             l1_partial, l1_out, l1_inv_n)
+            elif projected:
+                _lib.call("gol_render_fwd_projected", c_int(B), c_int(N), ctypes.byref(pj), fptr(background),
+                          c_int(1 if with_depth else 0), c_float(depth_norm_lo), c_i64(cap),
+                          ctypes.c_void_p(ws.data_ptr()), ctypes.byref(L), fptr(out_img), fptr(out_depth), fptr(alpha),
+                          fptr(depth_norm), fptr(l1_target), fptr(l1_mask), c_int(l1_mask_c), fptr(l1_partial),
+                          fptr(l1_out), c_float(l1_inv_n), stream_ptr())
+            elif _lib.TIMING is not None:
                 # instrumented pass (bench.py): the same work as three ABI calls, so that events bracket each stage
                 _render_fwd_stages(B, N, img_h, img_w, glob_scale, clip_thresh, means, scales, quats, opacity, colors,
                                    viewmats, intrins, background, with_depth, depth_norm_lo, cap, ws, L, out_img,
@@ -526,17 +574,19 @@ class _RenderViews(torch.autograd.Function):
         ctx.cfg = (img_h, img_w, glob_scale, with_depth, depth_norm_lo, with_l1)
         ctx.l1_inv_n = l1_inv_n
         l1 = l1_out.reshape(()) if with_l1 else None  # == mean(|(rgb - target) * mask|)
-        ctx.save_for_backward(means, scales, quats, opacity, viewmats, intrins, background, ws, l1_mask)
+        ctx.view_set = view_set
+        ctx.save_for_backward(means, scales, quats, opacity, viewmats, intrins, background, ws, l1_mask, records, pack)
         ctx.mark_non_differentiable(ws, n_isect)
         ctx.set_materialize_grads(False)
         return out_img, alpha, out_depth, depth_norm, l1, ws, n_isect
 
     @staticmethod
     def backward(ctx, v_img, v_alpha, v_depth, v_depth_norm, v_l1, *_non_differentiable):
-        means, scales, quats, opacity, viewmats, intrins, background, ws, l1_mask = ctx.saved_tensors
+        means, scales, quats, opacity, viewmats, intrins, background, ws, l1_mask, records, pack = ctx.saved_tensors
         img_h, img_w, glob_scale, with_depth, depth_norm_lo, with_l1 = ctx.cfg
-        B, N = means.shape[:2]
-        dev = means.device
+        projected = records is not None
+        B, N = (records if projected else means).shape[:2]
+        dev = ws.device
         L = ctx.L
         if v_depth_norm is not None:  # depth_norm = depth / clamp(alpha.detach(), lo, 1), alpha = 1 - final_T
             final_Ts = _ws_view(ws, L.final_T, torch.float32, (B, img_h, img_w))
@@ -545,7 +595,7 @@ class _RenderViews(torch.autograd.Function):
         if not with_l1:
             v_l1 = None
         if v_img is None and v_alpha is None and v_depth is None and v_l1 is None:
-            return (None,) * 19
+            return (None,) * 22
         # fused L1: d loss / d rgb = (sign code - 1) * mask * (v_l1 / n).  The raster backward decodes the sign bytes itself
         # and adds the term to v_img (if the image has another consumer); the scalar goes in as a device value: no sync,
         # no pass over the image
@@ -563,17 +613,30 @@ class _RenderViews(torch.autograd.Function):
         # 64-byte gradient records per Gaussian (include/goliath_hip.h: GOL_GRAD_RECORD), zeroed by the call: a Gaussian's
         # float atomics hit one cache line and are issued by 16 adjacent lanes
         rec = torch.empty(B, N, GRAD_RECORD, device=dev)
+        use_mask = l1_mask if v_l1 is not None else None
+        if projected:
+            pj = _views.proj_struct(ctx.view_set, records, pack)
+            with _lib.device_guard(dev):
+                if _lib.TIMING is not None:
+                    _render_bwd_stages_projected(B, N, img_h, img_w, pj, background, ctx.capacity, ws, L, v_img_c, v_depth_c,
+                                                 v_alpha_c, v_l1 is not None, use_mask, v_scale, ctx.l1_inv_n, rec)
+                else:
+                    _lib.call("gol_render_bwd_projected", c_int(B), c_int(N), ctypes.byref(pj), fptr(background),
+                              c_i64(ctx.capacity), ctypes.c_void_p(ws.data_ptr()), ctypes.byref(L), fptr(v_img_c),
+                              fptr(v_depth_c), fptr(v_alpha_c), c_int(1 if v_l1 is not None else 0), fptr(use_mask),
+                              c_int(0 if use_mask is None else use_mask.shape[1]), fptr(v_scale), c_float(ctx.l1_inv_n),
+                              fptr(rec), stream_ptr())
+            return (None,) * 19 + (rec, None, None)
         v_mean = torch.empty_like(means)
         v_scale_g = torch.empty_like(scales)
         v_quat = torch.empty_like(quats)
         v_opacity = torch.empty_like(opacity)
-        use_mask = l1_mask if v_l1 is not None else None
         if _lib.TIMING is not None:
             with _lib.device_guard(dev):
                 _render_bwd_stages(B, N, img_h, img_w, glob_scale, means, scales, quats, opacity, viewmats, intrins,
                                    background, ctx.capacity, ws, L, v_img_c, v_depth_c, v_alpha_c, v_l1 is not None,
                                    use_mask, v_scale, ctx.l1_inv_n, rec, v_mean, v_scale_g, v_quat, v_opacity)
-            return (v_mean, v_scale_g, v_quat, v_opacity, rec[..., :3]) + (None,) * 14
+            return (v_mean, v_scale_g, v_quat, v_opacity, rec[..., :3]) + (None,) * 17
         v_color = torch.empty(B, N, 3, device=dev)  # dense copy of the records' colour gradient (written by the projection backward)
         with _lib.device_guard(dev):
             _lib.call("gol_render_bwd", c_int(B), c_int(N), c_int(img_h), c_int(img_w), c_float(glob_scale), fptr(means),
@@ -584,7 +647,7 @@ class _RenderViews(torch.autograd.Function):
                       fptr(v_mean),
                       fptr(v_scale_g), fptr(v_quat), fptr(v_opacity), fptr(v_color), stream_ptr())
         # (the workspace stays alive with the node: retain_graph / a second backward re-reads the tile lists)
-        return (v_mean, v_scale_g, v_quat, v_opacity, v_color) + (None,) * 14
+        return (v_mean, v_scale_g, v_quat, v_opacity, v_color) + (None,) * 17
 
 
 _BLACK = {}
@@ -594,15 +657,15 @@ class _LazyRender(dict):
     """Result of render_views: the images are plain entries; the diagnostics (typed views into the call's workspace:
     radii, final_T, final_idx, sorted_ids, tile_bins) are created on first access."""
 
-    def __init__(self, ws, layout, dims, capacity):
+    def __init__(self, ws, layout, dims, capacity, projected=None):
         super().__init__()
-        self._ws, self._L, self._dims, self._cap = ws, layout, dims, capacity
+        self._ws, self._L, self._dims, self._cap, self._proj = ws, layout, dims, capacity, projected
 
     def __missing__(self, key):
         B, N, H, W, T = self._dims
         ws, L = self._ws, self._L
         if key == "radii":
-            v = _ws_view(ws, L.radii, torch.int32, (B, N))
+            v = _ws_view(ws, L.radii, torch.int32, (B, N)) if self._proj is None else self._proj.field("radii")
         elif key == "final_T":
             v = _ws_view(ws, L.final_T, torch.float32, (B, 1, H, W))
         elif key == "final_idx":
@@ -624,15 +687,16 @@ def raster_pair_counts(res):
     ws, L = res._ws, res._L
     counts = torch.empty(B, 2, dtype=torch.int64, device=ws.device)
     p = lambda off: ctypes.c_void_p(ws.data_ptr() + off)
+    rec = p(L.records) if res._proj is None else fptr(res._proj.records)
     with _lib.device_guard(ws.device):
         _lib.call("gol_raster_count_pairs", c_int(B), c_int(N), c_int(H), c_int(W), p(L.tile_bins), p(L.sorted_ids),
-                  c_i64(res._cap), p(L.records), p(L.final_idx), ptr(counts, torch.int64), stream_ptr())
+                  c_i64(res._cap), rec, p(L.final_idx), ptr(counts, torch.int64), stream_ptr())
     return counts
 
 
 def render_views(means, scales, quats, opacity, colors, viewmats, intrins, img_h, img_w,
                  background=None, glob_scale=1.0, clip_thresh=0.1, with_depth=True, capacity=None, depth_norm_lo=0.05,
-                 l1_target=None, l1_mask=None, raw_depth=True):
+                 l1_target=None, l1_mask=None, raw_depth=True, projected=None):
     """Render B views in one launch sequence.
 
     means[B,N,3] scales[B,N,3] quats[B,N,4] opacity[B,N] or [B,N,1] colors[B,N,3]  (fp32, GPU)
@@ -647,15 +711,25 @@ def render_views(means, scales, quats, opacity, colors, viewmats, intrins, img_h
     backward itself (no separate passes over the image; no gradient to target / mask).
     raw_depth=False: only depth_norm is produced (what AutoEncoder.render returns, rgca.py:144-145) -- the forward
     writes one image less; "depth" is then absent from the result.
+    projected (a views.Projected out of shading_tail(..., views=...)): the Gaussians are already projected onto these
+    cameras by the shading kernel; means ... intrins are ignored (pass None), glob_scale / clip_thresh are the ViewSet's.
     """
-    B, N = means.shape[:2]
-    dev = means.device
-    if not means.is_cuda:
-        raise _lib.GoliathHipError("render_views needs CUDA(HIP) tensors; there is no CPU path")
-    means, scales, quats, colors = _f32c(means), _f32c(scales), _f32c(quats), _f32c(colors)
-    opacity = _f32c(opacity).reshape(B, N)
-    viewmats = _f32c(viewmats).reshape(B, viewmats[0].numel() if B else 12)[:, :12].contiguous()
-    intrins = _f32c(intrins).reshape(B, 4)
+    if projected is not None:
+        B, N = projected.records.shape[:2]
+        dev = projected.records.device
+        if (projected.views.height, projected.views.width) != (img_h, img_w):
+            raise ValueError("projected for another image size")
+        means = scales = quats = opacity = colors = viewmats = intrins = None
+        glob_scale, clip_thresh = projected.views.glob_scale, projected.views.clip_thresh
+    else:
+        B, N = means.shape[:2]
+        dev = means.device
+        if not means.is_cuda:
+            raise _lib.GoliathHipError("render_views needs CUDA(HIP) tensors; there is no CPU path")
+        means, scales, quats, colors = _f32c(means), _f32c(scales), _f32c(quats), _f32c(colors)
+        opacity = _f32c(opacity).reshape(B, N)
+        viewmats = _f32c(viewmats).reshape(B, viewmats[0].numel() if B else 12)[:, :12].contiguous()
+        intrins = _f32c(intrins).reshape(B, 4)
     if background is None:
         background = _BLACK.get(dev)   # render_gsplat.py:38-39 (one constant per device: no fill kernel per call)
         if background is None:
@@ -691,16 +765,21 @@ def render_views(means, scales, quats, opacity, colors, viewmats, intrins, img_h
         l1_mask = None
     out = _RenderViews.apply(means, scales, quats, opacity, colors, viewmats, intrins, background, img_h,
                              img_w, float(glob_scale), float(clip_thresh), bool(with_depth), int(capacity),
-                             float(depth_norm_lo), plan_key, l1_target, l1_mask, bool(raw_depth))
+                             float(depth_norm_lo), plan_key, l1_target, l1_mask, bool(raw_depth),
+                             None if projected is None else projected.records,
+                             None if projected is None else projected.pack,
+                             None if projected is None else projected.views)
     img, alpha, depth, depth_norm, l1, ws, n_isect = out
     with_l1 = 1 if l1_target is not None else 0
-    if plan_key is not None and max(_layout(B, N, img_h, img_w, capacity, with_l1).total, 1) != ws.numel():
+    is_proj = projected is not None
+    if plan_key is not None and max(_layout(B, N, img_h, img_w, capacity, with_l1, is_proj).total, 1) != ws.numel():
         capacity = PLANNER.get(key)   # the checked call re-ran at a grown capacity: that is the workspace's layout
     if PLANNER.frozen:
         PLANNER.frozen_log.append((n_isect, capacity))
     elif deferred and B > 0:
         PLANNER.note(key, n_isect, capacity)
-    res = _LazyRender(ws, _layout(B, N, img_h, img_w, capacity, with_l1), (B, N, img_h, img_w, T), capacity)
+    res = _LazyRender(ws, _layout(B, N, img_h, img_w, capacity, with_l1, is_proj), (B, N, img_h, img_w, T), capacity,
+                      projected)
     res["render"], res["alpha"], res["n_isect"] = img, alpha[:, None], n_isect
     # per-pixel index of the last contributor in its view's depth-sorted list, and that list: res["final_idx"],
     # res["sorted_ids"], res["tile_bins"], res["final_T"], res["radii"] (views into the call's workspace, made on access)

@@ -130,7 +130,7 @@ def contracted_vnocond_torch(x_vn, weight, bias, light_sh, light_sh_rand, ncol, 
 
 def fused_tail(last_vn, last_vc, x_vn, x_vc, postex, tn, albedo, headrel_light_sh, headrel_campos,
                light_intensity=None, headrel_light_pos=None, n_lights=None, preconv_envmap=None, lightrot=None,
-               light_sh_rand=None, n_color_sh=3, n_diff_sh=8):
+               light_sh_rand=None, n_color_sh=3, n_diff_sh=8, views=None):
     """Same outputs as `shading_tail(last_vn(x_vn), last_vc(x_vc), ...)` without the 125-channel tensor.
     last_vn / last_vc: the final ConvTranspose2dWNUB modules (parameters weight_v, weight_g, bias)."""
     ncol = (n_color_sh + 1) ** 2
@@ -146,4 +146,4 @@ def fused_tail(last_vn, last_vc, x_vn, x_vc, postex, tn, albedo, headrel_light_s
         sel_r = f_c.new_tensor([0.0, 1.0]).expand(B, 3, 2).contiguous()
         kc = 2
     return shading_tail_coefs(f_in, f_vc, postex, tn, albedo, sel, headrel_campos, kc, 0, light_intensity,
-                              headrel_light_pos, n_lights, preconv_envmap, lightrot, sel_r)
+                              headrel_light_pos, n_lights, preconv_envmap, lightrot, sel_r, views)

@@ -316,6 +316,48 @@ int gol_shade_fwd(const gol_shade_in* in, const gol_shade_out* out, void* stream
 int gol_shade_bwd(const gol_shade_in* in, const gol_shade_out* saved, const gol_shade_out_grad* g,
                   const gol_shade_in_grad* gin, void* stream);
 
+/* Shading WITH the projection fused in (north_star: "streaming stages fused"; rgca.py:505-588 -> render_gsplat.py:49-63).
+ * The cameras of the B views are known before the decoder runs (AutoEncoder.forward builds headrel_Rt first,
+ * rgca.py:175-195), so the shading kernel projects the Gaussians it has just produced while their position, quaternion,
+ * clamped scale, opacity and colour are still in registers, and writes what binning and the rasterizer read; the render
+ * direction then starts at the tile count (gol_render_fwd_projected) and ends at the gradient records
+ * (gol_render_bwd_projected), which gol_shade_project_bwd pushes through the projection's vjp in its own prologue.
+ * gol_project_fwd / gol_project_bwd stay for the gsplat-compatible operators and for Gaussians that do not come out of
+ * the shading tail.  Same arithmetic (csrc/gol_project.h) either way. */
+typedef struct {
+  const float* viewmats;     /* [B,12] world -> camera, row-major 3x4                                   */
+  const float* intrins;      /* [B,4]  fx, fy, cx, cy                                                   */
+  int32_t img_h, img_w;
+  float glob_scale, clip_thresh;
+  /* written by gol_shade_project_fwd, read by binning / raster / gol_shade_project_bwd: shapes of gol_project_fwd's outputs */
+  float* xys;                /* [B,N,2] */
+  float* depths;             /* [B,N]   */
+  int32_t* radii;            /* [B,N]   */
+  float* conics;             /* [B,N,3] */
+  float* comp;               /* [B,N]   */
+  float* opac_eff;           /* [B,N]   opacity x compensation (render_gsplat.py:72)                    */
+  float* records;            /* [B,N,GOL_SPLAT_RECORD] the rasterizer's packed records (colour + depth) */
+} gol_shade_proj;
+int gol_shade_project_fwd(const gol_shade_in* in, const gol_shade_out* out, const gol_shade_proj* proj, void* stream);
+/* The render direction of Gaussians gol_shade_project_fwd has projected: gol_render_fwd minus its first kernel,
+ * gol_render_bwd minus its last (the workspace then holds only tile lists and per-pixel state:
+ * gol_render_layout_projected; the layout's xys ... records offsets are -1). */
+int gol_render_layout_projected(int B, int N, int img_h, int img_w, int64_t capacity, int with_l1, gol_render_ws* layout);
+int gol_render_fwd_projected(int B, int N, const gol_shade_proj* proj, const float* background, int with_depth,
+                             float norm_lo, int64_t capacity, void* workspace, const gol_render_ws* layout,
+                             float* out_img, float* out_depth, float* out_alpha, float* out_depth_norm,
+                             const float* l1_target, const float* l1_mask, int l1_mask_c, float* l1_partial, float* l1_out,
+                             float l1_scale, void* stream);
+int gol_render_bwd_projected(int B, int N, const gol_shade_proj* proj, const float* background, int64_t capacity,
+                             void* workspace, const gol_render_ws* layout, const float* v_img, const float* v_depth,
+                             const float* v_alpha, int use_l1_sign, const float* l1_mask, int l1_mask_c,
+                             const float* v_img_scale, float v_img_scale_mul, float* grad_records, void* stream);
+/* grad_records[B,N,GOL_GRAD_RECORD] = the output of gol_render_bwd_projected; its colour / opacity / position /
+ * quaternion / scale gradients are ADDED to the matching fields of `g` (other consumers of those outputs). */
+int gol_shade_project_bwd(const gol_shade_in* in, const gol_shade_out* saved, const gol_shade_out_grad* g,
+                          const gol_shade_proj* proj, const float* grad_records, int with_depth,
+                          const gol_shade_in_grad* gin, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Mixture-of-Volumetric-Primitives ray marcher + its helpers (BASELINE config 5).
  * Replaces utilslib.compute_raydirs_forward (extensions/utils/utils.cpp:46-82, kernel

@@ -25,7 +25,11 @@ CALLS = {  # kernel-name prefix -> ABI call
 
 
 def call_of(kernel):
-    return next((c for p, c in CALLS.items() if kernel.startswith(p)), None)
+    c = next((c for p, c in CALLS.items() if kernel.startswith(p)), None)
+    # the shading kernels with the projection fused in (last template argument true) belong to gol_shade_project_fwd / bwd
+    if c in ("gol_shade_fwd", "gol_shade_bwd") and kernel.startswith("shade_") and kernel.rstrip().endswith("true>"):
+        c = c.replace("gol_shade_", "gol_shade_project_")
+    return c
 
 
 def main(tag, traffic_name="traffic.json", only_traffic=False):
