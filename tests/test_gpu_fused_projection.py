@@ -86,6 +86,17 @@ def test_fused_projection_equals_the_separate_kernels(env, extra, rand):
         assert rel_l2(g1[k], g0[k]) < 2e-6, k
 
 
+def test_fused_projection_with_a_gaussian_count_that_is_not_a_multiple_of_four():
+    """N = 33 x 33: the one-Gaussian-per-lane instantiation of the fused forward (the 4-per-lane one needs N % 4 == 0)."""
+    B, S, H, W = 2, 33, 160, 112
+    t = _inputs(B, S, H, W, True)
+    p0, rgb0, a0, d0, l0, g0 = _run(t, H, W, True, False, True)
+    p1, rgb1, a1, d1, l1, g1 = _run(t, H, W, True, True, True)
+    assert torch.equal(rgb0, rgb1) and torch.equal(a0, a1) and torch.equal(d0, d1) and l0 == l1
+    for k in LEAVES:
+        assert rel_l2(g1[k], g0[k]) < 2e-6, k
+
+
 def test_fused_projection_at_the_benchmarked_size():
     """BASELINE config 2, one micro-batch of bench.py (4 views, 250k Gaussians, 2048x1334): the chain test
     (test_gpu_fullsize.py) pins the separate kernels to the oracle; here the fused path must reproduce them -- identical
