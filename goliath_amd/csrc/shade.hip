@@ -807,8 +807,7 @@ extern "C" int gol_envmap_pack(int B, int h, int w, const float* src, float* dst
 
 namespace {
 
-int check_proj(const gol_shade_in* in, const gol_shade_proj* pj, bool outputs_only_read) {
-  (void)outputs_only_read;
+int check_proj(const gol_shade_in* in, const gol_shade_proj* pj) {
   GOL_REQUIRE(pj != nullptr, "null gol_shade_proj");
   GOL_REQUIRE(pj->img_h > 0 && pj->img_w > 0, "empty image");
   if (in->B == 0 || in->N == 0) return GOL_OK;
@@ -821,7 +820,7 @@ int check_proj(const gol_shade_in* in, const gol_shade_proj* pj, bool outputs_on
 int shade_fwd_launch(const gol_shade_in* in, const gol_shade_out* out, const gol_shade_proj* proj, void* stream) {
   int rc = check_in(in);
   if (rc != GOL_OK) return rc;
-  if (proj && (rc = check_proj(in, proj, false)) != GOL_OK) return rc;
+  if (proj && (rc = check_proj(in, proj)) != GOL_OK) return rc;
   if (in->B == 0 || in->N == 0) return GOL_OK;
   GOL_REQUIRE(out != nullptr, "null gol_shade_out");
   GOL_REQUIRE(out->color && out->opacity && out->primpos && out->primqvec && out->primscale &&
@@ -847,7 +846,7 @@ int shade_bwd_launch(const gol_shade_in* in, const gol_shade_out* saved, const g
                      void* stream) {
   int rc = check_in(in);
   if (rc != GOL_OK) return rc;
-  if (proj && (rc = check_proj(in, proj, true)) != GOL_OK) return rc;
+  if (proj && (rc = check_proj(in, proj)) != GOL_OK) return rc;
   if (in->B == 0 || in->N == 0) return GOL_OK;
   GOL_REQUIRE(saved && g && gin, "null struct");
   GOL_REQUIRE(saved->diff_sum != nullptr, "saved diff_sum missing");
