@@ -40,6 +40,7 @@ _ROWS = {
     "test_gpu_urhand_model": "(+) URHand / teacher model-level bindings", "test_gpu_meshraster": "f4  mesh depth render (unpinned)",
     "test_gpu_tail": "f1  light-contracted decoder tail (tail.hip)", "test_gpu_ssim": "f3  SSIM (ssim.hip)",
     "test_gpu_losses": "f3  masked L1 (imgloss.hip)", "test_imgtail": "f3  image tail: CalV5 + LearnableBlur (imgtail.hip)",
+    "test_gpu_fused_projection": "S -> R2  projection fused into the shading kernels vs the separate kernels",
     "test_gpu_e2e_descent": "8d mode B  end-to-end descent", "test_gpu_multirank": "8e  N-rank path on one GPU",
 }
 _LEDGER = []
