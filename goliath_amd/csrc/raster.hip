@@ -516,13 +516,21 @@ __global__ __launch_bounds__(64 * Pix<PPL>::kWaves) void raster_bwd_kernel(
 
   float* acc_lane = &s_acc[wave][0][lane >> 4];  // this lane's column (lanes 15, 31, 47, 63 hold sums 0..3 / 4..7)
   const int n_batches = (bmax - range.x + kBatchB) / kBatchB;
+  // A batch is staged through two dependent loads (list id -> the Gaussian's record).  The id of the NEXT batch's entry is
+  // fetched while this batch is being worked on, so that only the record gather is left behind the barrier (nothing hides it
+  // in the tail of a launch, when a SIMD is down to one or two waves).
+  auto entry_id = [&](int bb2) {
+    const int e = bmax - bb2 * kBatchB - tid;
+    return (tid < kBatchB && e >= range.x) ? ids[e] : 0;
+  };
+  int gid_next = entry_id(0);
   for (int bb = 0; bb < n_batches; ++bb) {
     __syncthreads();
     const int batch_end = bmax - bb * kBatchB;
     const int batch_size = min(kBatchB, batch_end + 1 - range.x);
+    const int gid = gid_next;
     if (tid < kBatchB) {
       if (tid < batch_size) {
-        const int gid = ids[batch_end - tid];
         const Staged st = stage_entry<PPL>(records, goff + (size_t)gid, (float)(tc.tx * 16), (float)(tc.ty * 16));
         s_e[tid].a = st.a; s_e[tid].b = st.b; s_e[tid].c = st.c; s_mask[tid] = st.mask;
         s_id[tid] = gid;
@@ -530,6 +538,7 @@ __global__ __launch_bounds__(64 * Pix<PPL>::kWaves) void raster_bwd_kernel(
         s_mask[tid] = 0;
       }
     }
+    if (bb + 1 < n_batches) gid_next = entry_id(bb + 1);
     (&s_touched[0][0])[tid] = 0;  // NW * kBatchB == blockDim
     __syncthreads();
 
