@@ -781,6 +781,14 @@ extern "C" int gol_envmap_pack(int B, int h, int w, const float* src, float* dst
   return GOL_OK;
 }
 
+// Gaussians per lane of the forward: 4 (16-byte plane loads) when N allows and the launch then still has a workgroup per CU;
+// a smaller launch takes 2 -- one view of 250k Gaussians is 245 workgroups at 4 per lane, i.e. one wave per SIMD on most
+// CUs and nothing to hide the plane loads behind: 60 -> 52 us (1 per lane: 54; launches of >= 2 such views are fastest at 4).
+static int shade_fwd_width(const gol_shade_in* in) {
+  if (in->N % 4 == 0 && (long long)gol_cdiv(in->N / 4, 256) * in->B >= 256) return 4;
+  return (in->N % 2 == 0) ? 2 : 1;
+}
+
 #define GOL_SHADE_FWD_V(V, P, ...)                                                                \
   do {                                                                                           \
     dim3 grid(gol_cdiv(in->N / V, 256), in->B);                                                  \
@@ -794,8 +802,9 @@ extern "C" int gol_envmap_pack(int B, int h, int w, const float* src, float* dst
 #define GOL_SHADE_FWD_DISPATCH(P, ...)                                                           \
   do {                                                                                           \
     const bool env = in->n_mips > 0, rnd = in->light_sh_rand != nullptr;                         \
-    if (in->N % 4 == 0) GOL_SHADE_FWD_V(4, P, __VA_ARGS__);                                      \
-    else if (!P && in->N % 2 == 0) GOL_SHADE_FWD_V(2, false, __VA_ARGS__);                       \
+    const int vv = shade_fwd_width(in);                                                          \
+    if (vv == 4) GOL_SHADE_FWD_V(4, P, __VA_ARGS__);                                             \
+    else if (vv == 2) GOL_SHADE_FWD_V(2, P, __VA_ARGS__);                                        \
     else GOL_SHADE_FWD_V(1, P, __VA_ARGS__);                                                     \
   } while (0)
 
