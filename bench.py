@@ -98,7 +98,15 @@ def make_inputs(cfg, device, rank=0):
     albedo = 0.2 + 0.6 * torch.rand(1, N, 3, generator=g)
     light_sh = 0.3 * torch.randn(B, 3, 81, generator=g) / (1 + torch.arange(81.0)) ** 0.5
     light_sh[:, :, 0] = 1.5
-    mips = [torch.exp(0.5 * torch.randn(B, 3, 512 >> i, 1024 >> i, generator=g)) * 0.5 for i in range(cfg["n_mips"])]
+    if cfg.get("env_per_view"):
+        # rounds 1-4's workload: B DIFFERENT pyramids (harder than config 2: nothing of a map is shared between views)
+        mips = [torch.exp(0.5 * torch.randn(B, 3, 512 >> i, 1024 >> i, generator=g)) * 0.5 for i in range(cfg["n_mips"])]
+    else:
+        # BASELINE config 2 "single env-map relight" / SURVEY 8d: ONE synthetic HDR pyramid (log-normal pixels) for every view
+        # of the step on every rank, rotated per view by `lightrot` -- what EnvSpinDecorator feeds (light_decorator.py:96-100,
+        # 112-118: one registered pyramid expanded over the batch; the lookup direction is rotated, not the map)
+        ge = torch.Generator().manual_seed(cfg["seed"] + 4242)
+        mips = [torch.exp(0.5 * torch.randn(1, 3, 512 >> i, 1024 >> i, generator=ge)) * 0.5 for i in range(cfg["n_mips"])]
     K = torch.zeros(B, 3, 3)
     K[:, 0, 0] = K[:, 1, 1] = cfg["focal"]
     K[:, 0, 2], K[:, 1, 2], K[:, 2, 2] = cfg["width"] / 2.0, cfg["height"] / 2.0, 1.0
@@ -247,6 +255,8 @@ def make_step_inputs(cfg, device, rank, n_micro):
     albedo = micro[0]["albedo"].detach().clone().requires_grad_(True)
     for mb in micro:
         mb["albedo"] = albedo.detach().clone().requires_grad_(True)  # per-stream alias of the shared parameter
+        if not cfg.get("env_per_view"):
+            mb["mips"] = micro[0]["mips"]                            # ONE pyramid in HBM for the whole step
     return {"micro": micro, "albedo": albedo, "streams": [torch.cuda.Stream(device=device) for _ in range(n_micro)]}
 
 
@@ -824,6 +834,9 @@ def parse_args(argv=None):
     ap.add_argument("--smooth-normals", action="store_true",
                     help="decoder-like low-frequency normal offsets (f_vcond smooth over the slab) instead of SURVEY 8d's "
                          "white noise; with --coherent-uv this is the realistic case for the env-map gathers")
+    ap.add_argument("--env-per-view", action="store_true",
+                    help="every view gets its OWN env-map pyramid (rounds 1-4's workload; config 2 is ONE pyramid shared by "
+                         "all views and rotated per view, the default since round 5)")
     ap.add_argument("--grad-floats", type=int, default=-1,
                     help="size of the gradient set exchanged per step besides the albedo map (default: 60 M fp32 = the "
                          "config-3 decoder parameter set when N > 1, 0 when N = 1)")
@@ -883,7 +896,8 @@ def run_rgca(args, D, views, scaling, workload, overlap, micro=None, extras=True
     """Warm up, capture and time the rgca step for `views` views per rank; returns the result dict (rank 0; None on the
     other ranks).  overlap: exchange mode for N > 1 (see run_step).  extras: intersection counts, per-call HBM table."""
     cfg = dict(CFG, workload=workload, views_per_gpu=views, coherent_uv=bool(args.coherent_uv),
-               smooth_normals=bool(args.smooth_normals), fused_projection=not args.unfused_projection)
+               smooth_normals=bool(args.smooth_normals), fused_projection=not args.unfused_projection,
+               env_per_view=bool(getattr(args, "env_per_view", False)))
     # with the projection fused in, micro-batches of >= 4 views are joined once after their shading kernels (see step();
     # measured: 8 views 2803 -> 2855 views/s; 2 + 2 and 1 + 1 views are faster left alone, and so is the unfused path)
     cfg["align_micro_batches"] = (cfg["fused_projection"] and views // max(1, min(args.micro if micro is None else micro, views)) >= 4
@@ -1043,7 +1057,8 @@ def run_rgca(args, D, views, scaling, workload, overlap, micro=None, extras=True
                    "micro_batches": micro,
                    "launch": ("eager composite calls" if graph is None else "hip_graph_replay") +
                              " (kernels_ms_per_call / roofline: eager instrumented pass after the timed region)",
-                   "relight": "envmap_4mips",
+                   "relight": "envmap_4mips, " + ("one pyramid per view (rounds 1-4)" if cfg["env_per_view"] else
+                                                  "ONE pyramid shared by all views, per-view lightrot (config 2)"),
                    "slab_layout": "uv-coherent" if args.coherent_uv else "random permutation",
                    "normal_offsets": "smooth (decoder-like)" if args.smooth_normals else "white noise (SURVEY 8d)"}, **par)
     res["config"] = config
@@ -1125,6 +1140,8 @@ def secondary_workloads(args, D):
                 -> backward -> Adam, >= 60 steps so that the loss is past Adam's first overshoot
       mvp       BASELINE config 5 (4096 primitives, 2048x1334)
       urhand    BASELINE config 4 (1024^2 texels x 32 lights, incl. the 32 shadow depth renders)
+      env_distinct_maps     the headline step with a DIFFERENT env-map pyramid per view (rounds 1-4's headline workload;
+                harder than config 2, whose single pyramid stays cache-resident)
       env_coherent_smooth   the headline step on a UV-coherent slab with decoder-like smooth normal offsets: the realistic
                 case for the env-map gathers of shade_fwd (the default layout is the synthetic worst case)"""
     import copy
@@ -1144,6 +1161,10 @@ def secondary_workloads(args, D):
     a2.coherent_uv = a2.smooth_normals = True
     guarded("env_coherent_smooth", lambda: _brief(run_rgca(a2, D, CONFIG2_VIEWS, "weak", "rgca_config2_coherent_smooth",
                                                            False)))
+    a4 = copy.copy(args)
+    a4.env_per_view = True
+    guarded("env_distinct_maps", lambda: _brief(run_rgca(a4, D, CONFIG2_VIEWS, "weak", "rgca_8_distinct_envmaps", False,
+                                                         extras=False)))
     guarded("mvp", lambda: _brief(mvp_main(args, emit_line=False)))
     guarded("urhand", lambda: _brief(urhand_main(args, emit_line=False)))
     a3 = copy.copy(args)

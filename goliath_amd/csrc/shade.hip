@@ -181,6 +181,7 @@ __device__ __forceinline__ EnvSample env_lookup(const gol_shade_in& in, int b, f
   }
   const int h0 = in.mip_h[d1], w0 = in.mip_w[d1];
   const bool packed = in.mips_packed[0] != nullptr;
+  if (in.mips_shared) b = 0;  // one pyramid for all views: the map stays cache-resident, only lightrot is per view
   const Bilinear s0 = packed ? bilinear_border<true>(in.mips_packed[d1] + (size_t)b * 16 * h0 * w0, h0, w0, u, v)
                              : bilinear_border<false>(in.mips[d1] + (size_t)b * 3 * h0 * w0, h0, w0, u, v);
   if (q > 1) {
@@ -257,7 +258,9 @@ __device__ __forceinline__ void spec_forward(const gol_shade_in& in, int b, cons
     const float ry = R[3] * s.ref[0] + R[4] * s.ref[1] + R[5] * s.ref[2];
     const float rz = R[6] * s.ref[0] + R[7] * s.ref[1] + R[8] * s.ref[2];
     const float u = atan2f(rx, rz) * (1.f / kPi);
-    const float v = 2.f * acosf(fminf(1.f, fmaxf(-1.f, ry))) * (1.f / kPi) - 1.f;
+    // polar angle = acos(r_y) (envmap.py:289) evaluated as atan2(sqrt(r_x^2 + r_z^2), r_y): the same angle for a unit vector,
+    // without acos' loss of the rounding of r_y near the poles (acos'(y) = -1 / sqrt(1 - y^2) amplifies it without bound)
+    const float v = 2.f * atan2f(sqrtf(rx * rx + rz * rz), ry) * (1.f / kPi) - 1.f;
     const EnvSample e = env_lookup(in, b, u, v, 5.f * s.sigma);
     if (keep) *keep = e;
 #pragma unroll
@@ -570,8 +573,6 @@ __global__ __launch_bounds__(256) void shade_bwd_kernel(const gol_shade_in in, c
         const float rx = R[0] * s.ref[0] + R[1] * s.ref[1] + R[2] * s.ref[2];
         const float ry = R[3] * s.ref[0] + R[4] * s.ref[1] + R[5] * s.ref[2];
         const float rz = R[6] * s.ref[0] + R[7] * s.ref[1] + R[8] * s.ref[2];
-        const float ryc = fminf(1.f, fmaxf(-1.f, ry));
-        (void)ryc;
         float g_u = 0.f, g_v = 0.f;
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
@@ -583,7 +584,9 @@ __global__ __launch_bounds__(256) void shade_bwd_kernel(const gol_shade_in in, c
         const float iden = den > 0.f ? 1.f / den : 0.f;
         const float grx = g_u * (1.f / kPi) * rz * iden;
         const float grz = -g_u * (1.f / kPi) * rx * iden;
-        const float gry = (ry > -1.f && ry < 1.f) ? g_v * (-2.f / kPi) * rsqrtf(1.f - ry * ry) : 0.f;
+        // d acos(r_y) / d r_y = -1 / sqrt(1 - r_y^2), with 1 - r_y^2 formed as r_x^2 + r_z^2: the difference cancels to a few
+        // ulps of 1 near the poles, the sum keeps the relative precision of the two small components
+        const float gry = (den > 0.f && ry > -1.f && ry < 1.f) ? g_v * (-2.f / kPi) * rsqrtf(den) : 0.f;
 #pragma unroll
         for (int k = 0; k < 3; ++k) g_ref[k] = R[k] * grx + R[3 + k] * gry + R[6 + k] * grz;
       } else {
@@ -757,6 +760,7 @@ int check_in(const gol_shade_in* in) {
   GOL_REQUIRE(in->n_mips >= 0 && in->n_mips <= GOL_MAX_MIPS, "n_mips out of range");
   if (in->n_mips > 0) {
     GOL_REQUIRE(in->lightrot != nullptr, "env map needs lightrot");
+    GOL_REQUIRE(in->mips_shared == 0 || in->mips_shared == 1, "mips_shared must be 0 or 1");
     for (int i = 0; i < in->n_mips; ++i)
       GOL_REQUIRE(in->mips[i] && in->mip_h[i] > 0 && in->mip_w[i] > 0, "bad mip level");
     for (int i = 0; i < in->n_mips; ++i)

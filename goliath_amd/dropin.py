@@ -3,6 +3,7 @@
     import goliath_amd.dropin as dropin
     dropin.install()              # before importing ca_code.* / extensions.*
     dropin.patch_rgca()           # optional: fused shading tail + batched, sync-free render
+    dropin.patch_light_decorator()  # optional: the env-relight driver hands over ONE shared pyramid (config 2)
 
 `install()` registers the module names the reference imports for its native code:
     gsplat            project_gaussians, rasterize_gaussians   (ca_code/utils/render_gsplat.py:10-11)
@@ -46,6 +47,24 @@ def patch_rgca(rgca_module=None):
     rgca_module.AutoEncoder.forward = fused.autoencoder_forward
     rgca_module.PrimDecoder.forward = fused.prim_decoder_forward
     return rgca_module
+
+
+def _shared_mipmap(self, bsize, device, scale=1.0):
+    """EnvSpinDecorator.mipmap (ca_code/utils/light_decorator.py:96-100) without the B materialised copies: the reference
+    expands each registered level over the batch and then multiplies by `scale`, which writes B identical scaled maps (at the
+    run_vis_relight size 8 x 10.5 MB).  Here the ONE map is scaled and the batch axis is a stride-0 view: same shapes and
+    values for every reader, and goliath_amd.shade hands the kernel a single pyramid (gol_shade_in.mips_shared) that stays
+    cache-resident while the views differ only in `lightrot`."""
+    return [(getattr(self, f"mipmap_{i}").to(device) * scale).expand(bsize, -1, -1, -1) for i in range(self.miplevel)]
+
+
+def patch_light_decorator(decorator_module=None):
+    """BASELINE config 2's relight driver as a drop-in: `EnvSpinDecorator.mipmap` returns stride-0 batch views of the one
+    prefiltered pyramid (see _shared_mipmap); nothing else of the decorator changes.  Returns the patched module."""
+    if decorator_module is None:
+        import ca_code.utils.light_decorator as decorator_module
+    decorator_module.EnvSpinDecorator.mipmap = _shared_mipmap
+    return decorator_module
 
 
 def patch_losses(registry_module=None):

@@ -28,7 +28,7 @@ class ShadeIn(ctypes.Structure):
                 ("n_mips", ctypes.c_int32), ("mips", _fp * MAX_MIPS), ("mip_h", ctypes.c_int32 * MAX_MIPS),
                 ("mip_w", ctypes.c_int32 * MAX_MIPS), ("lightrot", _fp), ("mips_packed", _fp * MAX_MIPS),
                 ("primscale_min", ctypes.c_float),
-                ("primscale_max", ctypes.c_float)]
+                ("primscale_max", ctypes.c_float), ("mips_shared", ctypes.c_int32)]
 
 
 OUT_FIELDS = [("color", 3), ("opacity", 1), ("primpos", 3), ("primqvec", 4), ("primscale", 3),
@@ -103,6 +103,7 @@ def pack_envmap(mips, refresh=False):
 def _make_in(f_vnocond, f_vcond, postex, tn, albedo, light_sh, light_sh_rand, campos, light_intensity,
              light_pos, n_lights, mips, lightrot, ncol, nmono, packed=None):
     B, C = f_vnocond.shape[:2]
+    shared = bool(mips) and B > 1 and all(m.shape[0] == 1 for m in mips)
     N = f_vnocond[0, 0].numel()
     s = ShadeIn()
     s.B, s.N, s.n_color_coef, s.n_mono_coef = B, N, ncol, nmono
@@ -116,6 +117,9 @@ def _make_in(f_vnocond, f_vcond, postex, tn, albedo, light_sh, light_sh_rand, ca
             if packed:
                 s.mips_packed[i] = _p(packed[i])
         s.lightrot = _p(lightrot)
+        s.mips_shared = int(shared)
+        if not shared and any(m.shape[0] != B for m in mips):
+            raise ValueError(f"env-map levels must be [B={B},3,h,w] (one pyramid per view) or [1,3,h,w] (one for all views)")
     else:
         s.n_mips = 0
         s.L = light_intensity.shape[1]
@@ -137,7 +141,8 @@ class _Shade(torch.autograd.Function):
         outs = {n: torch.empty(B, N, k, device=dev) for n, k in OUT_FIELDS
                 if (rand or n != "color_rand") and (n != "env_saved" or (mips and need_grad))}
         with _lib.device_guard(dev):
-            packed = pack_envmap(mips) if mips else None
+            # GOLIATH_ENVMAP_RECORDS=0: gather from the planar [.,3,h,w] levels as given (no footprint records)
+            packed = pack_envmap(mips) if mips and os.environ.get("GOLIATH_ENVMAP_RECORDS", "1") != "0" else None
         sin = _make_in(f_vnocond, f_vcond, postex, tn, albedo, light_sh, light_sh_rand, campos,
                        light_intensity, light_pos, n_lights, list(mips), lightrot, ncol, nmono, packed)
         sout = ShadeOut()
@@ -244,23 +249,32 @@ def shading_tail_coefs(f_vnocond, f_vcond, postex, tn, albedo, headrel_light_sh,
     N = f_vnocond[0, 0].numel()
     mips = []
     if preconv_envmap is not None:
-        mips = [c(m) for m in (preconv_envmap if isinstance(preconv_envmap, (list, tuple)) else [preconv_envmap])]
+        mips = list(preconv_envmap) if isinstance(preconv_envmap, (list, tuple)) else [preconv_envmap]
         if len(mips) > MAX_MIPS:
             raise ValueError("too many mip levels")
+        # ONE pyramid for the whole batch -- [1,3,h,w] levels, or the stride-0 batch views `expand(B, ...)` gives (what
+        # dropin.patch_light_decorator makes of EnvSpinDecorator.mipmap, light_decorator.py:96-100): the kernel reads the
+        # single map for every view (gol_shade_in.mips_shared) instead of B materialised copies
+        if all(m.dim() == 4 and (m.shape[0] == 1 or m.stride(0) == 0) for m in mips):
+            mips = [m[:1] for m in mips]
+        mips = [c(m) for m in mips]
         lightrot = c(lightrot)
         li = lp = nl = None
     else:
         li, lp = c(light_intensity.expand(-1, -1, 3)), c(headrel_light_pos)
         nl = n_lights.to(torch.int32).contiguous()
         lightrot = None
+    if views is not None:   # before any launch: the kernel indexes the cameras by view
+        if views.K.shape[0] != B or views.Rt.shape[0] != B:
+            raise ValueError(f"the ViewSet holds {views.K.shape[0]} cameras, the batch {B} views")
+        if views.height <= 0 or views.width <= 0:
+            raise ValueError(f"bad image size {views.height} x {views.width}")
     outs = _Shade.apply(c(f_vnocond), c(f_vcond), c(postex), c(tn), c(albedo).reshape(N, 3),
                         c(headrel_light_sh), c(light_sh_rand), c(headrel_campos), li, lp, nl, lightrot,
                         ncol, nmono, views, *mips)
     names = [n for n in GRAD_FIELDS if light_sh_rand is not None or n != "color_rand"]
     preds = dict(zip(names, outs))
     if views is not None:
-        if views.K.shape[0] != B:
-            raise ValueError(f"the ViewSet holds {views.K.shape[0]} cameras, the batch {B} views")
         preds["projected"] = _views.Projected(views, outs[len(names)], outs[len(names) + 1], preds)
     preds["sigma"] = preds["sigma"][..., 0]  # [B,N] like rgca.py:526
     return preds

@@ -270,6 +270,11 @@ typedef struct {
    * aligned 64-byte fetch); all levels or none (NULL) */
   const float* mips_packed[GOL_MAX_MIPS];
   float primscale_min, primscale_max; /* rgca.py:47 (0.1, 20) */
+  /* 1: ONE pyramid lights all B views -- every level is [1,3,h,w] (packed: [1,h,w,16]) and only `lightrot` differs per
+   * view.  This is what the reference's relight driver feeds: EnvSpinDecorator.mipmap() expands one registered pyramid over
+   * the batch (ca_code/utils/light_decorator.py:96-100) and rotates the lookup, not the map (:112-118, rgca.py:548-550).
+   * 0: one pyramid per view, levels [B,...] as above. */
+  int32_t mips_shared;
 } gol_shade_in;
 
 typedef struct {  /* every field [B,N,k] row-major like the reference's preds (rgca.py:574-588) */

@@ -35,6 +35,8 @@ def mip_sample(mips, uv, level):
     lerp between the two levels around `level` (selection under no_grad).  mips: list of
     [B,3,h,w]; uv [B,N,2]; level [B,N] -> [B,N,3]."""
     q = len(mips)
+    # one pyramid for the batch: expanded over it as the reference's driver does (light_decorator.py:96-100)
+    mips = [m.expand(uv.shape[0], -1, -1, -1) if m.shape[0] == 1 else m for m in mips]
     with torch.no_grad():
         lam = level.clamp(min=0, max=q - 1 - 1e-6)
         d1 = lam.floor().long()

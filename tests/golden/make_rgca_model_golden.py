@@ -1,0 +1,278 @@
+"""Generates tests/golden/rgca_model_golden.npz by running the REFERENCE's own model code on the CPU:
+    ca_code.models.rgca.AutoEncoder.forward / .render        (rgca.py:112-151, 153-253)
+    ca_code.models.rgca.PrimDecoder.forward                  (rgca.py:466-620)
+    ca_code.utils.render_gsplat.render                       (render_gsplat.py:13-108)
+    ca_code.utils.light_decorator.EnvSpinDecorator           (__init__ incl. the SG-prefiltered pyramid, mipmap(), forward: :18-164)
+    ca_code.nn.color_cal.CalV5, ca_code.nn.dof_cal.LearnableBlur, ca_code.nn.layers (the weight-normalised decoder layers)
+as unbound methods / real classes on the seeded stand-in of tests/rgca_shaped.py (same attribute layout, an 8 -> 64 decoder
+ladder, 4096 Gaussians, 256 x 208 images).  What the reference obtains from third-party / CUDA code is served by the CPU oracles:
+    gsplat.project_gaussians / rasterize_gaussians  -> oracle/gsplat_module.py over oracle/gsplat_oracle.c (PARITY UNPINNED inside:
+                                                       gsplat's sources are absent; the autograd wiring follows the call sites)
+    sgutilslib.evaluate_gaussian_fwd / _bwd         -> the reference's OWN sg.cu compiled for the host (oracle/_ref/libref.so)
+    cv2.imread / cv2.resize                         -> a synthetic log-normal HDR of 64 x 128 texels (no image file, no OpenCV here)
+Cases:
+    train_point   training mode, point lights (n_lights mixed), is_fully_lit_frame mixed, calibration + learnable blur on;
+                  outputs, and the gradients of a fixed random scalar w.r.t. embs, geom and a set of parameters
+    eval_env      eval, the batch EnvSpinDecorator.forward hands to the model (preconv_envmap from mipmap(), lightrot, the 512
+                  env lights), WITHOUT `envbg` (the differentiable env path): outputs + gradients
+    vis_env       what run_vis_relight.py runs (run_vis_relight.py:110-122): decorated model, no_grad, `envbg` present -> the
+                  env background composite and the diffuse / specular breakdown renders (rgca.py:232-245); B = 1
+Run in the build container (needs /root/reference):   python tests/golden/make_rgca_model_golden.py
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+for p in (ROOT, os.path.join(ROOT, "tests"), HERE):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+import ref_stubs  # noqa: E402
+from oracle import cref, gsplat_module, refso  # noqa: E402
+
+_sg = refso if refso.available() else cref
+
+
+class _SgLib:
+    @staticmethod
+    def evaluate_gaussian_fwd(lobe_dirs, lobe_sigmas, light_values, light_pts, prim_pts, n_lights, integral, w_type):
+        integral.copy_(_sg.evaluate_gaussian_fwd(lobe_dirs, lobe_sigmas, light_values, light_pts, prim_pts, n_lights, w_type))
+        return []
+
+    @staticmethod
+    def evaluate_gaussian_bwd(lobe_dirs, lobe_sigmas, light_values, light_pts, prim_pts, n_lights, grad_integral, grad_dirs,
+                              grad_sigmas, grad_light_values, w_type):
+        gd, gs, _ = _sg.evaluate_gaussian_bwd(lobe_dirs, lobe_sigmas, light_values, light_pts, prim_pts, n_lights,
+                                              grad_integral, w_type)
+        grad_dirs.copy_(gd)
+        grad_sigmas.copy_(gs)
+        return []
+
+
+ref_stubs.install(sgutilslib=_SgLib)
+sys.modules["gsplat"] = gsplat_module.as_module()      # before ca_code.utils.render_gsplat binds the two names
+import ca_code.models.rgca as R  # noqa: E402
+import ca_code.nn.layers as la  # noqa: E402
+import ca_code.utils.light_decorator as LD  # noqa: E402
+import ca_code.utils.sh as ref_sh  # noqa: E402
+from ca_code.nn.color_cal import CalV5  # noqa: E402
+from ca_code.nn.dof_cal import LearnableBlur  # noqa: E402
+from ca_code.utils import envmap as ref_envmap  # noqa: E402
+
+import rgca_shaped as S  # noqa: E402
+
+SEED = 0
+
+
+def reference_model(embs, geom, cal=True, blur=True):
+    """The stand-in with every sub-module that has a reference class replaced by that class, loaded with the stand-in's seeded
+    parameters; the reference's methods bound on it."""
+    m = S.ShapedAutoEncoder(embs, geom, SEED, cal=cal, blur=blur)
+    dec = m.decoder
+    sd = dec.state_dict()
+    lrelu = lambda: torch.nn.LeakyReLU(0.2, inplace=True)
+    dec.viewmod = torch.nn.Sequential(*la.make_linear(3, 8, "wn", lrelu()))
+    dec.encmod = torch.nn.Sequential(*la.make_linear(256, 256 * 8 * 8, "wn", lrelu()))
+
+    def stack(n_in, n_out):
+        layers, c, s = [], n_in, 8
+        for co in S.HIDDEN:
+            s *= 2
+            layers += la.make_conv_trans(c, co, 4, 2, 1, "wn", lrelu(), ub=(s, s))
+            c = co
+        return torch.nn.Sequential(*layers, *la.make_conv_trans(c, n_out, 4, 2, 1, "wn", ub=(2 * s, 2 * s)))
+
+    dec.vnocond_mod, dec.vcond_mod = stack(256, dec.n_diff_coeffs + 12), stack(256 + 8, 4)
+    missing = dec.load_state_dict(sd, strict=True)
+    assert not missing.missing_keys and not missing.unexpected_keys
+    dec.forward = types.MethodType(R.PrimDecoder.forward, dec)
+    if cal:
+        shaped = m.cal
+        m.cal = CalV5(cameras=list(S.CAMERAS), identity_camera=S.IDENTITY)
+        assert m.cal.identity_idx == shaped.identity_idx and list(m.cal.grey_idxs) == list(shaped.grey_idxs)
+        assert (m.cal.gs_lrscale, m.cal.col_lrscale) == (shaped.gs_lrscale, shaped.col_lrscale)
+        with torch.no_grad():
+            m.cal.holder.params.copy_(shaped.params)
+    if blur:
+        shaped = m.learn_blur
+        m.learn_blur = LearnableBlur(list(S.CAMERAS))
+        with torch.no_grad():
+            m.learn_blur.weights_raw.copy_(shaped.weights_raw)
+    m.render = types.MethodType(R.AutoEncoder.render, m)
+    m.forward = types.MethodType(R.AutoEncoder.forward, m)
+    return m
+
+
+def grad_of(m, name):
+    if name == "cal.params":
+        return m.cal.holder.params.grad
+    obj = m
+    for part in name.split("."):
+        obj = getattr(obj, part) if not part.isdigit() else obj[int(part)]
+    return obj.grad
+
+
+class Recorder:
+    """Records every call of the reference's sh.dir2sh_torch and torch.rand made during a forward: the GPU test replays them
+    (the SH basis is reference Python that is absent on the GPU box; the random training light is drawn on the device there)."""
+
+    def __init__(self, out, tag):
+        self.out, self.tag, self.n_sh, self.n_rand = out, tag, 0, 0
+
+    def __enter__(self):
+        self._sh, self._rand = ref_sh.dir2sh_torch, torch.rand
+
+        def dir2sh(n, d):
+            r = self._sh(n, d)
+            self.out[f"{self.tag}/sh{self.n_sh}/dirs"] = d.detach().numpy().copy()
+            self.out[f"{self.tag}/sh{self.n_sh}/coeffs"] = r.detach().numpy().copy()
+            self.n_sh += 1
+            return r
+
+        def rand(*a, **k):
+            r = self._rand(*a, **k)
+            self.out[f"{self.tag}/rand{self.n_rand}"] = r.numpy().copy()
+            self.n_rand += 1
+            return r
+
+        ref_sh.dir2sh_torch, torch.rand = dir2sh, rand
+        return self
+
+    def __exit__(self, *exc):
+        ref_sh.dir2sh_torch, torch.rand = self._sh, self._rand
+
+
+def store(out, tag, preds, keys=None):
+    for k, v in preds.items():
+        if torch.is_tensor(v) and (keys is None or k in keys):
+            out[f"{tag}/out/{k}"] = v.detach().numpy().astype(np.float32)
+
+
+def backprop(out, tag, m, preds, embs, geom):
+    wf = S.loss_weights(SEED)
+    loss = sum((preds[k] * wf[k](preds[k])).sum() for k in ("rgb", "depth", "primscale_preclip", "spec_nml", "color_rand")
+               if k in preds)
+    loss.backward()
+    out[f"{tag}/loss"] = np.float64(loss.item())
+    out[f"{tag}/grad/embs"], out[f"{tag}/grad/geom"] = embs.grad.numpy().copy(), geom.grad.numpy().copy()
+    for name in S.GRAD_PARAMS:
+        if name.split(".")[0] in ("cal", "learn_blur") and not hasattr(m, name.split(".")[0]):
+            continue
+        g = grad_of(m, name)
+        if g is not None:
+            out[f"{tag}/grad/{name}"] = g.numpy().copy()
+
+
+def synthetic_hdr():
+    g = torch.Generator().manual_seed(SEED + 21)
+    # log-normal radiance with a few bright blobs: values above 1 exist (the specular clamp(max=1) of rgca.py:556 is active)
+    img = torch.exp(0.8 * torch.randn(64, 128, 3, generator=g)) * 0.25
+    yy, xx = torch.meshgrid(torch.arange(64.0), torch.arange(128.0), indexing="ij")
+    for cy, cx, amp in ((20.0, 30.0, 80.0), (40.0, 90.0, 40.0)):
+        img += amp * torch.exp(-((yy - cy) ** 2 + (xx - cx) ** 2) / 30.0)[..., None]
+    return img.numpy().astype(np.float32)
+
+
+def main():
+    out = {}
+    # ------------------------------------------------------------------------------------------ train_point
+    B = 2
+    embs, geom = S.leaves(B, SEED)
+    m = reference_model(embs, geom).train()
+    batch = S.batch_inputs(B, SEED)
+    torch.manual_seed(99)
+    with Recorder(out, "train_point"):
+        preds = m.forward(**batch)
+    store(out, "train_point", preds)
+    backprop(out, "train_point", m, preds, embs, geom)
+    print("train_point: alpha mean", float(preds["alpha"].mean()), "max", float(preds["alpha"].max()), "rgb mean",
+          float(preds["rgb"].mean()), "keys", sorted(preds))
+
+    # ------------------------------------------------------------------------------------------ the env-map driver
+    cv2 = sys.modules["cv2"]
+    hdr = synthetic_hdr()
+    cv2.imread = lambda path, flag=None: hdr[:, :, ::-1]           # (BGR on disk; _set_lightmap flips it back)
+    cv2.resize = lambda img, size, interpolation=None: img         # the synthetic map already has the size we want
+    cv2.INTER_AREA = 3
+    torch.Tensor.cuda = lambda self, *a, **k: self                 # _set_lightmap prefilters on "the GPU" (:76, :95)
+    torch.manual_seed(7)
+    embs, geom = S.leaves(B, SEED + 100)
+    m = reference_model(embs, geom)
+    m.eval()
+    m.learn_blur_enabled = m.cal_enabled = False                   # run_vis_relight.py:83-84
+    handed = {}
+
+    def model_call(**data):
+        handed.update(data)
+        return m.forward(**data)
+
+    deco = LD.EnvSpinDecorator(model_call, envmap_path="synthetic.hdr", ydown=True, env_scale=8.0)   # run_vis_relight.py:110-115
+    out["env/image"] = deco.image.numpy().copy()
+    for i in range(deco.miplevel):
+        out[f"env/mipmap_{i}"] = getattr(deco, f"mipmap_{i}").numpy().copy()
+    batch = S.batch_inputs(B, SEED + 100)
+    for k in ("light_intensity", "light_pos", "n_lights"):          # the decorator supplies them
+        batch.pop(k)
+
+    # eval_env: the decorator's batch without `envbg` -> the differentiable env path of AutoEncoder.forward
+    class NoBg(dict):
+        pass
+
+    def model_call_nobg(**data):
+        handed.update(data)
+        data = {k: v for k, v in data.items() if k != "envbg"}
+        return m.forward(**data)
+
+    deco.mod = model_call_nobg
+    with Recorder(out, "eval_env"):
+        preds = deco(**batch, index=[37, 120])
+    for k in ("light_intensity", "light_pos", "lightrot", "envbg", "n_lights"):
+        out[f"eval_env/in/{k}"] = handed[k].numpy().copy()
+    out["eval_env/in/preconv_scale"] = np.float32(float(handed["preconv_envmap"][0][0, 0, 0, 0] / deco.mipmap_0[0, 0, 0, 0]))
+    for i, lvl in enumerate(handed["preconv_envmap"]):
+        assert lvl.shape[0] == B and torch.equal(lvl[0], lvl[1])    # ONE pyramid expanded over the batch (:96-100)
+        out[f"eval_env/in/preconv_envmap_{i}"] = lvl[:1].numpy().copy()
+    store(out, "eval_env", preds)
+    backprop(out, "eval_env", m, preds, embs, geom)
+    print("eval_env: alpha mean", float(preds["alpha"].mean()), "spec max", float(preds["spec_color"].max()),
+          "spec clamp active on", int((preds["spec_color"] / preds["spec_vis"].clamp(min=1e-6) > 0.999).sum()), "values")
+
+    # vis_env: run_vis_relight's call (no_grad, envbg present), B = 1
+    embs1, geom1 = S.leaves(1, SEED + 200)
+    m = reference_model(embs1, geom1)
+    m.eval()
+    m.learn_blur_enabled = m.cal_enabled = False
+    deco.mod = model_call
+    batch = S.batch_inputs(1, SEED + 200)
+    for k in ("light_intensity", "light_pos", "n_lights"):
+        batch.pop(k)
+    handed.clear()
+    with torch.no_grad(), Recorder(out, "vis_env"):
+        preds = deco(**batch, index=[200])
+    for k in ("light_intensity", "light_pos", "lightrot", "envbg", "n_lights"):
+        out[f"vis_env/in/{k}"] = handed[k].numpy().copy()
+    for i, lvl in enumerate(handed["preconv_envmap"]):
+        out[f"vis_env/in/preconv_envmap_{i}"] = lvl[:1].numpy().copy()
+    store(out, "vis_env", preds, keys=("rgb", "alpha", "depth", "color", "headrel_light_sh", "spec_color", "diff_color"))
+    # compose_envmap (envmap.py:325-345) is an affine map of (render, alpha) whose coefficients depend on envbg, K, Rt only:
+    #   out = (1 - ma) * (render + (1 - alpha) * bg) + ma * mi.   Recorded through three probe calls of the reference function
+    # so that the GPU test (no ca_code there) can stand in for it.
+    K, Rt, envbg = batch["K"], batch["Rt"], handed["envbg"]
+    z3, z1 = torch.zeros(1, 3, S.H, S.W), torch.zeros(1, 1, S.H, S.W)
+    x00 = ref_envmap.compose_envmap(z3.clone(), z1.clone(), envbg, K, Rt)          # (1 - ma) * bg + ma * mi
+    x01 = ref_envmap.compose_envmap(z3.clone(), z1.clone() + 1.0, envbg, K, Rt)    # ma * mi
+    x11 = ref_envmap.compose_envmap(z3.clone() + 1.0, z1.clone() + 1.0, envbg, K, Rt)   # (1 - ma) + ma * mi
+    out["vis_env/compose/one_minus_ma"] = (x11 - x01).numpy().copy()
+    out["vis_env/compose/bg_term"] = (x00 - x01).numpy().copy()                    # (1 - ma) * bg
+    out["vis_env/compose/mirror_term"] = x01.numpy().copy()                        # ma * mi
+    path = os.path.join(HERE, "rgca_model_golden.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, os.path.getsize(path), "bytes;", len(out), "arrays")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,267 @@
+"""GPU: the model boundary north_star names -- `AutoEncoder.forward` / `AutoEncoder.render` / `PrimDecoder.forward`
+(ca_code/models/rgca.py:112-253, 466-620) and the env-relight driver's hand-over (ca_code/utils/light_decorator.py:96-164) --
+against a fixture produced by the REFERENCE's own code.
+
+tests/golden/rgca_model_golden.npz holds what the reference's methods return (and the gradients of a fixed random scalar)
+when run unbound on the seeded stand-in of tests/rgca_shaped.py on the CPU, with gsplat served by the C oracle and sgutilslib
+by the reference's sg.cu compiled for the host (tests/golden/make_rgca_model_golden.py).  Here the functions
+`goliath_amd.dropin.patch_rgca()` installs (tests/test_dropin_real_classes.py checks on the real classes that these are
+the ones) run on an identical stand-in on the GPU: head-relative transforms, fused decoder tail + shading tail with the
+projection fused in, ONE batched render, fused image tail -- every returned key and every recorded gradient is compared.
+
+Reference Python that the model code calls but that is absent on the GPU box is REPLAYED from the fixture, not restated:
+`sh.dir2sh_torch` (the recorded coefficients of the recorded directions), the device's `torch.rand` for the training-only
+random light (the recorded draw), and `compose_envmap` (the affine map it is, from three recorded probe calls).
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import pytest
+import torch
+
+import rgca_shaped as S
+from scenes import rel_l2
+
+pytestmark = pytest.mark.gpu
+GOLD_PATH = os.path.join(os.path.dirname(__file__), "golden", "rgca_model_golden.npz")
+
+# rel-L2 bars.  Per-Gaussian outputs of the shading tail are at rounding level (measured <= 1e-5); images carry the flip
+# pixels of two fp32 rasterizers (a Gaussian composited by one and cut at alpha < 1/255 by the other), gradients inherit
+# them -- the same effect tests/test_gpu_fullsize.py classifies Gaussian by Gaussian at config-2 size.
+BAR_PER_GAUSSIAN, BAR_IMAGE, BAR_GRAD = 5e-5, 1e-4, 1e-3
+
+
+def _gold():
+    return np.load(GOLD_PATH)
+
+
+def _t(a):
+    return torch.from_numpy(np.ascontiguousarray(a))
+
+
+class _Replay:
+    """Context: `ca_code.utils.sh.dir2sh_torch`, `ca_code.utils.envmap.compose_envmap` and `torch.rand` replayed from the
+    fixture for one case (`tag`)."""
+
+    def __init__(self, G, tag, compose=False):
+        self.G, self.tag = G, tag
+        self.sh = []
+        i = 0
+        while f"{tag}/sh{i}/dirs" in G:
+            self.sh.append((_t(G[f"{tag}/sh{i}/dirs"]), _t(G[f"{tag}/sh{i}/coeffs"])))
+            i += 1
+        self.rand = []
+        i = 0
+        while f"{tag}/rand{i}" in G:
+            self.rand.append(_t(G[f"{tag}/rand{i}"]))
+            i += 1
+        self.compose = None
+        if compose:
+            self.compose = tuple(_t(G[f"{tag}/compose/{k}"]).cuda() for k in ("one_minus_ma", "bg_term", "mirror_term"))
+        self.sh_calls = self.rand_calls = 0
+
+    def dir2sh_torch(self, n, d):
+        for dirs, coeffs in self.sh:
+            if tuple(dirs.shape) == tuple(d.shape) and float((dirs - d.detach().cpu()).abs().max()) < 2e-5:
+                assert coeffs.shape[-1] == (n + 1) ** 2
+                self.sh_calls += 1
+                return coeffs.to(d.device)
+        raise AssertionError(f"dir2sh_torch called with directions the reference never passed (shape {tuple(d.shape)})")
+
+    def compose_envmap(self, render, alpha, envbg, K, Rt):
+        one_minus_ma, bg_term, mirror_term = self.compose
+        return one_minus_ma * render + (1.0 - alpha) * bg_term + mirror_term
+
+    def __enter__(self):
+        self._saved = {k: sys.modules.get(k) for k in ("ca_code", "ca_code.utils", "ca_code.utils.sh", "ca_code.utils.envmap")}
+        for name in ("ca_code", "ca_code.utils"):
+            sys.modules[name] = types.ModuleType(name)
+        sh = types.ModuleType("ca_code.utils.sh")
+        sh.dir2sh_torch = self.dir2sh_torch
+        env = types.ModuleType("ca_code.utils.envmap")
+        env.compose_envmap = self.compose_envmap
+        sys.modules["ca_code.utils.sh"], sys.modules["ca_code.utils.envmap"] = sh, env
+        sys.modules["ca_code.utils"].sh, sys.modules["ca_code.utils"].envmap = sh, env
+        sys.modules["ca_code"].utils = sys.modules["ca_code.utils"]
+        self._rand = torch.rand
+        queue = list(self.rand)
+
+        def rand(*a, **k):
+            if not queue:
+                return self._rand(*a, **k)
+            r = queue.pop(0)
+            shape = tuple(a[0]) if len(a) == 1 and isinstance(a[0], (tuple, list, torch.Size)) else tuple(a)
+            assert tuple(r.shape) == shape, (r.shape, shape)
+            self.rand_calls += 1
+            return r.to(device=k.get("device", "cpu"), dtype=k.get("dtype", torch.float32))
+
+        torch.rand = rand
+        return self
+
+    def __exit__(self, *exc):
+        torch.rand = self._rand
+        for k, v in self._saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
+
+
+def _model(embs, geom, cal=True, blur=True):
+    """The stand-in on the GPU with what dropin.patch_rgca() installs on the reference classes bound to it."""
+    from goliath_amd import rgca
+
+    m = S.ShapedAutoEncoder(embs, geom, 0, cal=cal, blur=blur).cuda()
+    m.decoder.forward = types.MethodType(rgca.prim_decoder_forward, m.decoder)
+    m.render = types.MethodType(rgca.autoencoder_render, m)
+    m.forward = types.MethodType(rgca.autoencoder_forward, m)
+    return m
+
+
+def _cuda(d):
+    return {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in d.items()}
+
+
+def _param(m, name):
+    obj = m
+    for part in name.split("."):
+        obj = getattr(obj, part) if not part.isdigit() else obj[int(part)]
+    return obj
+
+
+def _compare_outputs(G, tag, preds, report, keys=None):
+    want_keys = [k.split("/out/")[1] for k in G.files if k.startswith(f"{tag}/out/")]
+    assert want_keys, tag
+    for k in want_keys:
+        if keys is not None and k not in keys:
+            continue
+        assert k in preds, f"{tag}: the reference returns `{k}`, the drop-in does not"
+        want = _t(G[f"{tag}/out/{k}"])
+        got = preds[k].detach().float().cpu()
+        assert tuple(got.shape) == tuple(want.shape), (tag, k, tuple(got.shape), tuple(want.shape))
+        report[f"out/{k}"] = rel_l2(got, want)
+    extra = set(k for k, v in preds.items() if torch.is_tensor(v)) - set(want_keys)
+    assert not extra or keys is not None, f"{tag}: keys the reference does not return: {sorted(extra)}"
+
+
+def _backprop(preds):
+    wf = S.loss_weights(0)   # the generator's cotangents, drawn in the same order on the CPU
+    loss = 0.0
+    for k in ("rgb", "depth", "primscale_preclip", "spec_nml", "color_rand"):
+        if k in preds:
+            loss = loss + (preds[k] * wf[k](preds[k]).to(preds[k].device)).sum()
+    loss.backward()
+    return float(loss)
+
+
+def _compare_grads(G, tag, m, embs, geom, report):
+    report["grad/embs"] = rel_l2(embs.grad, _t(G[f"{tag}/grad/embs"]))
+    report["grad/geom"] = rel_l2(geom.grad, _t(G[f"{tag}/grad/geom"]))
+    for name in S.GRAD_PARAMS:
+        key = f"{tag}/grad/{name}"
+        if key not in G.files:
+            continue
+        g = _param(m, name).grad
+        assert g is not None, name
+        report[f"grad/{name}"] = rel_l2(g, _t(G[key]))
+
+
+def _judge(tag, report):
+    print(f"\nRGCA_MODEL_GOLDEN {tag} " + " ".join(f"{k}={v:.2e}" for k, v in sorted(report.items())))
+    out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    if os.path.isdir(out_dir):
+        import json
+
+        path = os.path.join(out_dir, "rgca_model_parity.json")
+        data = json.load(open(path)) if os.path.exists(path) else {}
+        data[tag] = report
+        json.dump(data, open(path, "w"), indent=1)
+    for k, v in report.items():
+        assert v == v, (tag, k, "NaN")
+        if k.startswith("grad/"):
+            bar = BAR_GRAD
+        elif k in ("out/rgb", "out/alpha", "out/depth"):
+            bar = BAR_IMAGE
+        else:
+            bar = BAR_PER_GAUSSIAN
+        assert v < bar, (tag, k, v, bar)
+
+
+def test_train_point_lights_every_key_and_gradient():
+    """Training mode, point lights (n_lights 3 and 2), is_fully_lit_frame mixed, CalV5 + background + LearnableBlur on,
+    the training-only random light (color_rand, cos_weight)."""
+    G = _gold()
+    embs, geom = (t.detach().cuda().requires_grad_(True) for t in S.leaves(2, 0))
+    m = _model(embs, geom).train()
+    batch = _cuda(S.batch_inputs(2, 0))
+    with _Replay(G, "train_point") as rp:
+        preds = m.forward(**batch)
+        assert rp.sh_calls == 2 and rp.rand_calls == 1
+    report = {}
+    _compare_outputs(G, "train_point", preds, report)
+    assert not preds["alpha"].requires_grad and preds["depth"].requires_grad       # rgca.py:137, 144-145
+    _backprop(preds)
+    _compare_grads(G, "train_point", m, embs, geom, report)
+    _judge("train_point", report)
+
+
+def _env_batch(G, tag, B, seed, with_envbg):
+    batch = S.batch_inputs(B, seed)
+    for k in ("light_intensity", "light_pos", "n_lights"):
+        batch.pop(k)
+    for k in ("light_intensity", "light_pos", "lightrot", "n_lights"):
+        batch[k] = _t(G[f"{tag}/in/{k}"])
+    if with_envbg:
+        batch["envbg"] = _t(G[f"{tag}/in/envbg"])
+    # what dropin.patch_light_decorator makes EnvSpinDecorator.mipmap return: stride-0 batch views of ONE scaled pyramid
+    batch = _cuda(batch)
+    batch["preconv_envmap"] = [_t(G[f"{tag}/in/preconv_envmap_{i}"]).cuda().expand(B, -1, -1, -1) for i in range(4)]
+    # the rest of what EnvSpinDecorator.forward puts into the call (light_decorator.py:151-162); swallowed by **kwargs
+    batch.update(sigma_step=0.2, light_type="envmap", is_fullylit_frame=torch.zeros(1).cuda(), index=[0] * B)
+    return batch
+
+
+def test_eval_env_relight_driver_inputs_every_key_and_gradient():
+    """Eval, the batch EnvSpinDecorator.forward hands over (its own mipmap() pyramid x scale, lightrot, the 512 env lights for
+    the SH diffuse term), calibration / blur off as run_vis_relight.py:83-84 sets them; the shared pyramid reaches the kernel
+    as ONE map (gol_shade_in.mips_shared)."""
+    from goliath_amd import shade
+
+    G = _gold()
+    embs, geom = (t.detach().cuda().requires_grad_(True) for t in S.leaves(2, 100))
+    m = _model(embs, geom).eval()
+    m.learn_blur_enabled = m.cal_enabled = False
+    batch = _env_batch(G, "eval_env", 2, 100, with_envbg=False)
+    seen = []
+    make_in = shade._make_in
+    shade._make_in = lambda *a, **k: (lambda s: (seen.append(int(s.mips_shared)), s)[1])(make_in(*a, **k))
+    try:
+        with _Replay(G, "eval_env"):
+            preds = m.forward(**batch)
+            report = {}
+            _compare_outputs(G, "eval_env", preds, report)
+            _backprop(preds)
+    finally:
+        shade._make_in = make_in
+    assert seen and all(seen), "the expanded pyramid was not handed to the kernel as one shared map"
+    _compare_grads(G, "eval_env", m, embs, geom, report)
+    _judge("eval_env", report)
+
+
+def test_vis_env_run_vis_relight_call():
+    """run_vis_relight.py:110-122: no_grad, `envbg` present -> env background composite + diffuse / specular breakdown renders
+    concatenated along the width (rgca.py:232-245)."""
+    G = _gold()
+    embs, geom = (t.detach().cuda() for t in S.leaves(1, 200))
+    m = _model(embs, geom).eval()
+    m.learn_blur_enabled = m.cal_enabled = False
+    batch = _env_batch(G, "vis_env", 1, 200, with_envbg=True)
+    with torch.no_grad(), _Replay(G, "vis_env", compose=True):
+        preds = m.forward(**batch)
+    report = {}
+    _compare_outputs(G, "vis_env", preds, report, keys=("rgb", "alpha", "depth", "color", "headrel_light_sh", "spec_color",
+                                                       "diff_color"))
+    assert preds["rgb"].shape[-1] == 3 * S.W
+    _judge("vis_env", report)
