@@ -181,7 +181,7 @@ __device__ __forceinline__ EnvSample env_lookup(const gol_shade_in& in, int b, f
   }
   const int h0 = in.mip_h[d1], w0 = in.mip_w[d1];
   const bool packed = in.mips_packed[0] != nullptr;
-  if (in.mips_shared) b = 0;  // one pyramid for all views: the map stays cache-resident, only lightrot is per view
+  if (in.mips_shared) b = 0;  // one pyramid for all views; only lightrot is per view
   const Bilinear s0 = packed ? bilinear_border<true>(in.mips_packed[d1] + (size_t)b * 16 * h0 * w0, h0, w0, u, v)
                              : bilinear_border<false>(in.mips[d1] + (size_t)b * 3 * h0 * w0, h0, w0, u, v);
   if (q > 1) {

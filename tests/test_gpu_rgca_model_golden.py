@@ -27,10 +27,17 @@ from scenes import rel_l2
 pytestmark = pytest.mark.gpu
 GOLD_PATH = os.path.join(os.path.dirname(__file__), "golden", "rgca_model_golden.npz")
 
-# rel-L2 bars.  Per-Gaussian outputs of the shading tail are at rounding level (measured <= 1e-5); images carry the flip
-# pixels of two fp32 rasterizers (a Gaussian composited by one and cut at alpha < 1/255 by the other), gradients inherit
-# them -- the same effect tests/test_gpu_fullsize.py classifies Gaussian by Gaussian at config-2 size.
-BAR_PER_GAUSSIAN, BAR_IMAGE, BAR_GRAD = 5e-5, 1e-4, 1e-3
+# rel-L2 bars (north_star: 1e-4).  Measured (profiles/r05_rgca_model_parity.json): per-Gaussian outputs <= 9.9e-6 (SG specular
+# of train_point; everything else <= 1.2e-6), images <= 1.2e-5, every gradient <= 7.7e-5.
+# The fixture is built so that the comparison measures arithmetic, not which side of a discontinuity a rounding lands on
+# (tests/golden/make_rgca_model_golden.py; each was found by bisecting a first, failing version of this test):
+#   * no two Gaussians sharing a tile within 32 ulps in depth (their compositing order hinged on the last bit of
+#     Rt @ head_pose: one swapped pair = 7e-4 on rgb, 4e-4 on every gradient);
+#   * no LeakyReLU pre-activation of the decoder within 4e-6 of zero (one of 32768 at 4e-7 = 1.6e-3 on a weight gradient);
+#   * SG lobes of sigma >= 0.05 (at the 0.01 floor two fp32 evaluations of exp(-angle^2 / 2 sigma^2) differ by 1e-3);
+#   * the weight-norm denominator of the generator in fp64 (torch's CPU fp32 norm of 4 M elements is 9.5e-5 off; the GPU's is
+#     not), and the camera / light tensors that come out of LAPACK / BLAS stored in the fixture.
+BAR_PER_GAUSSIAN, BAR_IMAGE, BAR_GRAD = 3e-5, 5e-5, 2e-4
 
 
 def _gold():
@@ -109,11 +116,16 @@ class _Replay:
                 sys.modules[k] = v
 
 
-def _model(embs, geom, cal=True, blur=True):
+def _stored(G, tag):
+    """The fixture's copies of the inputs whose last bit depends on the host's BLAS / LAPACK / vector libm."""
+    return {k.split("/stored/")[1]: G[k] for k in G.files if k.startswith(f"{tag}/stored/")}
+
+
+def _model(G, embs, geom, cal=True, blur=True):
     """The stand-in on the GPU with what dropin.patch_rgca() installs on the reference classes bound to it."""
     from goliath_amd import rgca
 
-    m = S.ShapedAutoEncoder(embs, geom, 0, cal=cal, blur=blur).cuda()
+    m = S.ShapedAutoEncoder(embs, geom, 0, cal=cal, blur=blur, nudges=(G["nudges/index"], G["nudges/dz"])).cuda()
     m.decoder.forward = types.MethodType(rgca.prim_decoder_forward, m.decoder)
     m.render = types.MethodType(rgca.autoencoder_render, m)
     m.forward = types.MethodType(rgca.autoencoder_forward, m)
@@ -193,9 +205,10 @@ def test_train_point_lights_every_key_and_gradient():
     """Training mode, point lights (n_lights 3 and 2), is_fully_lit_frame mixed, CalV5 + background + LearnableBlur on,
     the training-only random light (color_rand, cos_weight)."""
     G = _gold()
-    embs, geom = (t.detach().cuda().requires_grad_(True) for t in S.leaves(2, 0))
-    m = _model(embs, geom).train()
-    batch = _cuda(S.batch_inputs(2, 0))
+    st = _stored(G, "train_point")
+    embs, geom = (t.detach().cuda().requires_grad_(True) for t in S.leaves(2, 0, st))
+    m = _model(G, embs, geom).train()
+    batch = _cuda(S.batch_inputs(2, 0, stored=st))
     with _Replay(G, "train_point") as rp:
         preds = m.forward(**batch)
         assert rp.sh_calls == 2 and rp.rand_calls == 1
@@ -208,7 +221,7 @@ def test_train_point_lights_every_key_and_gradient():
 
 
 def _env_batch(G, tag, B, seed, with_envbg):
-    batch = S.batch_inputs(B, seed)
+    batch = S.batch_inputs(B, seed, stored=_stored(G, tag))
     for k in ("light_intensity", "light_pos", "n_lights"):
         batch.pop(k)
     for k in ("light_intensity", "light_pos", "lightrot", "n_lights"):
@@ -230,8 +243,8 @@ def test_eval_env_relight_driver_inputs_every_key_and_gradient():
     from goliath_amd import shade
 
     G = _gold()
-    embs, geom = (t.detach().cuda().requires_grad_(True) for t in S.leaves(2, 100))
-    m = _model(embs, geom).eval()
+    embs, geom = (t.detach().cuda().requires_grad_(True) for t in S.leaves(2, 100, _stored(G, "eval_env")))
+    m = _model(G, embs, geom).eval()
     m.learn_blur_enabled = m.cal_enabled = False
     batch = _env_batch(G, "eval_env", 2, 100, with_envbg=False)
     seen = []
@@ -254,8 +267,8 @@ def test_vis_env_run_vis_relight_call():
     """run_vis_relight.py:110-122: no_grad, `envbg` present -> env background composite + diffuse / specular breakdown renders
     concatenated along the width (rgca.py:232-245)."""
     G = _gold()
-    embs, geom = (t.detach().cuda() for t in S.leaves(1, 200))
-    m = _model(embs, geom).eval()
+    embs, geom = (t.detach().cuda() for t in S.leaves(1, 200, _stored(G, "vis_env")))
+    m = _model(G, embs, geom).eval()
     m.learn_blur_enabled = m.cal_enabled = False
     batch = _env_batch(G, "vis_env", 1, 200, with_envbg=True)
     with torch.no_grad(), _Replay(G, "vis_env", compose=True):

@@ -39,18 +39,27 @@ def test_fixture_has_every_key_of_the_reference_forward():
     assert float(G["train_point/out/alpha"].max()) > 0.99 and 0.3 < float(G["train_point/out/alpha"].mean()) < 0.9
     for i in range(4):
         assert G[f"eval_env/in/preconv_envmap_{i}"].shape == (1, 3, 64 >> i, 128 >> i)
+    assert G["nudges/index"].shape == G["nudges/dz"].shape and len(np.unique(G["nudges/index"])) == len(G["nudges/index"])
+    assert 0.0 < float(G["nudges/dz"].min()) and float(G["nudges/dz"].max()) < 0.1          # mm
 
 
 @pytest.mark.parametrize("tag,seed", [("train_point", 0), ("eval_env", 100)])
-def test_stand_in_regenerates_and_the_shading_oracle_reproduces_the_reference_decoder(tag, seed):
+def test_stand_in_regenerates_and_the_shading_oracle_reproduces_the_reference_decoder(tag, seed, monkeypatch):
     from oracle import shade_ref
 
+    from goliath_amd import decoder as D
+
+    # torch's fp32 CPU norm of encmod's 4 M-element direction tensor is 9.5e-5 off (sequential accumulation); the fixture was
+    # generated with the weight-norm denominator in fp64 (see make_rgca_model_golden.py), the GPU's tree reduction agrees with
+    # that to 3e-7 -- so on the CPU the stand-in's layers get the same fp64 denominator here
+    monkeypatch.setattr(D, "_wn", lambda v, g: v * (g / v.double().pow(2).sum().sqrt().to(v.dtype)))
     G = np.load(GOLD)
     B = 2
-    embs, geom = S.leaves(B, seed)
-    m = S.ShapedAutoEncoder(embs, geom, 0)
+    st = {k.split("/stored/")[1]: G[k] for k in G.files if k.startswith(f"{tag}/stored/")}
+    embs, geom = S.leaves(B, seed, st)
+    m = S.ShapedAutoEncoder(embs, geom, 0, nudges=(G["nudges/index"], G["nudges/dz"]))
     dec = m.decoder.eval()
-    batch = S.batch_inputs(B, seed)
+    batch = S.batch_inputs(B, seed, stored=st)
     hp = batch["head_pose"]
     rot, trans = hp[:, :3, :3], hp[:, :3, 3]
     headrel_campos = ((batch["campos"] - trans)[:, None] @ rot)[:, 0]
@@ -73,11 +82,10 @@ def test_stand_in_regenerates_and_the_shading_oracle_reproduces_the_reference_de
             mips = [_t(G[f"{tag}/in/preconv_envmap_{i}"]) for i in range(4)]
             pr = shade_ref.shade(f_vn, f_vc, postex, tn, dec.albedo, light_sh, headrel_campos, envmips=mips, lightrot=lightrot)
     for k in ("primpos", "primqvec", "primscale", "opacity", "sigma", "spec_nml", "diff_color", "spec_color", "color"):
-        # measured <= 4e-7, except the SG specular of train_point: 2.1e-5 (the torch restatement of evaluate_gaussian against
-        # the reference's sg.cu; lobes down to sigma = 0.01 amplify the rounding of the angle 100x) and what sums it (color)
+        # measured: 0 (bit-identical decoder ladder and activations), except the specular terms: 9.4e-7 (the torch restatement
+        # of evaluate_gaussian against the reference's sg.cu) / 3.0e-7 (env lookups)
         v = rel_l2(pr[k], _t(G[f"{tag}/out/{k}"]))
-        print(tag, k, v)
-        assert v < (5e-5 if k in ("spec_color", "color") else 2e-6), k
+        assert v < (5e-6 if k in ("spec_color", "color") else 1e-6), (k, v)
 
 
 @pytest.mark.skipif(not os.path.isdir(REF), reason="reference tree only exists in the build container")
