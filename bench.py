@@ -1061,6 +1061,17 @@ def run_rgca(args, D, views, scaling, workload, overlap, micro=None, extras=True
                                                   "ONE pyramid shared by all views, per-view lightrot (config 2)"),
                    "slab_layout": "uv-coherent" if args.coherent_uv else "random permutation",
                    "normal_offsets": "smooth (decoder-like)" if args.smooth_normals else "white noise (SURVEY 8d)"}, **par)
+    # parity of THIS workload's chain against the CPU oracle (tests/test_gpu_fullsize.py at config-2 size, same kernels by
+    # digest): rel-L2 over ALL Gaussians per leaf gradient -- the number that exceeds the 1e-4 bar before the classified
+    # worst set W (flip pixels, texel borders, fp32 conditioning of the reference's own formulation) is taken out -- and
+    # without W.  null when the record under profiles/ was taken on other kernel sources.
+    par_rec = _stamped("fullsize_parity.json")
+    config["chain_parity_vs_oracle"] = None if par_rec is None else {
+        "outputs": par_rec.get("outputs"),
+        "leaf_gradients": {k: {"rel_l2_all_gaussians": v["rel_l2_all_gaussians"], "rel_l2_without_W": v["rel_l2_without_W"],
+                               "W_fraction": v["W_fraction"], "W_unexplained": v["W_unexplained"]}
+                           for k, v in par_rec.get("grads", {}).items()},
+        "pole_class_vs_fp64": par_rec.get("pole_class_vs_fp64")}
     res["config"] = config
     res["windows"] = _window_stats(win_ms)
     res["kernels_ms_per_call"] = kernels_ms

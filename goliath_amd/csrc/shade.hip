@@ -802,7 +802,7 @@ static int shade_fwd_width(const gol_shade_in* in) {
     else shade_fwd_kernel<V, false, false, P><<<grid, 256, 0, s>>>(__VA_ARGS__);                 \
   } while (0)
 
-// 4 Gaussians per lane (16-byte plane loads) when N allows, else 2 (8-byte), else 1 (with the projection epilogue: 4 or 1)
+// 4 Gaussians per lane (16-byte plane loads) when N allows, else 2 (8-byte), else 1 (the same widths with the projection epilogue; see shade_fwd_width)
 #define GOL_SHADE_FWD_DISPATCH(P, ...)                                                           \
   do {                                                                                           \
     const bool env = in->n_mips > 0, rnd = in->light_sh_rand != nullptr;                         \

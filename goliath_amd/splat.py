@@ -160,20 +160,25 @@ class CapacityPlanner:
             if self.mode == "async":
                 raise _lib.GoliathHipError(msg + " -- re-run the step (GOLIATH_CAPACITY_MODE=verify repairs inside the "
                                                  "call instead).")
+            import sys
             import warnings
 
             self.truncated += 1
-            warnings.warn(msg + "; calls of this shape check their own counts before returning until one has passed "
-                                "(GOLIATH_CAPACITY_MODE=verify checks every call).", CapacityWarning, stacklevel=3)
+            # shown on EVERY occurrence (a truncated step is a wrong step) without touching the process-wide filter list: the
+            # per-location "already shown" registry is a fresh dict each time, so the user's own filters (-W error, ignore)
+            # still decide what happens
+            try:
+                frame = sys._getframe(2)      # the caller of render_views (what stacklevel=3 pointed at)
+            except ValueError:
+                frame = sys._getframe(0)
+            warnings.warn_explicit(msg + "; calls of this shape check their own counts before returning until one has passed "
+                                         "(GOLIATH_CAPACITY_MODE=verify checks every call).", CapacityWarning,
+                                   frame.f_code.co_filename, frame.f_lineno, module=frame.f_globals.get("__name__"), registry={})
 
 
 class CapacityWarning(RuntimeWarning):
     """A render_views call was found, after the fact, to have rendered with truncated tile lists (adaptive mode)."""
 
-
-import warnings as _warnings
-
-_warnings.simplefilter("always", CapacityWarning)   # every occurrence, not once per call site: a truncated step is a wrong step
 
 PLANNER = CapacityPlanner()
 

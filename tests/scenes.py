@@ -69,3 +69,19 @@ def icosphere(subdiv=2, radius=1.0):
             nf += [(a, ab, ca), (b, bc, ab), (c, ca, bc), (ab, bc, ca)]
         f = nf
     return (torch.stack(v) * radius).float(), torch.tensor(f, dtype=torch.int64)
+
+
+def worst_set(a, b, tol):
+    """Smallest set of Gaussians (indices into the flattened [B*N] axis) whose removal brings rel-L2(a, b) under `tol`.
+    a, b: [B, C, N].  Returns (indices, rel-L2 over everything, rel-L2 over the rest)."""
+    a, b = a.double().cpu(), b.double().cpu()
+    err = (a - b).pow(2).sum(1).flatten()        # [B*N]
+    ref = b.pow(2).sum(1).flatten()
+    e_tot, r_tot = float(err.sum()), float(ref.sum())
+    order = err.argsort(descending=True)
+    ce = torch.cumsum(err[order], 0)
+    cr = torch.cumsum(ref[order], 0)
+    ok = (e_tot - ce) <= tol * tol * (r_tot - cr).clamp(min=1e-300)
+    k = 0 if e_tot <= tol * tol * r_tot else int(torch.nonzero(ok)[0]) + 1
+    rest = (max(e_tot - float(ce[k - 1]), 0.0) / max(r_tot - float(cr[k - 1]), 1e-300)) ** 0.5 if k else (e_tot / r_tot) ** 0.5
+    return order[:k], (e_tot / r_tot) ** 0.5, rest

@@ -55,20 +55,7 @@ STAGE = ("color", "opacity", "primpos", "primscale", "primqvec")
 # An unexplained member of W fails the test.
 
 
-def _worst_set(a, b, tol):
-    """Smallest set of Gaussians (indices into the flattened [B*N] axis) whose removal brings rel-L2(a, b) under `tol`.
-    a, b: [B, C, N].  Returns (indices, rel-L2 over everything, rel-L2 over the rest)."""
-    a, b = a.double().cpu(), b.double().cpu()
-    err = (a - b).pow(2).sum(1).flatten()        # [B*N]
-    ref = b.pow(2).sum(1).flatten()
-    e_tot, r_tot = float(err.sum()), float(ref.sum())
-    order = err.argsort(descending=True)
-    ce = torch.cumsum(err[order], 0)
-    cr = torch.cumsum(ref[order], 0)
-    ok = (e_tot - ce) <= tol * tol * (r_tot - cr).clamp(min=1e-300)
-    k = 0 if e_tot <= tol * tol * r_tot else int(torch.nonzero(ok)[0]) + 1
-    rest = (max(e_tot - float(ce[k - 1]), 0.0) / max(r_tot - float(cr[k - 1]), 1e-300)) ** 0.5 if k else (e_tot / r_tot) ** 0.5
-    return order[:k], (e_tot / r_tot) ** 0.5, rest
+from scenes import worst_set as _worst_set  # noqa: E402  (shared with __graft_entry__.smoke)
 
 
 def _flip_touched(o, flag_yx):
@@ -177,7 +164,7 @@ def test_bench_step_matches_oracle_chain(name):
         one = {k: (v[b:b + 1].detach().clone().requires_grad_(v.requires_grad) if torch.is_tensor(v) and k != "albedo"
                    else v) for k, v in cpu.items()}
         one["albedo"] = cpu["albedo"].detach().clone().requires_grad_(True)
-        one["mips"] = [m[b:b + 1] for m in cpu["mips"]]
+        one["mips"] = [m[b:b + 1] if m.shape[0] > 1 else m for m in cpu["mips"]]   # (config 2: ONE pyramid for all views)
         o = chain.cpu_view(one, H, W, loss_scale=1.0 / (B * 3 * H * W))
         ref_loss += o["loss"]
         if name == "config2":
@@ -249,21 +236,24 @@ def test_bench_step_matches_oracle_chain(name):
             fp64 = e_o >= 0.0625 * e_h
             allowed = allowed | fp64
             if pole is not None:
-                # near the poles BOTH fp32 evaluations are ill-conditioned (1 - r_y^2 cancels: the derivative of acos / atan2
-                # carries a relative error of 6e-8 / (1 - r_y^2)), and which of the two lands further from fp64 on ONE
-                # Gaussian is chance -- so the yardstick is taken over the whole class: HIP's distance from the fp64 evaluation
-                # over ALL near-pole Gaussians, relative to the fp32 oracle's.  Measured (profiles/r04_parity_ledger.json):
-                # 3.6x at config 2 (2.5e-5 vs 7.0e-6 of the tensor's norm over 12.9 k Gaussians), 2.1x at config 1 -- HIP's
-                # reflection direction carries 2-3 more roundings than torch's (reciprocal-multiply normalisations), which
-                # the (1 - r_y^2)^-3/2 conditioning magnifies; in absolute terms the class stays 4x under the 1e-4 bar.  The
-                # tripwire is 5x: a regression of the shade backward confined to near-pole directions inflates the ratio
-                # and un-explains every pole member of W.
+                # near the poles the reference's formulation is ill-conditioned in fp32 (v = acos(r_y): the derivative
+                # -1 / sqrt(1 - r_y^2) is formed from a difference that cancels to a few ulps of 1), and which of two fp32
+                # evaluations lands further from fp64 on ONE Gaussian is chance -- so the yardstick is taken over the whole
+                # class: HIP's distance from the fp64 evaluation over ALL near-pole Gaussians, relative to the fp32 oracle's.
+                # Rounds 3-4: HIP was 3.6x (config 2) / 2.1x (config 1) FARTHER than the oracle (it formed 1 - r_y^2 the same
+                # way with 2-3 more roundings in the reflection direction).  Round 5: shade.hip forms the polar angle as
+                # atan2(sqrt(r_x^2 + r_z^2), r_y) and 1 - r_y^2 as r_x^2 + r_z^2 -- the same quantities without the
+                # cancellation -- and is now 0.05x / 0.03x: 20-30x CLOSER to fp64 than the fp32 oracle itself
+                # (profiles/r05_fullsize_parity.json: f_vc 3.7e-7 vs 7.5e-6 over 12.8 k Gaussians).  The tripwire is 2x: a
+                # regression of the shade backward confined to near-pole directions un-explains every pole member of W.
                 # (class = near-pole Gaussians that no other predicate touches: a flip pixel under a near-pole Gaussian changes
-                # HIP's UPSTREAM gradient, which the fp64 evaluation -- fed the oracle's upstream -- does not see)
+                # HIP's UPSTREAM gradient, which the fp64 evaluation -- fed the oracle's upstream -- does not see.  The floor
+                # of 1e-7 of the tensor's norm keeps leaves that do not depend on the direction at all -- albedo: both
+                # distances ~1e-11 -- from tripping it.)
                 e_h64 = (a.double().cpu() - b64.double().cpu()).pow(2).sum(1).flatten()
                 pure = pole & ~allowed_in
                 hip_vs_64, orc_vs_64 = float(e_h64[pure].sum().sqrt()), float(e_o[pure].sum().sqrt())
-                class_ok = hip_vs_64 <= 5.0 * orc_vs_64 + 1e-30
+                class_ok = hip_vs_64 <= 2.0 * orc_vs_64 + 1e-7 * float(b64.double().pow(2).sum().sqrt())
                 report.setdefault("pole_class_vs_fp64", {})[k] = {"hip": hip_vs_64, "fp32_oracle": orc_vs_64,
                                                                    "gaussians": int(pure.sum()), "ok": bool(class_ok)}
                 if class_ok:
@@ -314,6 +304,9 @@ def test_bench_step_matches_oracle_chain(name):
     print(f"\nCHAIN_PARITY {name} " + json.dumps(report))
     out_dir = os.path.join(ROOT, "gpurun_out")
     if os.path.isdir(out_dir):
+        from goliath_amd import build
+
+        report["_stamp"] = {"csrc_sha16": build.source_digest()}   # bench.py quotes the copy under profiles/ while it matches
         with open(os.path.join(out_dir, "fullsize_parity.json" if name == "config2" else f"chain_parity_{name}.json"), "w") as f:
             json.dump(report, f, indent=1)
     assert abs(loss - ref_loss) < 1e-5 * abs(ref_loss)
