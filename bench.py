@@ -310,13 +310,14 @@ def _stamped(name):
 ALG_OPS_PER_PAIR = {"raster_fwd_kernel": 17, "raster_bwd_kernel": 35}
 
 
-def make_roofline(call, ms, views_per_launch, N, I, P, mip_bytes, pairs_taken=None):
+def make_roofline(call, ms, views_per_launch, N, I, P, mip_bytes, pairs_taken=None, records=""):
     """Roofline of the dominant ABI call.  Time: HIP events around the call, measured live.  Algorithmic bytes: DESIGN.md
     section 4.  HBM traffic and instruction counts: rocprofv3 PMC passes recorded under profiles/ (tools/gpu_profile.sh +
-    tools/make_profile_record.py), used only while their source digest matches this tree (else null)."""
+    tools/make_profile_record.py), used only while their source digest matches this tree (else null).  records: "" = the
+    250k-Gaussian records (traffic.json / valu.json), "_e2e" = the ones taken at 1,048,576 Gaussians (tools/e2e_pmc.sh)."""
     alg = views_per_launch * algorithmic_bytes(call, N, I, P, mip_bytes)
     gbs = alg / (ms * 1e-3) / 1e9
-    traffic = _stamped("traffic.json")
+    traffic = _stamped(f"traffic{records}.json")
     traffic = None if traffic is None or call not in traffic else traffic[call] * views_per_launch / 8.0
     hbm = {"achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
            "algorithmic_bytes_per_launch": alg}
@@ -324,7 +325,7 @@ def make_roofline(call, ms, views_per_launch, N, I, P, mip_bytes, pairs_taken=No
         return dict(hbm, bound="hbm", kernel=call, traffic=traffic)
     # the rasterizer moves ~1/10 of what HBM could deliver in its run time and keeps the vector ALUs busy instead:
     # report the instruction-issue roofline (and the HBM numbers beside it)
-    valu = _stamped("valu.json")
+    valu = _stamped(f"valu{records}.json")
     roof = dict(_valu_roofline(valu, VALU_BOUND_CALLS[call], ms, views_per_launch / 8.0), kernel=call, traffic=traffic,
                 hbm=hbm)
     if pairs_taken is not None:
@@ -795,14 +796,32 @@ def e2e_main(args, emit_line=True):
                                         t["Rt"], intr, H, W)
                 bins = o1["tile_bins"]
                 I = float((bins[..., 1] - bins[..., 0]).sum(1).float().mean())
+                pairs_taken = float(splat.raster_pair_counts(o1).double().mean(0)[1])
+                res["config"]["tiles_with_more_than_2048_entries"] = float(((bins[..., 1] - bins[..., 0]) > 2048).float().sum(1).mean())
                 del f_vn1, f_vc1, p1, o1, bins
             res["config"]["intersections_per_view"] = I
+            res["config"]["pixel_gaussian_pairs_taken_per_view"] = pairs_taken
             dom = max(hot, key=hot.get)
-            res["roofline"] = make_roofline(dom, hot[dom], B, N, I, H * W, 0)
-            if res["roofline"].get("bound") == "valu":
-                # the stamped instruction counts belong to the 250k-Gaussian scene: not transferable to this one
-                res["roofline"] = dict(res["roofline"]["hbm"], bound="valu (no PMC record at this size: HBM figures only)",
-                                       kernel=dom, traffic=None)
+            # PMC records taken AT THIS SIZE (tools/e2e_pmc.sh -> profiles/traffic_e2e.json / valu_e2e.json; the scene of the
+            # record is the fit's first steps, the time is the live one of this run)
+            res["roofline"] = make_roofline(dom, hot[dom], B, N, I, H * W, 0, pairs_taken, records="_e2e")
+            # every hot-path call at this size: live time, PMC traffic of the recorded launch, and for the binning / raster
+            # kernels the issue statistics that say what they wait for
+            tr, va = _stamped("traffic_e2e.json"), _stamped("valu_e2e.json")
+            if tr is not None:
+                res["hbm_traffic_per_call_MB"] = {k: round(tr[k] / 1e6, 1) for k in hot if k in tr}
+            if va is not None:
+                ks = {}
+                for kern, c in va.items():
+                    if kern.startswith("_") or c.get("abi_call") not in hot or not c.get("SQ_BUSY_CYCLES"):
+                        continue
+                    ks[kern] = {"abi_call": c["abi_call"], "valu_inst": c.get("SQ_INSTS_VALU"),
+                                # quad-cycles over 1024 SIMDs / XCD-summed active cycles (as in _valu_roofline)
+                                "valu_busy": round(4.0 * c["SQ_ACTIVE_INST_VALU"] / 1024.0 / (c["GRBM_GUI_ACTIVE"] / 8.0), 3)
+                                if c.get("SQ_ACTIVE_INST_VALU") and c.get("GRBM_GUI_ACTIVE") else None,
+                                "wait_inst_any_of_wave_cycles": round(c["SQ_WAIT_INST_ANY"] / c["SQ_WAVE_CYCLES"], 3)
+                                if c.get("SQ_WAIT_INST_ANY") and c.get("SQ_WAVE_CYCLES") else None}
+                res["kernel_issue_stats_at_this_size"] = ks
         if emit_line:
             emit(res)
     if world > 1:

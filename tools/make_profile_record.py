@@ -21,6 +21,9 @@ CALLS = {  # kernel-name prefix -> ABI call
     "sort_kernel": "gol_bin_sort", "sort_queue_kernel": "gol_bin_sort", "sort_big_kernel": "gol_bin_sort", "bin_": "gol_bin_sort",
     "raster_fwd_kernel": "gol_rasterize_fwd", "l1_sum_kernel": "gol_rasterize_fwd", "splat_pack_kernel": "gol_splat_pack",
     "raster_bwd_kernel": "gol_rasterize_bwd", "l1_kernel<false>": "gol_l1_fwd", "l1_kernel<true>": "gol_l1_bwd",
+    "tail_conv_fwd_kernel": "gol_tail_conv_fwd", "tail_bias_fwd_kernel": "gol_tail_conv_fwd", "tail_conv_bwd": "gol_tail_conv_bwd",
+    "tail_bias_bwd_kernel": "gol_tail_conv_bwd", "ssim_fwd_kernel": "gol_ssim_fwd", "ssim_bwd_kernel": "gol_ssim_bwd",
+    "envmap_pack_kernel": "gol_envmap_pack",
 }
 
 
@@ -51,7 +54,10 @@ def main(tag, traffic_name="traffic.json", only_traffic=False):
             if c and r["FETCH_SIZE"] and r["WRITE_SIZE"]:
                 traffic[c] = traffic.get(c, 0.0) + 1024.0 * (2.0 * float(r["FETCH_SIZE"]) + float(r["WRITE_SIZE"]))
         traffic["_stamp"] = dict(stamp, note="bytes per 8-view launch = 2*FETCH_SIZE + WRITE_SIZE (KiB counters); counts "
-                                              "L2->fabric requests, i.e. includes Infinity-Cache hits and memory-side atomics")
+                                              "L2->fabric requests, i.e. includes Infinity-Cache hits and memory-side atomics.  "
+                                              "The doubling is calibrated for gathers too (profiles/r05_gather_calibration.txt: "
+                                              "random 16 / 64 / 128-byte gathers all fetch ONE 128-byte line that the counter "
+                                              "tallies at 64 B -- so a 64-byte record costs 128 B of fabric traffic)")
         json.dump(traffic, open(os.path.join(dst, traffic_name), "w"), indent=1)
     spath = os.path.join(src, "pmc_sq.csv")
     if os.path.exists(spath) and not only_traffic:
@@ -93,9 +99,42 @@ def secondary(tag):
     print("recorded secondary", tag, "csrc", sha, list(out))
 
 
+def e2e(tag):
+    """gpurun_out/TAG/e2e_pmc_{traffic,sq}.csv + e2e_kernel_stats.csv (tools/e2e_pmc.sh: the hot path at the reference-native
+    1,048,576 Gaussians, 8 views per launch) -> profiles/traffic_e2e.json (bytes per launch of every C-ABI call) and
+    profiles/valu_e2e.json (instruction / cycle counters per launch of every kernel), stamped with the kernel-source digest."""
+    src = os.path.join(ROOT, "gpurun_out", tag)
+    dst = os.path.join(ROOT, "profiles")
+    sha = open(os.path.join(src, "csrc_sha16.txt")).read().strip()
+    for f in ("e2e_kernel_stats.csv", "e2e_pmc_traffic.csv", "e2e_pmc_sq.csv", "bench_e2e.json"):
+        if os.path.exists(os.path.join(src, f)):
+            shutil.copy(os.path.join(src, f), os.path.join(dst, f"{tag}_{f}"))
+    stamp = {"csrc_sha16": sha, "source": f"profiles/{tag}_e2e_pmc_*.csv",
+             "command": "rocprofv3 --pmc <counters> -- python bench.py --workload e2e --no-cpu-baseline --steps 3 --warmup 2 "
+                        "(1,048,576 Gaussians, 8 views per launch; one pass per counter group; mean over the dispatches)"}
+    traffic = {}
+    for r in csv.DictReader(open(os.path.join(src, "e2e_pmc_traffic.csv"))):
+        c = call_of(r["kernel"])
+        if c and r["FETCH_SIZE"] and r["WRITE_SIZE"]:
+            traffic[c] = traffic.get(c, 0.0) + 1024.0 * (2.0 * float(r["FETCH_SIZE"]) + float(r["WRITE_SIZE"]))
+    traffic["_stamp"] = dict(stamp, note="bytes per 8-view launch = 2*FETCH_SIZE + WRITE_SIZE (KiB counters).  The doubling is "
+                                         "calibrated for this repo's gather patterns too (profiles/r05_gather_calibration.txt: "
+                                         "16-, 64- and 128-byte random gathers all fetch one 128-byte line tallied at 64 B)")
+    json.dump(traffic, open(os.path.join(dst, "traffic_e2e.json"), "w"), indent=1)
+    valu = {}
+    for r in csv.DictReader(open(os.path.join(src, "e2e_pmc_sq.csv"))):
+        valu[r["kernel"]] = {k: float(v) for k, v in r.items() if k.startswith(("SQ_", "GRBM_")) and v not in ("", None)}
+        valu[r["kernel"]]["abi_call"] = call_of(r["kernel"])
+    valu["_stamp"] = dict(stamp, note="per 8-view launch at 1,048,576 Gaussians; quad-cycle counters summed over all SIMDs")
+    json.dump(valu, open(os.path.join(dst, "valu_e2e.json"), "w"), indent=1)
+    print("recorded e2e", tag, "csrc", sha, sorted(k for k in traffic if not k.startswith("_")))
+
+
 if __name__ == "__main__":
     if sys.argv[1] == "--secondary":
         secondary(sys.argv[2])
+    elif sys.argv[1] == "--e2e":
+        e2e(sys.argv[2])
     elif sys.argv[1] == "--coherent-smooth":   # FETCH / WRITE of the micro1 command with --coherent-uv --smooth-normals
         main(sys.argv[2], traffic_name="traffic_coherent_smooth.json", only_traffic=True)
     else:

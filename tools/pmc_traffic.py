@@ -1,7 +1,9 @@
 #!/usr/bin/env python
 """Turn two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE; `bench.py --micro 1`) into profiles/traffic.json:
 HBM-side bytes per 8-view launch of every C-ABI call = 2 * FETCH_SIZE + WRITE_SIZE (FETCH_SIZE is doubled on gfx950,
-MI355X_MICROARCH.md; calibrated on the streaming L1-loss kernel whose reads are known exactly).
+MI355X_MICROARCH.md; calibrated on the streaming L1-loss kernel whose reads are known exactly, and -- round 5,
+tools/probe/gather_probe.hip, profiles/r05_gather_calibration.txt -- on random 16- / 64- / 128-byte gathers: each fetches
+ONE 128-byte line, tallied at 64 B, so the factor 2 holds for the gather kernels and a 64-byte record costs 128 B of traffic).
 Usage: python tools/pmc_traffic.py fetch_counter_collection.csv write_counter_collection.csv out_prefix"""
 import collections
 import csv
