@@ -3,7 +3,8 @@
 # -> gpurun_out/gather_calibration.txt : useful bytes / time of each probe launch (tools/probe/gather_probe.hip) and the raw
 #    FETCH_SIZE rocprofv3 reports for the same kernels (mean per dispatch).
 export TMPDIR=/tmp
-O=gpurun_out/gathercal; mkdir -p $O
+O=gpurun_out/gathercal; mkdir -p $O tools/bin
+[ -x tools/bin/gather_probe ] || hipcc --offload-arch=gfx950 -O3 -Wno-unused-value tools/probe/gather_probe.hip -o tools/bin/gather_probe
 tools/bin/gather_probe > $O/timing.txt 2>&1
 rocprofv3 --pmc FETCH_SIZE -f csv -d $O/pmc -o p -- tools/bin/gather_probe > $O/pmc.log 2>&1
 python - "$O" <<'PY'
