@@ -34,7 +34,7 @@ with torch.no_grad():
     pick = nz[torch.randperm(nz.numel(), generator=g)[:n_tiles].to(nz.device)]
     lane_hist = torch.zeros(65, dtype=torch.int64, device="cuda")
     pix_hist = torch.zeros(129, dtype=torch.int64, device="cuda")
-    visits = taker_less = 0
+    visits = taker_less = both = one = 0
     for tile in pick.tolist():
         ty, tx = divmod(tile, tiles_x)
         lo, hi = int(bins[tile, 0]), int(bins[tile, 1])
@@ -50,6 +50,9 @@ with torch.no_grad():
         sg = 0.5 * (conics[e, 0][:, None, None] * dx * dx + conics[e, 2][:, None, None] * dy * dy) + conics[e, 1][:, None, None] * dx * dy
         alpha = torch.clamp(op[e][:, None, None] * torch.exp(-sg), max=0.99)
         taken = (sg >= 0) & (alpha >= 1.0 / 255.0) & (li[:, None, None] <= f[None]) & inside[None]     # [E,16,16]
+        any_half = [(taken[:, 8 * h:8 * h + 8].flatten(1).any(1)) for h in range(2)]
+        both += int((any_half[0] & any_half[1]).sum())
+        one += int((any_half[0] ^ any_half[1]).sum())
         for half in range(2):
             th = taken[:, 8 * half:8 * half + 8]                             # [E,8,16]
             lanes = (th[:, 0::2] | th[:, 1::2]).flatten(1).sum(1)            # [E] lanes with a taker (4 row pairs x 16)
@@ -73,3 +76,6 @@ for a, b in ((1, 4), (5, 8), (9, 16), (17, 24), (25, 32), (33, 48), (49, 63), (6
 ph = pix_hist.cpu().double()
 print("mean taker lanes per visit (given >= 1):", float((lh[1:] * torch.arange(1, 65)).sum() / tot),
       " mean taken pixels:", float((ph[1:] * torch.arange(1, 129)).sum() / ph[1:].sum()))
+print(f"tile entries with takers in BOTH 16x8 halves: {both}, in exactly one: {one}  ->  both / (both + one) = {both / max(both + one, 1):.3f}")
+print("instruction model (vector instructions per tile entry; visit = 75 at 2 px / lane, ~110 at 4 px / lane over the whole tile):",
+      f"2 px/lane {(150 * both + 75 * one) / max(both + one, 1):.1f}   4 px/lane 110.0")
