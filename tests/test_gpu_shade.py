@@ -142,3 +142,51 @@ def test_packed_envmap_cache_and_its_refresh():
     assert torch.allclose(shade.pack_envmap(m)[0], a)
     shade.invalidate_envmap_cache()
     assert torch.allclose(shade.pack_envmap(m)[0], a)
+
+
+@pytest.mark.parametrize("form", ["one_map", "expanded_view"])
+@pytest.mark.parametrize("fused_projection", [False, True])
+def test_shared_env_pyramid_equals_per_view_copies(form, fused_projection):
+    """BASELINE config 2 / light_decorator.py:96-100: ONE pyramid lights every view (gol_shade_in.mips_shared).  Handing the
+    levels over as [1,3,h,w], or as the stride-0 `expand(B, ...)` views dropin.patch_light_decorator returns, must give
+    bit-identical outputs and gradients to B materialised copies, with and without the projection fused in; env + the
+    training-only random light (shade_fwd_kernel<.., ENV, RAND, ..>) included."""
+    from goliath_amd import render_gs, shade
+
+    B, S = 3, 24
+    N = S * S
+    g = torch.Generator().manual_seed(5)
+    r = lambda *s: torch.randn(*s, generator=g)
+    base = dict(f_vn=0.3 * r(B, 125, S, S), f_vc=0.3 * r(B, 4, S, S), postex=60.0 * r(B, 3, S, S), tn=F.normalize(r(B, 3, S, S), dim=1),
+                albedo=0.2 + 0.6 * torch.rand(1, N, 3, generator=g), light_sh=0.3 * r(B, 3, 81), campos=torch.tensor([[30.0, -40.0, -900.0]]).repeat(B, 1),
+                lightrot=torch.linalg.qr(r(B, 3, 3))[0], rand=0.3 * r(B, 3, 81))
+    one = [torch.rand(1, 3, 16 >> i, 32 >> i, generator=g) * 1.6 for i in range(3)]
+    K = torch.zeros(B, 3, 3)
+    K[:, 0, 0] = K[:, 1, 1] = 300.0
+    K[:, 0, 2], K[:, 1, 2], K[:, 2, 2] = 48.0, 64.0, 1.0
+    Rt = torch.eye(3, 4)[None].repeat(B, 1, 1)
+    Rt[:, 2, 3] = 900.0
+
+    def run(mips):
+        leaf = {k: base[k].clone().cuda().requires_grad_(True) for k in ("f_vn", "f_vc", "postex", "tn", "albedo")}
+        vs = render_gs.view_set(K.cuda(), Rt.cuda(), 128, 96) if fused_projection else None
+        out = shade.shading_tail(leaf["f_vn"], leaf["f_vc"], leaf["postex"], leaf["tn"], leaf["albedo"], base["light_sh"].cuda(),
+                                 base["campos"].cuda(), preconv_envmap=mips, lightrot=base["lightrot"].cuda(),
+                                 light_sh_rand=base["rand"].cuda(), views=vs)
+        w = torch.Generator().manual_seed(9)
+        loss = sum((v * torch.randn(v.shape, generator=w).cuda()).sum() for k, v in sorted(out.items()) if torch.is_tensor(v) and v.requires_grad)
+        if fused_projection:
+            loss = loss + (out["projected"].records * torch.randn(out["projected"].records.shape, generator=w).cuda()).sum()
+        loss.backward()
+        return {k: v.detach() for k, v in out.items() if torch.is_tensor(v)}, {k: v.grad for k, v in leaf.items()}
+
+    copies = [m.cuda().expand(B, -1, -1, -1).contiguous() for m in one]
+    shared = [m.cuda() for m in one] if form == "one_map" else [m.cuda().expand(B, -1, -1, -1) for m in one]
+    o1, g1 = run(copies)
+    o2, g2 = run(shared)
+    for k in o1:
+        assert torch.equal(o1[k], o2[k]), k
+    for k in g1:
+        assert torch.equal(g1[k], g2[k]), k
+    with pytest.raises(ValueError):      # neither one map nor one per view
+        run([m.cuda().expand(2, -1, -1, -1).contiguous() for m in one])
