@@ -170,11 +170,21 @@ class _EdgeGrad(torch.autograd.Function):
                 weight = d_ac_b * d_ac_b / (d_ac_b * d_ac_b + d_al * d_al).clamp(min=1e-30)
                 coef = (0.5 * (gp + gq) * (cp - cq)).sum(1) * ok.to(leaf.dtype) * weight
                 total = total + (coef.detach() * x_star).sum()
+                # discontinuities whose occluder edge does not cross within a pixel get NO gradient: counted on the device (no
+                # extra sync) so a caller can see how many were dropped (EDGE_STATS)
+                EDGE_STATS["edges"] = EDGE_STATS.get("edges", 0) + ok.numel()
+                dropped = (~ok).sum()
+                EDGE_STATS["dropped"] = dropped if EDGE_STATS.get("dropped") is None else EDGE_STATS["dropped"] + dropped
             if total.requires_grad:
                 (gv,) = torch.autograd.grad(total, leaf)
             else:
                 gv = torch.zeros_like(leaf)
         return gv, None, g, None, None
+
+
+# running totals of the last backward passes: "edges" (int) = discontinuities seen, "dropped" (0-dim device tensor or None) =
+# those without a crossing occluder edge within a pixel (no gradient).  Reset with EDGE_STATS.clear().
+EDGE_STATS = {}
 
 
 def edge_grad_estimator(v_pix, vi, bary_img, img, index_img, depth_img=None):
