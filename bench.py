@@ -1149,6 +1149,12 @@ def run_rgca(args, D, views, scaling, workload, overlap, micro=None, extras=True
 def _release():
     import gc
 
+    try:   # the packed env-map levels of the workload that just ended (the cache keeps its source tensors alive)
+        from goliath_amd import shade
+
+        shade.invalidate_envmap_cache()
+    except Exception:
+        pass
     gc.collect()
     if torch.cuda.is_available():
         torch.cuda.empty_cache()

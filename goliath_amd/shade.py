@@ -85,6 +85,7 @@ def pack_envmap(mips, refresh=False):
                     _PACKED[key] = (hit[0], hit[1], None)
                 else:
                     torch.cuda.current_stream(m.device).wait_event(hit[2])
+            _PACKED[key] = _PACKED.pop(key)    # most recently used last: eviction below drops the least recently used
             out.append(hit[1])
             continue
         B, _, h, w = m.shape
@@ -92,7 +93,7 @@ def pack_envmap(mips, refresh=False):
         _lib.call("gol_envmap_pack", _lib.c_int(B), _lib.c_int(h), _lib.c_int(w), _lib.fptr(m), _lib.fptr(p),
                   stream_ptr())
         while len(_PACKED) >= 16:
-            _PACKED.pop(next(iter(_PACKED)))   # oldest entry
+            _PACKED.pop(next(iter(_PACKED)))   # least recently used entry
         ev = torch.cuda.Event()
         ev.record()
         _PACKED[key] = (m, p, ev)
