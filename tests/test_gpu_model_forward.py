@@ -3,7 +3,9 @@ ca_code/models/rgca.py:153-253) driven end to end on a module shaped like the re
 decoder (1024^2 slab, 162.8 M parameters, goliath_amd.decoder), head-relative transforms, fused decoder tail + shading
 tail, batched render, fused image tail (calibration + background + learnable blur).  Checked: the output keys of
 rgca.py:574-618 / :247-251, shapes, and the image against the same steps composed from separately tested pieces
-(render_batch + plain-torch calibration / composite / gaussian blur)."""
+(render_batch + plain-torch calibration / composite / gaussian blur) -- a CONSISTENCY test at the reference's decoder size
+(1,048,576 Gaussians), not a parity test: PARITY of these entry points against the reference's own AutoEncoder.forward /
+render / PrimDecoder.forward is tests/test_gpu_rgca_model_golden.py (round 5)."""
 import math
 import os
 import sys

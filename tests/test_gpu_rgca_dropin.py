@@ -1,6 +1,7 @@
 """GPU: the model-level drop-in entry points (goliath_amd.rgca) reproduce the reference's
 PrimDecoder.forward outputs (golden) when installed on a stand-in decoder, and AutoEncoder.render
-semantics (alpha detached, depth normalised)."""
+semantics (alpha detached, depth normalised).  (The render test below checks the binding against render_batch, i.e.
+consistency; parity of AutoEncoder.render / forward against the reference's own code: tests/test_gpu_rgca_model_golden.py.)"""
 import types
 
 import pytest
