@@ -118,3 +118,54 @@ def test_spawn_command_is_the_drivers_command_line():
     assert cmd[1:] == ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=8", "--master-addr", "127.0.0.1",
                        "--master-port", "1234", "bench.py", "--gpus", "8"]
     assert launch.maybe_spawn(1) is None
+
+
+def test_one_line_record_is_short_strict_json():
+    """the driver could not parse a 22.5 KB line.  The stdout line must stay under 8 KB, be strict JSON
+    (no NaN / Infinity tokens) and carry value / roofline / cpu_baseline; everything else goes to the detail record.  Fed
+    with the largest full records under profiles/ (round 5's 22.5 KB line, and round 6's detail record once it exists)."""
+    import glob
+    import math
+
+    sys.path.insert(0, ROOT)
+    import bench
+
+    fulls = [os.path.join(ROOT, "profiles", "r05z_bench.json")] + sorted(glob.glob(os.path.join(ROOT, "profiles", "r06*_bench_detail.json")))
+    for path in fulls:
+        full = json.load(open(path))
+        full["config"]["poison"] = float("nan")              # must not reach the line as a NaN token
+        full["kernels_ms_per_call"]["gol_bin_sort"] = float("inf")
+        text = json.dumps(bench.compact_line(full), allow_nan=False, separators=(",", ":"))
+        assert len(text) < 8192, (path, len(text))
+        line = json.loads(text, parse_constant=lambda c: (_ for _ in ()).throw(ValueError(c)))
+        for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                  "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+            assert k in line, (path, k)
+        assert math.isfinite(line["value"]) and line["config"]["workload"] == "rgca_config2_envrelight"
+        assert set(line["config"]) <= set(bench._CONFIG_KEYS) | {"grad_exchange"}       # workload keys only
+        for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic"):
+            assert k in line["roofline"], k
+        for k in ("value", "unit", "cores", "kind", "sample"):
+            assert k in line["cpu_baseline"], k
+        for name, sec in line.get("secondary", {}).items():
+            assert set(sec) <= {"value", "unit", "ms_per_step", "ms_per_step_median", "roofline", "loss_first_step",
+                                "loss_last_step", "hot_path_ms_per_step", "error"}, (name, sorted(sec))
+
+
+def test_emit_writes_the_detail_record_and_one_line(tmp_path, capfd):
+    sys.path.insert(0, ROOT)
+    import bench
+
+    full = json.load(open(os.path.join(ROOT, "profiles", "r05z_bench.json")))
+    old = bench.DETAIL_PATH
+    bench.DETAIL_PATH = str(tmp_path / "d" / "bench_detail.json")
+    try:
+        bench.emit(full)
+    finally:
+        bench.DETAIL_PATH = old
+    out, err = capfd.readouterr()
+    lines = [l for l in out.splitlines() if l.strip()]
+    assert len(lines) == 1 and len(lines[0]) < 8192
+    assert json.loads(lines[0])["value"] == float(f"{full['value']:.5g}")
+    assert json.load(open(tmp_path / "d" / "bench_detail.json"))["secondary"]["mvp"]["config"]["prims"] == 4096
+    assert "bench.py detail:" in err
