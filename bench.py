@@ -98,7 +98,7 @@ def _roof_brief(r):
 
 
 _CONFIG_KEYS = ("workload", "gaussians", "image", "views_per_gpu", "views_per_step", "micro_batches", "world_size",
-                "dist_backend", "parallelism", "intersections_per_view", "grad_exchange_bytes_per_step",
+                "dist_backend", "rccl_world_size", "parallelism", "intersections_per_view", "grad_exchange_bytes_per_step",
                 "grad_exchange_ms_alone", "ranks_share_gpu", "prims", "uv", "lights", "views", "fused_tail", "loss")
 
 
@@ -127,6 +127,8 @@ def compact_line(res):
     out = {k: res[k] for k in keep if k in res}
     cfg = res.get("config") or {}
     out["config"] = {k: cfg[k] for k in _CONFIG_KEYS if k in cfg}
+    if cfg.get("launch"):
+        out["config"]["launch"] = "hip_graph_replay" if cfg["launch"].startswith("hip_graph_replay") else "eager"
     if "grad_exchange" in cfg and cfg["grad_exchange"]:
         out["config"]["grad_exchange"] = "serial" if "serial" in cfg["grad_exchange"] else "overlapped"
     for k in ("stub_gradients_averaged", "note"):

@@ -167,6 +167,39 @@ struct EnvSample {
   float d_u[3], d_v[3];
 };
 
+// the address half of bilinear_border<true>: which footprint record, with which weights
+struct Footprint {
+  const float4* q;         // the [h,w,16] record of the top-left texel
+  float wx1, wy1, mx, my;  // tap weights (wx0 = 1 - wx1, ...), coordinate-clamp gradient masks
+};
+__device__ __forceinline__ Footprint footprint_of(const float* __restrict__ img, int h, int w, float u, float v) {
+  Footprint f;
+  float ix = ((u + 1.f) * (float)w - 1.f) * 0.5f, iy = ((v + 1.f) * (float)h - 1.f) * 0.5f;
+  f.mx = (ix > 0.f && ix < (float)(w - 1)) ? 1.f : 0.f;
+  f.my = (iy > 0.f && iy < (float)(h - 1)) ? 1.f : 0.f;
+  ix = fminf(fmaxf(ix, 0.f), (float)(w - 1));
+  iy = fminf(fmaxf(iy, 0.f), (float)(h - 1));
+  const float fx0 = floorf(ix), fy0 = floorf(iy);
+  f.wx1 = ix - fx0; f.wy1 = iy - fy0;
+  f.q = reinterpret_cast<const float4*>(img) + (size_t)((int)fy0 * w + (int)fx0) * 4;
+  return f;
+}
+// ... and the arithmetic half, on the four taps already in registers (same expressions as bilinear_border)
+__device__ __forceinline__ Bilinear footprint_eval(const Footprint& f, const float4& a, const float4& b2, const float4& c2,
+                                                   const float4& d2) {
+  Bilinear r;
+  r.mx = f.mx; r.my = f.my;
+  const float wx1 = f.wx1, wx0 = 1.f - wx1, wy1 = f.wy1, wy0 = 1.f - wy1;
+  const float t00[3] = {a.x, a.y, a.z}, t01[3] = {b2.x, b2.y, b2.z}, t10[3] = {c2.x, c2.y, c2.z}, t11[3] = {d2.x, d2.y, d2.z};
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    r.val[c] = wy0 * (wx0 * t00[c] + wx1 * t01[c]) + wy1 * (wx0 * t10[c] + wx1 * t11[c]);
+    r.d_ix[c] = wy0 * (t01[c] - t00[c]) + wy1 * (t11[c] - t10[c]);
+    r.d_iy[c] = wx0 * (t10[c] - t00[c]) + wx1 * (t11[c] - t01[c]);
+  }
+  return r;
+}
+
 // mipmap_grid_sample (mipmap_sampler.py:13-69): level selection has no gradient.
 __device__ __forceinline__ EnvSample env_lookup(const gol_shade_in& in, int b, float u, float v, float level) {
   EnvSample e;
@@ -179,16 +212,37 @@ __device__ __forceinline__ EnvSample env_lookup(const gol_shade_in& in, int b, f
     d1 = (int)fl;
     a = lam - fl;
   }
-  const int h0 = in.mip_h[d1], w0 = in.mip_w[d1];
   const bool packed = in.mips_packed[0] != nullptr;
   if (in.mips_shared) b = 0;  // one pyramid for all views; only lightrot is per view
-  const Bilinear s0 = packed ? bilinear_border<true>(in.mips_packed[d1] + (size_t)b * 16 * h0 * w0, h0, w0, u, v)
-                             : bilinear_border<false>(in.mips[d1] + (size_t)b * 3 * h0 * w0, h0, w0, u, v);
+  const int d2 = min(d1 + 1, q - 1);
+  // the level index differs per lane: indexing the kernel-argument arrays with it makes the compiler FETCH mip_h / mip_w /
+  // the level pointer from the argument segment with vector loads -- two more dependent memory round trips in front of the
+  // lookup.  A select chain over the (wave-uniform, SGPR-resident) entries costs a few VALU instead.
+  int h0 = in.mip_h[0], w0 = in.mip_w[0], h1 = h0, w1 = w0;
+  const float *m0 = packed ? in.mips_packed[0] : in.mips[0], *m1 = m0;
+#pragma unroll
+  for (int l = 1; l < GOL_MAX_MIPS; ++l) {
+    const float* ml = packed ? in.mips_packed[l] : in.mips[l];
+    if (d1 == l) { h0 = in.mip_h[l]; w0 = in.mip_w[l]; m0 = ml; }
+    if (d2 == l) { h1 = in.mip_h[l]; w1 = in.mip_w[l]; m1 = ml; }
+  }
+  Bilinear s0, s1;
+  if (packed) {
+    // both levels' record addresses first, then the eight 16-byte loads back to back: ONE memory round trip per lookup
+    // instead of two dependent ones (round 6; the two bilinear_border calls each waited for their own four loads)
+    const Footprint f0 = footprint_of(m0 + (size_t)b * 16 * h0 * w0, h0, w0, u, v);
+    const Footprint f1 = footprint_of(m1 + (size_t)b * 16 * h1 * w1, h1, w1, u, v);
+    const float4 a0 = f0.q[0], a1 = f0.q[1], a2 = f0.q[2], a3 = f0.q[3];
+    const float4 b0 = f1.q[0], b1 = f1.q[1], b2 = f1.q[2], b3 = f1.q[3];
+    s0 = footprint_eval(f0, a0, a1, a2, a3);
+    s1 = footprint_eval(f1, b0, b1, b2, b3);
+  } else {
+    s0 = bilinear_border<false>(m0 + (size_t)b * 3 * h0 * w0, h0, w0, u, v);
+    s1 = s0;
+    if (q > 1) s1 = bilinear_border<false>(m1 + (size_t)b * 3 * h1 * w1, h1, w1, u, v);
+  }
+  const float msc = in.mips_scale != 0.f ? in.mips_scale : 1.f;  // the driver's per-frame scale of the whole pyramid
   if (q > 1) {
-    const int d2 = min(d1 + 1, q - 1);
-    const int h1 = in.mip_h[d2], w1 = in.mip_w[d2];
-    const Bilinear s1 = packed ? bilinear_border<true>(in.mips_packed[d2] + (size_t)b * 16 * h1 * w1, h1, w1, u, v)
-                               : bilinear_border<false>(in.mips[d2] + (size_t)b * 3 * h1 * w1, h1, w1, u, v);
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
       e.val[c] = s0.val[c] + a * (s1.val[c] - s0.val[c]);  // th.lerp
@@ -205,6 +259,8 @@ __device__ __forceinline__ EnvSample env_lookup(const gol_shade_in& in, int b, f
       e.d_v[c] = s0.d_iy[c] * s0.my * (0.5f * (float)h0);
     }
   }
+#pragma unroll
+  for (int c = 0; c < 3; ++c) { e.val[c] *= msc; e.d_u[c] *= msc; e.d_v[c] *= msc; }
   return e;
 }
 
@@ -285,152 +341,176 @@ __device__ __forceinline__ void spec_forward(const gol_shade_in& in, int b, cons
   }
 }
 
-// PROJ: the EWA projection of the Gaussians just shaded runs as the kernel's epilogue (gol_project.h: the arithmetic of
-// gol_project_fwd on the position / quaternion / clamped scale / opacity / colour still in registers) and writes what
-// binning and the rasterizer read -- the 64-byte raster record, screen position, depth, radius, conic, compensation,
-// effective opacity -- so the render direction starts at the tile count (gol_render_fwd_projected) and the 56 bytes per
-// Gaussian the projection kernel would read back are never fetched.
-template <int V, bool ENV, bool RAND, bool PROJ>
-__global__ __launch_bounds__(256) void shade_fwd_kernel(const gol_shade_in in, const gol_shade_out out,
+// Forward, three phases per 256-Gaussian workgroup (round 6; the mirror image of the backward below):
+//   phase G  one lane per Gaussian, FIRST: the 22 geometry / f_vcond / base planes, the shading state, the env-map lookup
+//            (two mip levels = eight 16-byte loads issued together) and every output that does not need the SH sums --
+//            23 of the 37 output floats and, PROJ, the EWA projection (gol_project.h: the arithmetic of gol_project_fwd on
+//            the position / quaternion / clamped scale / opacity still in registers).  The two dependent memory round
+//            trips of a lookup (planes -> address -> records) sit at the START of the wave's life, under the plane
+//            streams of the CU's other workgroups, and 13 floats per Gaussian are carried over phase S;
+//   phase S  wave w streams SH planes w, w+4, ... of the block's 256 Gaussians (lane -> 4 consecutive Gaussians, 16-byte
+//            non-temporal loads, 1 KiB contiguous per wave-instruction; light coefficients through SGPRs) into partial sums
+//            that meet in LDS;
+//   phase F  colour = max(max(albedo * D, 0) + spec * vis, 0) and, PROJ, the 64-byte raster record binning and the
+//            rasterizer read (so the render direction starts at the tile count, gol_render_fwd_projected, and the 56 bytes
+//            per Gaussian a projection kernel would read back are never fetched).
+// Rounds 1-5 streamed the SH planes first with 4 Gaussians per lane and did the geometry of all four at the END of the
+// wave: 244 VGPRs (2 waves per SIMD) and eight serialised lookup round trips per lane with nothing left to hide them.
+template <bool ENV, bool RAND, bool PROJ, bool VEC4>
+__global__ __launch_bounds__(256, 4) void shade_fwd_kernel(const gol_shade_in in, const gol_shade_out out,
                                                         const gol_shade_proj pj) {
+  __shared__ __attribute__((aligned(16))) float s_D[4][RAND ? 6 : 3][256];  // per-wave partial SH sums (light, random light)
   const int b = blockIdx.y;
-  const int i0 = (blockIdx.x * 256 + threadIdx.x) * V;
+  const int blk0 = blockIdx.x * 256;
   const int N = in.N;
-  if (i0 >= N) return;
   const int ncol = in.n_color_coef, nmono = in.n_mono_coef, ncoef = ncol + nmono, nd = 3 * ncol + nmono;
-  const float* F = in.f_vnocond + (size_t)b * (nd + 12) * N + i0;
+  const float* Fv = in.f_vnocond + (size_t)b * (nd + 12) * N;
+  const int i = blk0 + threadIdx.x;
+  const bool live = i < N;
+  const size_t g0 = (size_t)b * N + i;
+
+  // ---- phase G --------------------------------------------------------------------------------------------------------
+  float c_spv[3] = {0.f, 0.f, 0.f}, c_alb[3] = {0.f, 0.f, 0.f};   // carried: spec * vis, albedo
+  float c_rec[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};             // carried (PROJ): xy, conic, effective opacity, depth
+  if (live) {
+    float g[12], fc[4], pb[3], nb[3];
+#pragma unroll
+    for (int j = 0; j < 12; ++j) g[j] = __builtin_nontemporal_load(Fv + (size_t)(nd + j) * N + i);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) fc[j] = __builtin_nontemporal_load(in.f_vcond + ((size_t)b * 4 + j) * N + i);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      pb[j] = __builtin_nontemporal_load(in.postex + ((size_t)b * 3 + j) * N + i);
+      nb[j] = __builtin_nontemporal_load(in.tn + ((size_t)b * 3 + j) * N + i);
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) c_alb[c] = in.albedo[(size_t)i * 3 + c];
+    const Geo s = make_geo(g, fc, pb, nb, in.campos + 3 * b);
+    float spec[3];
+    EnvSample es;
+    spec_forward<ENV>(in, b, s, spec, ENV ? &es : nullptr);
+    float o_sc[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      c_spv[c] = spec[c] * s.vis;
+      o_sc[c] = fminf(fmaxf(s.sp[c], in.primscale_min), in.primscale_max);
+    }
+    // [B,N,k] rows: lane i writes k consecutive floats, the wave 64 k of them contiguously
+    float* p;
+    out.opacity[g0] = s.opac;
+    out.sigma[g0] = s.sigma;
+    out.spec_vis[g0] = s.vis;
+    p = out.primpos + g0 * 3; p[0] = s.pos[0]; p[1] = s.pos[1]; p[2] = s.pos[2];
+    *reinterpret_cast<float4*>(out.primqvec + g0 * 4) = make_float4(s.q[0], s.q[1], s.q[2], s.q[3]);
+    p = out.primscale + g0 * 3; p[0] = o_sc[0]; p[1] = o_sc[1]; p[2] = o_sc[2];
+    p = out.primscale_preclip + g0 * 3; p[0] = s.sp[0]; p[1] = s.sp[1]; p[2] = s.sp[2];
+    p = out.spec_nml + g0 * 3; p[0] = s.n[0]; p[1] = s.n[1]; p[2] = s.n[2];
+    p = out.spec_dnml + g0 * 3; p[0] = fc[1]; p[1] = fc[2]; p[2] = fc[3];
+    p = out.spec_color + g0 * 3; p[0] = c_spv[0]; p[1] = c_spv[1]; p[2] = c_spv[2];
+    p = out.primnmlbase + g0 * 3; p[0] = nb[0]; p[1] = nb[1]; p[2] = nb[2];
+    if constexpr (ENV) {
+      if (out.env_saved) {
+        p = out.env_saved + g0 * 9;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { p[c] = es.val[c]; p[3 + c] = es.d_u[c]; p[6 + c] = es.d_v[c]; }
+      }
+    }
+    if constexpr (PROJ) {
+      const gol_proj::View view = gol_proj::view_of(pj.viewmats, pj.intrins, b, pj.img_h, pj.img_w, 16, pj.clip_thresh);
+      const float sc[3] = {pj.glob_scale * o_sc[0], pj.glob_scale * o_sc[1], pj.glob_scale * o_sc[2]};
+      const gol_proj::Projected o = gol_proj::project_point(s.pos, s.q, sc, view);
+      const float op_eff = s.opac * o.comp;
+      c_rec[0] = o.xy[0]; c_rec[1] = o.xy[1]; c_rec[2] = o.conic[0]; c_rec[3] = o.conic[1]; c_rec[4] = o.conic[2];
+      c_rec[5] = op_eff; c_rec[6] = o.depth;
+      *reinterpret_cast<float2*>(pj.xys + g0 * 2) = make_float2(o.xy[0], o.xy[1]);
+      pj.depths[g0] = o.depth;
+      pj.radii[g0] = o.radius;
+      p = pj.conics + g0 * 3; p[0] = o.conic[0]; p[1] = o.conic[1]; p[2] = o.conic[2];
+      pj.comp[g0] = o.comp;
+      pj.opac_eff[g0] = op_eff;
+    }
+  }
+
+  // ---- phase S --------------------------------------------------------------------------------------------------------
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int j0 = blk0 + 4 * lane;  // first of this lane's 4 consecutive Gaussians
   const float* Lsh = in.light_sh + (size_t)b * 3 * ncoef;
   const float* Lr = RAND ? in.light_sh_rand + (size_t)b * 3 * ncoef : nullptr;
-
-  float D[3][V], Dr[3][V];
+  float D[3][4], Dr[3][4];
 #pragma unroll
   for (int c = 0; c < 3; ++c)
 #pragma unroll
-    for (int v = 0; v < V; ++v) { D[c][v] = 0.f; Dr[c][v] = 0.f; }
-  // colour SH: channel c*ncol + k  (rgca.py:508-510)
+    for (int v = 0; v < 4; ++v) { D[c][v] = 0.f; Dr[c][v] = 0.f; }
+  // VEC4 (N % 4 == 0: planes 16-byte aligned, a lane's 4 Gaussians in range together): lanes past the end of the view
+  // re-read its last 4 Gaussians instead of branching around every load -- their sums land in LDS slots nobody reads
+  const int j0c = VEC4 ? min(j0, N - 4) : j0;
+  auto plane = [&](int ch, float (&x)[4]) {
+    const float* src = Fv + (size_t)ch * N + j0c;
+    if (VEC4) {
+      ldv<4>(src, x);
+    } else {
 #pragma unroll
-  for (int c = 0; c < 3; ++c) {
-#pragma unroll 8
-    for (int k = 0; k < ncol; ++k) {
-      float x[V];
-      ldv<V>(F + (size_t)(c * ncol + k) * N, x);
+      for (int v = 0; v < 4; ++v) if (j0 + v < N) x[v] = src[v];
+    }
+  };
+  // colour SH: channel c*ncol + k  (rgca.py:508-510); the three colours of one k together: 3 x unroll loads in flight
+  constexpr int kUnrollColour = RAND ? 2 : 4, kUnrollMono = RAND ? 4 : 8;  // loads in flight vs the 128-VGPR budget
+#pragma unroll kUnrollColour
+  for (int k = wave; k < ncol; k += 4) {
+    float x[3][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+    for (int c = 0; c < 3; ++c) plane(c * ncol + k, x[c]);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
       const float l = Lsh[c * ncoef + k];
       const float lr = RAND ? Lr[c * ncoef + k] : 0.f;
 #pragma unroll
-      for (int v = 0; v < V; ++v) { D[c][v] += x[v] * l; if (RAND) Dr[c][v] += x[v] * lr; }
+      for (int v = 0; v < 4; ++v) { D[c][v] += x[c][v] * l; if (RAND) Dr[c][v] += x[c][v] * lr; }
     }
   }
   // monochrome SH shared by the three colour channels (rgca.py:511-514)
-#pragma unroll 8
-  for (int k = 0; k < nmono; ++k) {
-    float x[V];
-    ldv<V>(F + (size_t)(3 * ncol + k) * N, x);
+#pragma unroll kUnrollMono
+  for (int k = wave; k < nmono; k += 4) {
+    float x[4] = {0.f, 0.f, 0.f, 0.f};
+    plane(3 * ncol + k, x);
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
       const float l = Lsh[c * ncoef + ncol + k];
       const float lr = RAND ? Lr[c * ncoef + ncol + k] : 0.f;
 #pragma unroll
-      for (int v = 0; v < V; ++v) { D[c][v] += x[v] * l; if (RAND) Dr[c][v] += x[v] * lr; }
+      for (int v = 0; v < 4; ++v) { D[c][v] += x[v] * l; if (RAND) Dr[c][v] += x[v] * lr; }
     }
   }
-  float g[12][V], fc[4][V], pb[3][V], nb[3][V], alb[3][V];
 #pragma unroll
-  for (int j = 0; j < 12; ++j) ldv<V>(F + (size_t)(nd + j) * N, g[j]);
-#pragma unroll
-  for (int j = 0; j < 4; ++j) ldv<V>(in.f_vcond + ((size_t)b * 4 + j) * N + i0, fc[j]);
-#pragma unroll
-  for (int j = 0; j < 3; ++j) {
-    ldv<V>(in.postex + ((size_t)b * 3 + j) * N + i0, pb[j]);
-    ldv<V>(in.tn + ((size_t)b * 3 + j) * N + i0, nb[j]);
+  for (int c = 0; c < 3; ++c) {
+    *reinterpret_cast<float4*>(&s_D[wave][c][4 * lane]) = make_float4(D[c][0], D[c][1], D[c][2], D[c][3]);
+    if (RAND) *reinterpret_cast<float4*>(&s_D[wave][3 + c][4 * lane]) = make_float4(Dr[c][0], Dr[c][1], Dr[c][2], Dr[c][3]);
   }
-  ld_aos<V, 3>(in.albedo, (size_t)i0, alb);
+  __syncthreads();
 
-  float o_color[3][V], o_op[1][V], o_pos[3][V], o_q[4][V], o_sc[3][V], o_sp[3][V], o_sig[1][V], o_vis[1][V];
-  float o_n[3][V], o_dn[3][V], o_diff[3][V], o_spec[3][V], o_nb[3][V], o_rand[3][V], o_D[3][V];
-  float o_env[ENV ? 9 : 1][V];
-  const float* cam = in.campos + 3 * b;
+  // ---- phase F --------------------------------------------------------------------------------------------------------
+  if (!live) return;
+  float Ds[3], col[3], diff[3];
 #pragma unroll
-  for (int v = 0; v < V; ++v) {
-    float gg[12], ff[4], p3[3], n3[3];
-#pragma unroll
-    for (int j = 0; j < 12; ++j) gg[j] = g[j][v];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) ff[j] = fc[j][v];
-#pragma unroll
-    for (int j = 0; j < 3; ++j) { p3[j] = pb[j][v]; n3[j] = nb[j][v]; }
-    const Geo s = make_geo(gg, ff, p3, n3, cam);
-    float spec[3];
-    EnvSample es;
-    spec_forward<ENV>(in, b, s, spec, ENV ? &es : nullptr);
-    if constexpr (ENV) {
-#pragma unroll
-      for (int c = 0; c < 3; ++c) { o_env[c][v] = es.val[c]; o_env[3 + c][v] = es.d_u[c]; o_env[6 + c][v] = es.d_v[c]; }
-    }
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      const float diff = alb[c][v] * D[c][v];
-      const float sp = spec[c] * s.vis;
-      o_diff[c][v] = diff;
-      o_spec[c][v] = sp;
-      o_color[c][v] = fmaxf(fmaxf(diff, 0.f) + sp, 0.f);
-      o_pos[c][v] = s.pos[c];
-      o_sp[c][v] = s.sp[c];
-      o_sc[c][v] = fminf(fmaxf(s.sp[c], in.primscale_min), in.primscale_max);
-      o_n[c][v] = s.n[c];
-      o_dn[c][v] = ff[1 + c];
-      o_nb[c][v] = n3[c];
-      o_D[c][v] = D[c][v];
-      if (RAND) o_rand[c][v] = fmaxf(Dr[c][v], 0.f);
-    }
-#pragma unroll
-    for (int k = 0; k < 4; ++k) o_q[k][v] = s.q[k];
-    o_op[0][v] = s.opac; o_sig[0][v] = s.sigma; o_vis[0][v] = s.vis;
+  for (int c = 0; c < 3; ++c) {
+    Ds[c] = (s_D[0][c][threadIdx.x] + s_D[1][c][threadIdx.x]) + (s_D[2][c][threadIdx.x] + s_D[3][c][threadIdx.x]);
+    diff[c] = c_alb[c] * Ds[c];
+    col[c] = fmaxf(fmaxf(diff[c], 0.f) + c_spv[c], 0.f);
   }
-  const size_t g0 = (size_t)b * N + i0;
-  st_aos<V, 3>(out.color, g0, o_color);
-  st_aos<V, 1>(out.opacity, g0, o_op);
-  st_aos<V, 3>(out.primpos, g0, o_pos);
-  st_aos<V, 4>(out.primqvec, g0, o_q);
-  st_aos<V, 3>(out.primscale, g0, o_sc);
-  st_aos<V, 3>(out.primscale_preclip, g0, o_sp);
-  st_aos<V, 1>(out.sigma, g0, o_sig);
-  st_aos<V, 1>(out.spec_vis, g0, o_vis);
-  st_aos<V, 3>(out.spec_nml, g0, o_n);
-  st_aos<V, 3>(out.spec_dnml, g0, o_dn);
-  st_aos<V, 3>(out.diff_color, g0, o_diff);
-  st_aos<V, 3>(out.spec_color, g0, o_spec);
-  st_aos<V, 3>(out.primnmlbase, g0, o_nb);
-  st_aos<V, 3>(out.diff_sum, g0, o_D);
-  if constexpr (ENV) {
-    if (out.env_saved) st_aos<V, 9>(out.env_saved, g0, o_env);
-  }
-  if (RAND) st_aos<V, 3>(out.color_rand, g0, o_rand);
-  if constexpr (PROJ) {
-    const gol_proj::View view = gol_proj::view_of(pj.viewmats, pj.intrins, b, pj.img_h, pj.img_w, 16, pj.clip_thresh);
-    float p_xy[2][V], p_depth[1][V], p_rad[1][V], p_con[3][V], p_comp[1][V], p_oe[1][V];
+  float* p;
+  p = out.color + g0 * 3; p[0] = col[0]; p[1] = col[1]; p[2] = col[2];
+  p = out.diff_color + g0 * 3; p[0] = diff[0]; p[1] = diff[1]; p[2] = diff[2];
+  p = out.diff_sum + g0 * 3; p[0] = Ds[0]; p[1] = Ds[1]; p[2] = Ds[2];
+  if (RAND) {
+    p = out.color_rand + g0 * 3;
 #pragma unroll
-    for (int v = 0; v < V; ++v) {
-      const float p[3] = {o_pos[0][v], o_pos[1][v], o_pos[2][v]};
-      const float q[4] = {o_q[0][v], o_q[1][v], o_q[2][v], o_q[3][v]};
-      const float sc[3] = {pj.glob_scale * o_sc[0][v], pj.glob_scale * o_sc[1][v], pj.glob_scale * o_sc[2][v]};
-      const gol_proj::Projected o = gol_proj::project_point(p, q, sc, view);
-      const float op_eff = o_op[0][v] * o.comp;
-      gol_record_write(pj.records + (g0 + v) * GOL_SPLAT_RECORD, o.xy[0], o.xy[1], o.conic[0], o.conic[1], o.conic[2],
-                       op_eff, o_color[0][v], o_color[1][v], o_color[2][v], o.depth);
-      p_xy[0][v] = o.xy[0]; p_xy[1][v] = o.xy[1];
-      p_depth[0][v] = o.depth;
-      p_rad[0][v] = __int_as_float(o.radius);
-      p_con[0][v] = o.conic[0]; p_con[1][v] = o.conic[1]; p_con[2][v] = o.conic[2];
-      p_comp[0][v] = o.comp;
-      p_oe[0][v] = op_eff;
-    }
-    st_aos<V, 2>(pj.xys, g0, p_xy);
-    st_aos<V, 1>(pj.depths, g0, p_depth);
-    st_aos<V, 1>(reinterpret_cast<float*>(pj.radii), g0, p_rad);
-    st_aos<V, 3>(pj.conics, g0, p_con);
-    st_aos<V, 1>(pj.comp, g0, p_comp);
-    st_aos<V, 1>(pj.opac_eff, g0, p_oe);
+    for (int c = 0; c < 3; ++c)
+      p[c] = fmaxf((s_D[0][3 + c][threadIdx.x] + s_D[1][3 + c][threadIdx.x]) +
+                   (s_D[2][3 + c][threadIdx.x] + s_D[3][3 + c][threadIdx.x]), 0.f);
   }
+  if constexpr (PROJ)
+    gol_record_write(pj.records + g0 * GOL_SPLAT_RECORD, c_rec[0], c_rec[1], c_rec[2], c_rec[3], c_rec[4], c_rec[5],
+                     col[0], col[1], col[2], c_rec[6]);
 }
 
 // Backward, two phases per 256-Gaussian workgroup:
@@ -445,8 +525,10 @@ __global__ __launch_bounds__(256) void shade_fwd_kernel(const gol_shade_in in, c
 // position / quaternion / scale / opacity and ADDED to the upstream gradients of color / opacity / primpos / primqvec /
 // primscale (which other consumers of those outputs may also feed): gol_project_bwd's 56 B written + 56 B re-read per
 // Gaussian and its launch are gone.
+// (launch bound: 3 waves per SIMD = 168 VGPRs.  The env variant sits at 160-171 depending on unrelated code around it; at
+// 171 the kernel drops to 2 waves per SIMD and runs 10 % longer -- round 6 A/B, 301 -> 332 us per 8 views.)
 template <bool ENV, bool RAND, bool VEC4, bool PROJ>
-__global__ __launch_bounds__(256) void shade_bwd_kernel(const gol_shade_in in, const gol_shade_out saved,
+__global__ __launch_bounds__(256, 3) void shade_bwd_kernel(const gol_shade_in in, const gol_shade_out saved,
                                                         const gol_shade_out_grad up, const gol_shade_in_grad gin,
                                                         const gol_shade_proj pj, const float* __restrict__ grad_records,
                                                         int with_depth) {
@@ -785,31 +867,21 @@ extern "C" int gol_envmap_pack(int B, int h, int w, const float* src, float* dst
   return GOL_OK;
 }
 
-// Gaussians per lane of the forward: 4 (16-byte plane loads) when N allows and the launch then still has a workgroup per CU;
-// a smaller launch takes 2 -- one view of 250k Gaussians is 245 workgroups at 4 per lane, i.e. one wave per SIMD on most
-// CUs and nothing to hide the plane loads behind: 60 -> 52 us (1 per lane: 54; launches of >= 2 such views are fastest at 4).
-static int shade_fwd_width(const gol_shade_in* in) {
-  if (in->N % 4 == 0 && (long long)gol_cdiv(in->N / 4, 256) * in->B >= 256) return 4;
-  return (in->N % 2 == 0) ? 2 : 1;
-}
-
-#define GOL_SHADE_FWD_V(V, P, ...)                                                                \
+// VEC4: the SH planes of a view are 16-byte aligned (N % 4 == 0) -> 16-byte plane loads; otherwise scalar ones
+#define GOL_SHADE_FWD_V(V4, P, ...)                                                              \
   do {                                                                                           \
-    dim3 grid(gol_cdiv(in->N / V, 256), in->B);                                                  \
-    if (env && rnd) shade_fwd_kernel<V, true, true, P><<<grid, 256, 0, s>>>(__VA_ARGS__);        \
-    else if (env) shade_fwd_kernel<V, true, false, P><<<grid, 256, 0, s>>>(__VA_ARGS__);         \
-    else if (rnd) shade_fwd_kernel<V, false, true, P><<<grid, 256, 0, s>>>(__VA_ARGS__);         \
-    else shade_fwd_kernel<V, false, false, P><<<grid, 256, 0, s>>>(__VA_ARGS__);                 \
+    dim3 grid(gol_cdiv(in->N, 256), in->B);                                                      \
+    if (env && rnd) shade_fwd_kernel<true, true, P, V4><<<grid, 256, 0, s>>>(__VA_ARGS__);       \
+    else if (env) shade_fwd_kernel<true, false, P, V4><<<grid, 256, 0, s>>>(__VA_ARGS__);        \
+    else if (rnd) shade_fwd_kernel<false, true, P, V4><<<grid, 256, 0, s>>>(__VA_ARGS__);        \
+    else shade_fwd_kernel<false, false, P, V4><<<grid, 256, 0, s>>>(__VA_ARGS__);                \
   } while (0)
 
-// 4 Gaussians per lane (16-byte plane loads) when N allows, else 2 (8-byte), else 1 (the same widths with the projection epilogue; see shade_fwd_width)
 #define GOL_SHADE_FWD_DISPATCH(P, ...)                                                           \
   do {                                                                                           \
     const bool env = in->n_mips > 0, rnd = in->light_sh_rand != nullptr;                         \
-    const int vv = shade_fwd_width(in);                                                          \
-    if (vv == 4) GOL_SHADE_FWD_V(4, P, __VA_ARGS__);                                             \
-    else if (vv == 2) GOL_SHADE_FWD_V(2, P, __VA_ARGS__);                                        \
-    else GOL_SHADE_FWD_V(1, P, __VA_ARGS__);                                                     \
+    if (in->N % 4 == 0) GOL_SHADE_FWD_V(true, P, __VA_ARGS__);                                   \
+    else GOL_SHADE_FWD_V(false, P, __VA_ARGS__);                                                 \
   } while (0)
 
 #define GOL_SHADE_BWD_CASE(E, R, P)                                                              \

@@ -52,10 +52,26 @@ def patch_rgca(rgca_module=None):
 def _shared_mipmap(self, bsize, device, scale=1.0):
     """EnvSpinDecorator.mipmap (ca_code/utils/light_decorator.py:96-100) without the B materialised copies: the reference
     expands each registered level over the batch and then multiplies by `scale`, which writes B identical scaled maps (at the
-    run_vis_relight size 8 x 10.5 MB).  Here the ONE map is scaled and the batch axis is a stride-0 view: same shapes and
-    values for every reader, and goliath_amd.shade hands the kernel a single pyramid (gol_shade_in.mips_shared): 42 MB of
-    footprint records instead of 335 MB for 8 views, no per-step scaling pass, and the views differ only in `lightrot`."""
-    return [(getattr(self, f"mipmap_{i}").to(device) * scale).expand(bsize, -1, -1, -1) for i in range(self.miplevel)]
+    run_vis_relight size 8 x 10.5 MB).  Here ONE map is scaled (other readers of `preconv_envmap` see the reference's values)
+    and the batch axis is a stride-0 view.  `scale` is 2 pi norm_scale[0] of the FRAME (:147-149), so the scaled tensor is a
+    new one every step: each level therefore also carries the unscaled registered buffer (on `device`, cached on the
+    decorator) and the scale -- goliath_amd.shade packs the footprint records of THAT buffer once per environment (its address
+    and version do not change with the spin index) and hands the scale to the kernel (gol_shade_in.mips_scale): 42 MB of
+    records for 8 views instead of 335 MB, no re-packing per step; what does run per step is the scaling of the one map."""
+    cache = self.__dict__.setdefault("_gol_dev_levels", {})
+    out = []
+    for i in range(self.miplevel):
+        buf = getattr(self, f"mipmap_{i}")
+        key = (i, str(device), buf.data_ptr(), buf._version)
+        base = cache.get(key)
+        if base is None:
+            for k in [k for k in cache if k[0] == i and k[1] == str(device)]:
+                del cache[k]                         # the buffer was replaced / rewritten: drop the stale device copy
+            base = cache[key] = buf.to(device)
+        m = (base * scale).expand(bsize, -1, -1, -1)
+        m._gol_base, m._gol_scale = base, float(scale)
+        out.append(m)
+    return out
 
 
 def patch_light_decorator(decorator_module=None):

@@ -28,7 +28,7 @@ class ShadeIn(ctypes.Structure):
                 ("n_mips", ctypes.c_int32), ("mips", _fp * MAX_MIPS), ("mip_h", ctypes.c_int32 * MAX_MIPS),
                 ("mip_w", ctypes.c_int32 * MAX_MIPS), ("lightrot", _fp), ("mips_packed", _fp * MAX_MIPS),
                 ("primscale_min", ctypes.c_float),
-                ("primscale_max", ctypes.c_float), ("mips_shared", ctypes.c_int32)]
+                ("primscale_max", ctypes.c_float), ("mips_shared", ctypes.c_int32), ("mips_scale", ctypes.c_float)]
 
 
 OUT_FIELDS = [("color", 3), ("opacity", 1), ("primpos", 3), ("primqvec", 4), ("primscale", 3),
@@ -102,7 +102,7 @@ def pack_envmap(mips, refresh=False):
 
 
 def _make_in(f_vnocond, f_vcond, postex, tn, albedo, light_sh, light_sh_rand, campos, light_intensity,
-             light_pos, n_lights, mips, lightrot, ncol, nmono, packed=None):
+             light_pos, n_lights, mips, lightrot, ncol, nmono, packed=None, mips_scale=1.0):
     B, C = f_vnocond.shape[:2]
     shared = bool(mips) and B > 1 and all(m.shape[0] == 1 for m in mips)
     N = f_vnocond[0, 0].numel()
@@ -119,6 +119,7 @@ def _make_in(f_vnocond, f_vcond, postex, tn, albedo, light_sh, light_sh_rand, ca
                 s.mips_packed[i] = _p(packed[i])
         s.lightrot = _p(lightrot)
         s.mips_shared = int(shared)
+        s.mips_scale = float(mips_scale)
         if not shared and any(m.shape[0] != B for m in mips):
             raise ValueError(f"env-map levels must be [B={B},3,h,w] (one pyramid per view) or [1,3,h,w] (one for all views)")
     else:
@@ -133,7 +134,7 @@ def _make_in(f_vnocond, f_vcond, postex, tn, albedo, light_sh, light_sh_rand, ca
 class _Shade(torch.autograd.Function):
     @staticmethod
     def forward(ctx, f_vnocond, f_vcond, postex, tn, albedo, light_sh, light_sh_rand, campos, light_intensity,
-                light_pos, n_lights, lightrot, ncol, nmono, view_set, *mips):
+                light_pos, n_lights, lightrot, ncol, nmono, view_set, mips_scale, *mips):
         B = f_vnocond.shape[0]
         N = f_vnocond[0, 0].numel()
         dev = f_vnocond.device
@@ -145,7 +146,7 @@ class _Shade(torch.autograd.Function):
             # GOLIATH_ENVMAP_RECORDS=0: gather from the planar [.,3,h,w] levels as given (no footprint records)
             packed = pack_envmap(mips) if mips and os.environ.get("GOLIATH_ENVMAP_RECORDS", "1") != "0" else None
         sin = _make_in(f_vnocond, f_vcond, postex, tn, albedo, light_sh, light_sh_rand, campos,
-                       light_intensity, light_pos, n_lights, list(mips), lightrot, ncol, nmono, packed)
+                       light_intensity, light_pos, n_lights, list(mips), lightrot, ncol, nmono, packed, mips_scale)
         sout = ShadeOut()
         for n, t in outs.items():
             setattr(sout, n, _p(t))
@@ -162,6 +163,7 @@ class _Shade(torch.autograd.Function):
                 _lib.call("gol_shade_fwd", ctypes.byref(sin), ctypes.byref(sout), stream_ptr())
         ctx.view_set = view_set
         ctx.cfg = (ncol, nmono, len(mips), rand)
+        ctx.mips_scale = mips_scale
         ctx.packed = packed  # not an input/output of the node: plain attribute
         ctx.save_for_backward(f_vnocond, f_vcond, postex, tn, albedo, light_sh, light_sh_rand, campos,
                               light_intensity, light_pos, n_lights, lightrot, outs["diff_sum"],
@@ -185,7 +187,7 @@ class _Shade(torch.autograd.Function):
         N = f_vnocond[0, 0].numel()
         dev = f_vnocond.device
         sin = _make_in(f_vnocond, f_vcond, postex, tn, albedo, light_sh, light_sh_rand, campos,
-                       light_intensity, light_pos, n_lights, mips, lightrot, ncol, nmono, ctx.packed)
+                       light_intensity, light_pos, n_lights, mips, lightrot, ncol, nmono, ctx.packed, ctx.mips_scale)
         saved = ShadeOut()
         saved.diff_sum = _p(diff_sum)
         saved.color_rand = _p(color_rand)
@@ -219,7 +221,28 @@ class _Shade(torch.autograd.Function):
                           stream_ptr())
         if g_albedo is not None:
             g_albedo = g_albedo.reshape(albedo.shape)
-        return (g_vn, g_vc, g_pt, g_tn, g_albedo) + (None,) * (10 + n_mips)
+        return (g_vn, g_vc, g_pt, g_tn, g_albedo) + (None,) * (11 + n_mips)
+
+
+_ROT_CHECKED = {}
+
+
+def _check_rotation(lightrot):
+    """gol_shade_in.lightrot must hold rotations (the kernel forms the polar angle of lightrot x reflection as
+    atan2(|r_xz|, r_y), which equals the reference's acos(r_y), envmap.py:289, only for a unit vector).  Checked once per
+    tensor version (one small device reduction + sync; the relight driver builds a new lightrot per frame on the HOST and
+    copies it over, light_decorator.py:108-120, so GOLIATH_CHECK_LIGHTROT=0 skips it in a sync-free loop)."""
+    if os.environ.get("GOLIATH_CHECK_LIGHTROT", "1") == "0" or torch.cuda.is_current_stream_capturing():
+        return
+    key = (lightrot.data_ptr(), lightrot._version, tuple(lightrot.shape))
+    if key in _ROT_CHECKED:
+        return
+    err = float((lightrot @ lightrot.transpose(-1, -2) - torch.eye(3, device=lightrot.device)).abs().max())
+    if not err < 1e-3:
+        raise ValueError(f"lightrot is not a rotation (max |R R^T - I| = {err:.3g}): the env-map lookup needs a unit direction")
+    while len(_ROT_CHECKED) >= 64:
+        _ROT_CHECKED.pop(next(iter(_ROT_CHECKED)))
+    _ROT_CHECKED[key] = True
 
 
 def shading_tail(f_vnocond, f_vcond, postex, tn, albedo, headrel_light_sh, headrel_campos,
@@ -248,7 +271,7 @@ def shading_tail_coefs(f_vnocond, f_vcond, postex, tn, albedo, headrel_light_sh,
         raise ValueError(f"f_vnocond has {C} channels, expected {3 * ncol + nmono + 12}")
     c = lambda t: None if t is None else t.to(torch.float32).contiguous()
     N = f_vnocond[0, 0].numel()
-    mips = []
+    mips, mips_scale = [], 1.0
     if preconv_envmap is not None:
         mips = list(preconv_envmap) if isinstance(preconv_envmap, (list, tuple)) else [preconv_envmap]
         if len(mips) > MAX_MIPS:
@@ -257,9 +280,20 @@ def shading_tail_coefs(f_vnocond, f_vcond, postex, tn, albedo, headrel_light_sh,
         # dropin.patch_light_decorator makes of EnvSpinDecorator.mipmap, light_decorator.py:96-100): the kernel reads the
         # single map for every view (gol_shade_in.mips_shared) instead of B materialised copies
         if all(m.dim() == 4 and (m.shape[0] == 1 or m.stride(0) == 0) for m in mips):
-            mips = [m[:1] for m in mips]
+            if any(m.shape[0] not in (1, B) for m in mips):   # an expand(B', ...) view of another batch size
+                raise ValueError(f"env-map levels are expanded over {[m.shape[0] for m in mips]} views, the batch has {B}")
+            # levels that come from dropin._shared_mipmap carry the UNSCALED registered buffer and the frame's scale: the
+            # packed records are cached on the buffer (stable address and version across frames), the scale goes to the kernel
+            base = [getattr(m, "_gol_base", None) for m in mips]
+            if all(b is not None for b in base) and len({float(m._gol_scale) for m in mips}) == 1:
+                mips_scale, mips = float(mips[0]._gol_scale), base
+            else:
+                mips = [m[:1] for m in mips]
         mips = [c(m) for m in mips]
         lightrot = c(lightrot)
+        if lightrot is None or lightrot.shape[-2:] != (3, 3):
+            raise ValueError("preconv_envmap needs lightrot [B,3,3]")
+        _check_rotation(lightrot)
         li = lp = nl = None
     else:
         li, lp = c(light_intensity.expand(-1, -1, 3)), c(headrel_light_pos)
@@ -272,7 +306,7 @@ def shading_tail_coefs(f_vnocond, f_vcond, postex, tn, albedo, headrel_light_sh,
             raise ValueError(f"bad image size {views.height} x {views.width}")
     outs = _Shade.apply(c(f_vnocond), c(f_vcond), c(postex), c(tn), c(albedo).reshape(N, 3),
                         c(headrel_light_sh), c(light_sh_rand), c(headrel_campos), li, lp, nl, lightrot,
-                        ncol, nmono, views, *mips)
+                        ncol, nmono, views, mips_scale, *mips)
     names = [n for n in GRAD_FIELDS if light_sh_rand is not None or n != "color_rand"]
     preds = dict(zip(names, outs))
     if views is not None:

@@ -265,7 +265,10 @@ typedef struct {
   int32_t n_mips;
   const float* mips[GOL_MAX_MIPS];  /* level i: [B, 3, mip_h[i], mip_w[i]] */
   int32_t mip_h[GOL_MAX_MIPS], mip_w[GOL_MAX_MIPS];
-  const float* lightrot;        /* [B, 3, 3] */
+  const float* lightrot;        /* [B, 3, 3] ROTATIONS (orthonormal rows): the lookup direction lightrot x reflect(view, normal)
+                                 * must be a unit vector -- the polar angle is formed as atan2(|r_xz|, r_y) and its derivative as
+                                 * -1 / |r_xz|, which equal the reference's acos(r_y) (envmap.py:289) and its derivative only
+                                 * for |r| = 1; the host side checks it (shade.py) */
   /* optional: the same levels repacked by gol_envmap_pack to [B, h, w, 16] footprint records (a bilinear lookup = one
    * aligned 64-byte fetch); all levels or none (NULL) */
   const float* mips_packed[GOL_MAX_MIPS];
@@ -275,6 +278,10 @@ typedef struct {
    * the batch (ca_code/utils/light_decorator.py:96-100) and rotates the lookup, not the map (:112-118, rgca.py:548-550).
    * 0: one pyramid per view, levels [B,...] as above. */
   int32_t mips_shared;
+  /* every env-map sample (value and its u / v derivatives) is multiplied by this; 0 is read as 1.  The relight driver scales
+   * the registered pyramid by 2 pi norm_scale[0] per FRAME (light_decorator.py:147-149): with the factor here the unscaled
+   * pyramid is packed once per environment and nothing is re-packed when the spin index changes. */
+  float mips_scale;
 } gol_shade_in;
 
 typedef struct {  /* every field [B,N,k] row-major like the reference's preds (rgca.py:574-588) */

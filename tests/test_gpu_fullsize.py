@@ -22,9 +22,12 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 TOL = 1e-4           # north_star: within 1e-4 L2 -- outputs AND gradients
-# all-Gaussian cap on every gradient tensor incl. its explained outliers (measured: config 2 <= 1.25e-3; config 1, 10 k
-# Gaussians, <= 2.75e-2 -- all of it from 8 Gaussians under flip pixels)
-ALL_CAP = {"config2": 3e-3, "config1": 5e-2}
+# all-Gaussian cap on every gradient tensor incl. its explained outliers, ~3x what is measured (round 5/6: config 2 <= 7.8e-4;
+# config 1, 10 k Gaussians, <= 4.7e-4 -- two near-pole Gaussians.  A flip pixel under config 1's few Gaussians can put
+# percents on a tensor -- round 3 saw 2.75e-2 from 8 Gaussians: if the cap trips with every member of W flip-explained,
+# say so in the failure instead of loosening the cap)
+ALL_CAP = {"config2": 2.5e-3, "config1": 1.5e-3}
+UNFLAGGED_BAR = 2e-4  # rel-L2 over the Gaussians no predicate flags (measured in round 6: see profiles/r06_fullsize_parity.json)
 MAX_EXPLAINED = 2e-3  # at most this fraction of the Gaussians may need an explanation (measured: ~1e-4)
 LEAVES = ("f_vn", "f_vc", "postex", "tn", "albedo")
 STAGE = ("color", "opacity", "primpos", "primscale", "primqvec")
@@ -222,14 +225,22 @@ def test_bench_step_matches_oracle_chain(name):
     report["tolerance"] = TOL
     failures = []
 
-    def judge(kind, k, a, b, allowed, b64=None, pole=None):
+    def judge(kind, k, a, b, allowed, b64=None, pole=None, exk=None):
         """a, b: [B, C, N].  Remove the smallest worst set W that brings the rest under TOL; every member must be explained.
         ADVICE r3: position alone (`pole`, 2 % of all directions) excuses nothing -- near-pole members of W are explained only
         while HIP is as close to the fp64 evaluation over the WHOLE near-pole class as the fp32 oracle is; and an
         all-Gaussian cap bounds what the explained outliers may add up to."""
         W_idx, all_rel, rest_rel = _worst_set(a, b, TOL)
-        by = {kk: int(ex[kk][W_idx].sum()) for kk in ex}
+        exk = ex if exk is None else exk   # predicate vectors in THIS tensor's Gaussian indexing (albedo: any view)
+        by = {kk: int(exk[kk][W_idx].sum()) for kk in exk}
         allowed_in = allowed
+        # the honest pair of numbers (VERDICT r5 weak 1): rel-L2 over ALL Gaussians, and over the Gaussians that NO a-priori
+        # predicate flags -- flip / border / kink, + the near-pole class for the leaves (all evaluated on the oracle's data
+        # before HIP's gradients are looked at; NOT the worst-k, whose remainder is < TOL by construction)
+        flagged = allowed if pole is None else (allowed | pole)
+        e2 = (a.double().cpu() - b.double().cpu()).pow(2).sum(1).flatten()
+        r2 = b.double().cpu().pow(2).sum(1).flatten()
+        rel_unflagged = float((e2[~flagged].sum() / r2[~flagged].sum().clamp(min=1e-300)).sqrt())
         if b64 is not None:   # fp64 predicate: the fp32 oracle's own distance from its fp64 evaluation, per Gaussian
             e_h = (a.double().cpu() - b.double().cpu()).pow(2).sum(1).flatten()
             e_o = (b.double().cpu() - b64.double().cpu()).pow(2).sum(1).flatten()
@@ -263,7 +274,9 @@ def test_bench_step_matches_oracle_chain(name):
             report.setdefault("fp32_oracle_vs_fp64_oracle_rel_l2", {})[k] = float(
                 (e_o.sum() / b64.double().pow(2).sum()).sqrt())
         unexplained = int((~allowed[W_idx]).sum())
-        report.setdefault(kind, {})[k] = {"rel_l2_all_gaussians": all_rel, "rel_l2_without_W": rest_rel,
+        report.setdefault(kind, {})[k] = {"rel_l2_all_gaussians": all_rel, "rel_l2_without_flagged": rel_unflagged,
+                                          "flagged_fraction": float(flagged.float().mean()),
+                                          "rel_l2_without_W": rest_rel,
                                           "W_size": int(W_idx.numel()), "W_fraction": W_idx.numel() / (B * N),
                                           "W_explained_by": by, "W_unexplained": unexplained}
         if unexplained:   # diagnostics of the unexplained members (oracle data)
@@ -278,7 +291,10 @@ def test_bench_step_matches_oracle_chain(name):
                     info.update({kk: float(vv[g]) for kk, vv in view_diag[vb].items()})
                 det.append(info)
             report[kind][k]["unexplained_examples"] = det
-        if unexplained or rest_rel > TOL or W_idx.numel() > MAX_EXPLAINED * B * N or all_rel > ALL_CAP[name]:
+        # the un-flagged 80 % of the Gaussians carry no discontinuity by construction of the predicates: they must agree
+        # to the bar outright (what remains there is the fp64-conditioning class, measured <= 1e-4)
+        if (unexplained or rest_rel > TOL or W_idx.numel() > MAX_EXPLAINED * B * N or all_rel > ALL_CAP[name]
+                or rel_unflagged > UNFLAGGED_BAR):
             failures.append((kind, k, report[kind][k]))
 
     for b in range(B):   # per-Gaussian relative error of the stage gradients (diagnostics of the leaf outliers)
@@ -294,8 +310,11 @@ def test_bench_step_matches_oracle_chain(name):
             # shared by the B views: a texel is explained if it is in ANY view
             ref = torch.stack(ref_grads[k]).sum(0)                                              # [1, N, 3]
             ref64 = torch.stack(ref_grads64[k]).sum(0)
+            # (no pole yardstick: the albedo gradient is D x upstream and does not depend on the lookup direction; both
+            # distances from fp64 are rounding noise, ~1e-11 -- the row said `ok: false` on a zero-vs-zero comparison)
             judge("grads", k, mb[k].grad.reshape(1, N, 3).transpose(1, 2), ref.reshape(1, N, 3).transpose(1, 2),
-                  ex_any.reshape(B, N).any(0), ref64.reshape(1, N, 3).transpose(1, 2), ex["pole"].reshape(B, N).any(0))
+                  ex_any.reshape(B, N).any(0), ref64.reshape(1, N, 3).transpose(1, 2), None,
+                  exk={kk: v.reshape(B, N).any(0) for kk, v in ex.items()})
             report["grads"][k]["W_fraction"] = report["grads"][k]["W_size"] / N
             continue
         ref = torch.cat(ref_grads[k], 0)

@@ -37,7 +37,7 @@ GOLD_PATH = os.path.join(os.path.dirname(__file__), "golden", "rgca_model_golden
 #   * SG lobes of sigma >= 0.05 (at the 0.01 floor two fp32 evaluations of exp(-angle^2 / 2 sigma^2) differ by 1e-3);
 #   * the weight-norm denominator of the generator in fp64 (torch's CPU fp32 norm of 4 M elements is 9.5e-5 off; the GPU's is
 #     not), and the camera / light tensors that come out of LAPACK / BLAS stored in the fixture.
-BAR_PER_GAUSSIAN, BAR_IMAGE, BAR_GRAD = 3e-5, 5e-5, 2e-4
+BAR_PER_GAUSSIAN, BAR_IMAGE, BAR_GRAD = 3e-5, 5e-5, 1e-4  # gradients: north_star's bar (measured 7.7e-5)
 
 
 def _gold():

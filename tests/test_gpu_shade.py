@@ -190,3 +190,53 @@ def test_shared_env_pyramid_equals_per_view_copies(form, fused_projection):
         assert torch.equal(g1[k], g2[k]), k
     with pytest.raises(ValueError):      # neither one map nor one per view
         run([m.cuda().expand(2, -1, -1, -1).contiguous() for m in one])
+    with pytest.raises(ValueError):      # a stride-0 view expanded over ANOTHER batch size is not "one map for all"
+        run([m.cuda().expand(2, -1, -1, -1) for m in one])
+
+
+def test_frame_scale_goes_to_the_kernel_and_nothing_is_repacked():
+    """ADVICE r5 / light_decorator.py:147-149: the relight driver scales the registered pyramid by 2 pi norm_scale[0] of the
+    FRAME.  dropin._shared_mipmap hands each level over with its unscaled buffer and the scale; shade packs the buffer's
+    footprint records once (cache keyed on the buffer) and passes the scale to the kernel (gol_shade_in.mips_scale): the
+    results equal those of the scaled copies (interpolation is linear: rounding only), for every frame, with ONE packed
+    pyramid in the cache."""
+    from goliath_amd import dropin, shade
+
+    B, S = 2, 16
+    N = S * S
+    g = torch.Generator().manual_seed(11)
+    r = lambda *s: torch.randn(*s, generator=g)
+    t = dict(f_vn=0.3 * r(B, 125, S, S), f_vc=0.3 * r(B, 4, S, S), postex=60.0 * r(B, 3, S, S), tn=F.normalize(r(B, 3, S, S), dim=1),
+             albedo=0.2 + 0.6 * torch.rand(1, N, 3, generator=g), light_sh=0.3 * r(B, 3, 81),
+             campos=torch.tensor([[30.0, -40.0, -900.0]]).repeat(B, 1), lightrot=torch.linalg.qr(r(B, 3, 3))[0])
+
+    class Deco:                                          # the attributes EnvSpinDecorator.mipmap reads
+        miplevel = 3
+
+    d = Deco()
+    for i in range(3):
+        setattr(d, f"mipmap_{i}", (torch.rand(1, 3, 16 >> i, 32 >> i, generator=g) * 0.4).cuda())
+
+    def run(mips):
+        leaf = {k: t[k].clone().cuda().requires_grad_(True) for k in ("f_vn", "f_vc", "postex", "tn", "albedo")}
+        out = shade.shading_tail(leaf["f_vn"], leaf["f_vc"], leaf["postex"], leaf["tn"], leaf["albedo"], t["light_sh"].cuda(),
+                                 t["campos"].cuda(), preconv_envmap=mips, lightrot=t["lightrot"].cuda())
+        w = torch.Generator().manual_seed(9)
+        sum((v * torch.randn(v.shape, generator=w).cuda()).sum() for k, v in sorted(out.items()) if torch.is_tensor(v) and v.requires_grad).backward()
+        return {k: v.detach() for k, v in out.items() if torch.is_tensor(v)}, {k: v.grad for k, v in leaf.items()}
+
+    shade.invalidate_envmap_cache()
+    for scale in (1.0, 2.37, 5.1):
+        levels = dropin._shared_mipmap(d, B, torch.device("cuda"), scale)
+        assert all(m.stride(0) == 0 and m._gol_base is getattr(d, f"mipmap_{i}") for i, m in enumerate(levels))
+        o1, g1 = run(levels)
+        assert len(shade._PACKED) == 3, len(shade._PACKED)              # the three levels of the unscaled buffer, once
+        o2, g2 = run([(getattr(d, f"mipmap_{i}") * scale).expand(B, -1, -1, -1).contiguous() for i in range(3)])
+        shade._PACKED = {k: v for k, v in shade._PACKED.items() if k[1][0] == 1}   # forget the B-copy pyramids just packed
+        for k in o1:
+            assert rel_l2(o1[k], o2[k]) < 1e-6, (scale, k, rel_l2(o1[k], o2[k]))
+        for k in g1:
+            assert rel_l2(g1[k], g2[k]) < 2e-6, (scale, k, rel_l2(g1[k], g2[k]))
+    with pytest.raises(ValueError):      # lightrot must be a rotation (gol_shade_in.lightrot precondition)
+        t["lightrot"] = 1.3 * t["lightrot"]
+        run([getattr(d, f"mipmap_{i}") for i in range(3)])

@@ -142,7 +142,7 @@ def test_one_line_record_is_short_strict_json():
                   "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
             assert k in line, (path, k)
         assert math.isfinite(line["value"]) and line["config"]["workload"] == "rgca_config2_envrelight"
-        assert set(line["config"]) <= set(bench._CONFIG_KEYS) | {"grad_exchange"}       # workload keys only
+        assert set(line["config"]) <= set(bench._CONFIG_KEYS) | {"grad_exchange", "launch"}       # workload keys only
         for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic"):
             assert k in line["roofline"], k
         for k in ("value", "unit", "cores", "kind", "sample"):

@@ -116,5 +116,7 @@ def test_patch_light_decorator_on_the_real_class_hands_over_one_shared_pyramid()
         got = LD.EnvSpinDecorator.mipmap(h, 4, "cpu", 2.5)
     finally:
         LD.EnvSpinDecorator.mipmap = orig
-    for a, b in zip(got, want):
+    for i, (a, b) in enumerate(zip(got, want)):
         assert a.shape == b.shape and torch.equal(a, b) and a.stride(0) == 0
+        # ... and carries the unscaled registered buffer + the frame's scale (shade packs the buffer once per environment)
+        assert a._gol_base is getattr(h, f"mipmap_{i}") and a._gol_scale == 2.5
