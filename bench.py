@@ -300,16 +300,29 @@ def step(t, cfg, world):
     for stream in streams:
         stream.wait_stream(main)
 
-    def render_and_backward(mb, p):
+    def render_and_backward(mb, p, hi=None):
         # loss == (rgb - target).abs().mean() (loss/__init__.py:411), evaluated in the raster epilogue and
         # back-propagated by the raster backward itself (losses.l1_image is the stand-alone form of the same op)
-        loss = render_gs.render_batch(mb["K"], mb["Rt"], p, cfg["height"], cfg["width"], l1_target=mb["target"])[3]
+        from goliath_amd import splat
+
+        splat.BIN_STREAM = (lambda dev: hi) if (hi is not None and cfg.get("prio") == "shade+bin") else None
+        try:
+            loss = render_gs.render_batch(mb["K"], mb["Rt"], p, cfg["height"], cfg["width"], l1_target=mb["target"])[3]
+        finally:
+            splat.BIN_STREAM = None
         loss.backward()
         return loss
 
     preds, loss = [], None
-    for mb, stream in zip(micro, streams):
-        with torch.cuda.stream(stream):
+    his = t.get("hi_streams") or [None] * len(streams)
+    for hi in his:
+        if hi is not None:
+            hi.wait_stream(main)
+    for mb, stream, hi in zip(micro, streams, his):
+        # --prio: the shading calls (HBM-bound, almost no VALU) go on a HIGH-PRIORITY stream of their own; autograd runs the
+        # shading backward on the stream its forward ran on, so both directions of the shading tail are dispatched ahead of
+        # the other micro-batch's raster workgroups instead of queueing behind them
+        with torch.cuda.stream(stream if hi is None else hi):
             for k in ("f_vn", "f_vc", "postex", "tn", "albedo"):
                 mb[k].grad = None
             # the cameras go into the shading call: its kernel projects the Gaussians it produces, the render starts at the
@@ -318,14 +331,17 @@ def step(t, cfg, world):
             vs = render_gs.view_set(mb["K"], mb["Rt"], cfg["height"], cfg["width"]) if cfg.get("fused_projection", True) else None
             preds.append(shade.shading_tail(mb["f_vn"], mb["f_vc"], mb["postex"], mb["tn"], mb["albedo"], mb["light_sh"],
                                             mb["campos"], preconv_envmap=mb["mips"], lightrot=mb["lightrot"], views=vs))
-            if not align:
-                loss = render_and_backward(mb, preds[-1])
+        if hi is not None:
+            stream.wait_stream(hi)
+        if not align:
+            with torch.cuda.stream(stream):
+                loss = render_and_backward(mb, preds[-1], hi)
     if align:
         _join_streams(streams, main)
-        for mb, stream, p in zip(micro, streams, preds):
+        for mb, stream, p, hi in zip(micro, streams, preds, his):
             with torch.cuda.stream(stream):
-                loss = render_and_backward(mb, p)
-    for stream in streams:
+                loss = render_and_backward(mb, p, hi)
+    for stream in list(streams) + [h for h in his if h is not None]:
         main.wait_stream(stream)
     # the path's only parameter (albedo, rgca.py:462-464) is shared by all views: sum the micro-batch grads
     grads = [mb["albedo"].grad for mb in t["micro"]]
@@ -371,7 +387,10 @@ def make_step_inputs(cfg, device, rank, n_micro):
         mb["albedo"] = albedo.detach().clone().requires_grad_(True)  # per-stream alias of the shared parameter
         if not cfg.get("env_per_view"):
             mb["mips"] = micro[0]["mips"]                            # ONE pyramid in HBM for the whole step
-    return {"micro": micro, "albedo": albedo, "streams": [torch.cuda.Stream(device=device) for _ in range(n_micro)]}
+    t = {"micro": micro, "albedo": albedo, "streams": [torch.cuda.Stream(device=device) for _ in range(n_micro)]}
+    if cfg.get("prio", "none") != "none":
+        t["hi_streams"] = [torch.cuda.Stream(device=device, priority=-1) for _ in range(n_micro)]
+    return t
 
 
 # algorithmic HBM bytes per view of each ABI call: what the call has to move given the data layout
@@ -1015,6 +1034,10 @@ def parse_args(argv=None):
                          "cannot be taken inside a graph: they come from an eager pass right after the timed replays")
     ap.add_argument("--workload", choices=["rgca", "mvp", "urhand", "sg", "e2e"], default="rgca",
                     help="rgca = the BASELINE metric (default); mvp = secondary BASELINE config 5 line")
+    ap.add_argument("--prio", choices=["none", "shade", "shade+bin"], default="none",
+                    help="rgca experiment (round 6): the HBM-bound calls on HIGH-PRIORITY streams of their own -- shade: the "
+                         "shading forward / backward; shade+bin: also the binning kernels (the raster kernels stay on the "
+                         "normal-priority micro-batch streams)")
     ap.add_argument("--no-align", action="store_true",
                     help="rgca: do not join the micro-batch streams after the shading calls (see step())")
     ap.add_argument("--unfused-projection", action="store_true",
@@ -1051,7 +1074,7 @@ def run_rgca(args, D, views, scaling, workload, overlap, micro=None, extras=True
     other ranks).  overlap: exchange mode for N > 1 (see run_step).  extras: intersection counts, per-call HBM table."""
     cfg = dict(CFG, workload=workload, views_per_gpu=views, coherent_uv=bool(args.coherent_uv),
                smooth_normals=bool(args.smooth_normals), fused_projection=not args.unfused_projection,
-               env_per_view=bool(getattr(args, "env_per_view", False)))
+               env_per_view=bool(getattr(args, "env_per_view", False)), prio=getattr(args, "prio", "none"))
     # with the projection fused in, micro-batches of >= 4 views are joined once after their shading kernels (see step();
     # measured: 8 views 2803 -> 2855 views/s; 2 + 2 and 1 + 1 views are faster left alone, and so is the unfused path)
     cfg["align_micro_batches"] = (cfg["fused_projection"] and views // max(1, min(args.micro if micro is None else micro, views)) >= 4

@@ -30,3 +30,13 @@ def test_gradsync_world2_gloo():
            "127.0.0.1", "--master-port", "29533", os.path.join(HERE, "_dist_worker.py")]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=240, env=env)
     assert r.returncode == 0 and "DIST_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_config3_world8_gloo():
+    """BASELINE config 3 on 8 ranks: 8 views / 8 ranks, and 4 (and 3) views / 8 ranks -- ranks without a
+    view issue the same collectives; gradients and the global norm equal the single-process full-batch ones."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1", MKL_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr",
+           "127.0.0.1", "--master-port", "29541", os.path.join(HERE, "_dist_worker8.py")]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=420, env=env)
+    assert r.returncode == 0 and "DIST8_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
