@@ -300,48 +300,71 @@ def step(t, cfg, world):
     for stream in streams:
         stream.wait_stream(main)
 
-    def render_and_backward(mb, p, hi=None):
+    def render_and_backward(mb, p):
         # loss == (rgb - target).abs().mean() (loss/__init__.py:411), evaluated in the raster epilogue and
         # back-propagated by the raster backward itself (losses.l1_image is the stand-alone form of the same op)
-        from goliath_amd import splat
-
-        splat.BIN_STREAM = (lambda dev: hi) if (hi is not None and cfg.get("prio") == "shade+bin") else None
-        try:
-            loss = render_gs.render_batch(mb["K"], mb["Rt"], p, cfg["height"], cfg["width"], l1_target=mb["target"])[3]
-        finally:
-            splat.BIN_STREAM = None
+        loss = render_gs.render_batch(mb["K"], mb["Rt"], p, cfg["height"], cfg["width"], l1_target=mb["target"])[3]
         loss.backward()
         return loss
 
     preds, loss = [], None
-    his = t.get("hi_streams") or [None] * len(streams)
-    for hi in his:
-        if hi is not None:
+    his = t.get("hi_streams")
+    if his:
+        # --prio (round 6 experiment): the HBM-bound shading calls of a micro-batch on a stream of their own (high priority
+        # unless "pipe"), the VALU-bound renders on another, so that shading B can run under raster A and the shading backward
+        # of A under raster B.  Every cross-stream edge goes THROUGH `main` (fork / join; direct waits between side streams --
+        # which is what autograd issues when a backward crosses streams -- crash hipStreamEndCapture on ROCm 7.0), so the
+        # backward is run in two stages by hand: raster backward -> gradient records on the render stream, then the shading
+        # backward on the shading stream.  main only ever waits, it runs nothing.
+        for hi in his:
             hi.wait_stream(main)
-    for mb, stream, hi in zip(micro, streams, his):
-        # --prio: the shading calls (HBM-bound, almost no VALU) go on a HIGH-PRIORITY stream of their own; autograd runs the
-        # shading backward on the stream its forward ran on, so both directions of the shading tail are dispatched ahead of
-        # the other micro-batch's raster workgroups instead of queueing behind them
-        with torch.cuda.stream(stream if hi is None else hi):
-            for k in ("f_vn", "f_vc", "postex", "tn", "albedo"):
-                mb[k].grad = None
-            # the cameras go into the shading call: its kernel projects the Gaussians it produces, the render starts at the
-            # tile count and hands its gradient records back to the shading backward (what AutoEncoder.forward does,
-            # goliath_amd/rgca.py); --unfused-projection: gol_project_fwd / bwd as kernels of their own (rounds 1-3)
-            vs = render_gs.view_set(mb["K"], mb["Rt"], cfg["height"], cfg["width"]) if cfg.get("fused_projection", True) else None
-            preds.append(shade.shading_tail(mb["f_vn"], mb["f_vc"], mb["postex"], mb["tn"], mb["albedo"], mb["light_sh"],
-                                            mb["campos"], preconv_envmap=mb["mips"], lightrot=mb["lightrot"], views=vs))
-        if hi is not None:
-            stream.wait_stream(hi)
-        if not align:
+        recs, g_recs = [], []
+        for mb, stream, hi in zip(micro, streams, his):
+            with torch.cuda.stream(hi):
+                for k in ("f_vn", "f_vc", "postex", "tn", "albedo"):
+                    mb[k].grad = None
+                vs = render_gs.view_set(mb["K"], mb["Rt"], cfg["height"], cfg["width"])
+                p = shade.shading_tail(mb["f_vn"], mb["f_vc"], mb["postex"], mb["tn"], mb["albedo"], mb["light_sh"],
+                                       mb["campos"], preconv_envmap=mb["mips"], lightrot=mb["lightrot"], views=vs)
+            main.wait_stream(hi)
+            stream.wait_stream(main)
             with torch.cuda.stream(stream):
-                loss = render_and_backward(mb, preds[-1], hi)
-    if align:
-        _join_streams(streams, main)
-        for mb, stream, p, hi in zip(micro, streams, preds, his):
+                from goliath_amd import splat
+
+                splat.BIN_STREAM = (lambda dev, h=hi: (h, main)) if cfg.get("prio") == "shade+bin" else None
+                try:
+                    loss = render_gs.render_batch(mb["K"], mb["Rt"], p, cfg["height"], cfg["width"], l1_target=mb["target"])[3]
+                finally:
+                    splat.BIN_STREAM = None
+                rec = p["projected"].records
+                g_recs.append(torch.autograd.grad(loss, [rec])[0])
+                recs.append(rec)
+        for stream, hi, rec, g in zip(streams, his, recs, g_recs):
+            main.wait_stream(stream)
+            hi.wait_stream(main)
+            with torch.cuda.stream(hi):
+                torch.autograd.backward([rec], [g])
+        for hi in his:
+            main.wait_stream(hi)
+    else:
+        for mb, stream in zip(micro, streams):
             with torch.cuda.stream(stream):
-                loss = render_and_backward(mb, p, hi)
-    for stream in list(streams) + [h for h in his if h is not None]:
+                for k in ("f_vn", "f_vc", "postex", "tn", "albedo"):
+                    mb[k].grad = None
+                # the cameras go into the shading call: its kernel projects the Gaussians it produces, the render starts at the
+                # tile count and hands its gradient records back to the shading backward (what AutoEncoder.forward does,
+                # goliath_amd/rgca.py); --unfused-projection: gol_project_fwd / bwd as kernels of their own (rounds 1-3)
+                vs = render_gs.view_set(mb["K"], mb["Rt"], cfg["height"], cfg["width"]) if cfg.get("fused_projection", True) else None
+                preds.append(shade.shading_tail(mb["f_vn"], mb["f_vc"], mb["postex"], mb["tn"], mb["albedo"], mb["light_sh"],
+                                                mb["campos"], preconv_envmap=mb["mips"], lightrot=mb["lightrot"], views=vs))
+                if not align:
+                    loss = render_and_backward(mb, preds[-1])
+        if align:
+            _join_streams(streams, main)
+            for mb, stream, p in zip(micro, streams, preds):
+                with torch.cuda.stream(stream):
+                    loss = render_and_backward(mb, p)
+    for stream in streams:
         main.wait_stream(stream)
     # the path's only parameter (albedo, rgca.py:462-464) is shared by all views: sum the micro-batch grads
     grads = [mb["albedo"].grad for mb in t["micro"]]
@@ -389,7 +412,8 @@ def make_step_inputs(cfg, device, rank, n_micro):
             mb["mips"] = micro[0]["mips"]                            # ONE pyramid in HBM for the whole step
     t = {"micro": micro, "albedo": albedo, "streams": [torch.cuda.Stream(device=device) for _ in range(n_micro)]}
     if cfg.get("prio", "none") != "none":
-        t["hi_streams"] = [torch.cuda.Stream(device=device, priority=-1) for _ in range(n_micro)]
+        t["hi_streams"] = [torch.cuda.Stream(device=device, priority=0 if cfg["prio"] == "pipe" else -1)
+                           for _ in range(n_micro)]
     return t
 
 
@@ -1034,10 +1058,10 @@ def parse_args(argv=None):
                          "cannot be taken inside a graph: they come from an eager pass right after the timed replays")
     ap.add_argument("--workload", choices=["rgca", "mvp", "urhand", "sg", "e2e"], default="rgca",
                     help="rgca = the BASELINE metric (default); mvp = secondary BASELINE config 5 line")
-    ap.add_argument("--prio", choices=["none", "shade", "shade+bin"], default="none",
+    ap.add_argument("--prio", choices=["none", "pipe", "shade", "shade+bin"], default="none",
                     help="rgca experiment (round 6): the HBM-bound calls on HIGH-PRIORITY streams of their own -- shade: the "
                          "shading forward / backward; shade+bin: also the binning kernels (the raster kernels stay on the "
-                         "normal-priority micro-batch streams)")
+                         "normal-priority micro-batch streams); pipe: the same four-stream dependency graph at normal priority")
     ap.add_argument("--no-align", action="store_true",
                     help="rgca: do not join the micro-batch streams after the shading calls (see step())")
     ap.add_argument("--unfused-projection", action="store_true",

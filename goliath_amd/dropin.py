@@ -125,7 +125,7 @@ def patch_urhand(urhand_module=None, mesh_render_layer=False):
         warnings.warn("patch_urhand(mesh_render_layer=True): the model's final, differentiable render goes through "
                       "goliath_amd.meshraster.RenderLayer, whose edge gradients are checked against finite differences only -- "
                       "drtk is absent in this build, so their parity with drtk.edge_grad_estimator is UNVERIFIED; "
-                      "meshraster.EDGE_STATS counts the discontinuities that receive no gradient", RuntimeWarning, stacklevel=2)
+                      "meshraster.EDGE_STATS (opt-in: GOLIATH_EDGE_STATS=1) counts the discontinuities that receive no gradient", RuntimeWarning, stacklevel=2)
         urhand_module.RenderLayer = meshraster.RenderLayer
     urhand_module.ConvTeacherDecoder.forward = urhand.conv_teacher_decoder_forward
     return urhand_module

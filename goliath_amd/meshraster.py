@@ -131,18 +131,20 @@ class _EdgeGrad(torch.autograd.Function):
                 sl_q = (slice(None), slice(None), slice(1, W)) if axis == 0 else (slice(None), slice(1, H), slice(None))
                 ip, iq = index_img[sl_p], index_img[sl_q]
                 cand = (ip != iq)
-                if not bool(cand.any()):
-                    continue
+                # (torch.nonzero is the one host sync of this backward -- the candidate count sizes every tensor below; an
+                # empty candidate set flows through as zero-length tensors, no second sync on `.any()`)
                 bb, ii, jj = torch.nonzero(cand, as_tuple=True)
+                if bb.numel() == 0:
+                    continue
                 fp, fq = ip[bb, ii, jj].long(), iq[bb, ii, jj].long()
                 tp, tq = vi[fp.clamp(min=0)], vi[fq.clamp(min=0)]                          # [n,3]
                 shared = (tp[:, :, None] == tq[:, None, :]).any(2).sum(1)
                 keep = ~((fp >= 0) & (fq >= 0) & (shared >= 2))
                 zp, zq = z[sl_p][bb, ii, jj], z[sl_q][bb, ii, jj]
                 occ_is_p = zp <= zq
-                bb, ii, jj, tp, tq, occ_is_p = bb[keep], ii[keep], jj[keep], tp[keep], tq[keep], occ_is_p[keep]
-                if bb.numel() == 0:
-                    continue
+                # (no compaction by `keep`: boolean indexing would be a second host sync; the dropped candidates -- two faces
+                # that share a mesh edge continue each other -- get coefficient 0 below)
+                keep_w = keep.to(leaf.dtype)
                 tri = torch.where(occ_is_p[:, None], tp, tq)                               # occluder's vertex ids [n,3]
                 P = leaf[bb[:, None], tri]                                                 # [n,3,3]
                 # along = coordinate that varies from p to q, across = the fixed one
@@ -168,13 +170,15 @@ class _EdgeGrad(torch.autograd.Function):
                 d_al = (e1[..., al] - e0[..., al]).gather(1, best[:, None])[:, 0].detach()
                 d_ac_b = d_ac.gather(1, best[:, None])[:, 0].detach()
                 weight = d_ac_b * d_ac_b / (d_ac_b * d_ac_b + d_al * d_al).clamp(min=1e-30)
-                coef = (0.5 * (gp + gq) * (cp - cq)).sum(1) * ok.to(leaf.dtype) * weight
-                total = total + (coef.detach() * x_star).sum()
-                # discontinuities whose occluder edge does not cross within a pixel get NO gradient: counted on the device (no
-                # extra sync) so a caller can see how many were dropped (EDGE_STATS)
-                EDGE_STATS["edges"] = EDGE_STATS.get("edges", 0) + ok.numel()
-                dropped = (~ok).sum()
-                EDGE_STATS["dropped"] = dropped if EDGE_STATS.get("dropped") is None else EDGE_STATS["dropped"] + dropped
+                coef = (0.5 * (gp + gq) * (cp - cq)).sum(1) * ok.to(leaf.dtype) * weight * keep_w
+                total = total + (coef.detach() * torch.where(ok & keep, x_star, torch.zeros_like(x_star))).sum()
+                # discontinuities whose occluder edge does not cross within a pixel get NO gradient: counted -- opt-in
+                # (GOLIATH_EDGE_STATS=1 or meshraster.COLLECT_EDGE_STATS = True), per device, on the device (no extra sync)
+                if COLLECT_EDGE_STATS:
+                    st = EDGE_STATS.setdefault(leaf.device, {"edges": None, "dropped": None})
+                    n_e, n_d = keep.sum(), (keep & ~ok).sum()
+                    st["edges"] = n_e if st["edges"] is None else st["edges"] + n_e
+                    st["dropped"] = n_d if st["dropped"] is None else st["dropped"] + n_d
             if total.requires_grad:
                 (gv,) = torch.autograd.grad(total, leaf)
             else:
@@ -182,8 +186,13 @@ class _EdgeGrad(torch.autograd.Function):
         return gv, None, g, None, None
 
 
-# running totals of the last backward passes: "edges" (int) = discontinuities seen, "dropped" (0-dim device tensor or None) =
-# those without a crossing occluder edge within a pixel (no gradient).  Reset with EDGE_STATS.clear().
+# Opt-in running totals of the backward passes, keyed by DEVICE (a second GPU's backward must not add into cuda:0's tensors):
+# EDGE_STATS[device] = {"edges": discontinuities seen, "dropped": those without a crossing occluder edge within a pixel (no
+# gradient)}, both 0-dim device tensors.  Off by default (an extra reduction per backward and a process-global mutation nobody
+# may read); reset with EDGE_STATS.clear().
+import os as _os
+
+COLLECT_EDGE_STATS = _os.environ.get("GOLIATH_EDGE_STATS", "0") == "1"
 EDGE_STATS = {}
 
 

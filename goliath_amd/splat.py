@@ -479,9 +479,16 @@ def _render_fwd_stages_projected(B, N, img_h, img_w, pj, background, with_depth,
     p = lambda off: ctypes.c_void_p(ws.data_ptr() + off) if off >= 0 else ctypes.c_void_p(0)
     v = ctypes.c_void_p
     side = BIN_STREAM(ws.device) if BIN_STREAM is not None else None
+    hub = None
+    if isinstance(side, tuple):     # (side stream, hub): fork / join through a stream that runs nothing (graph capture on
+        side, hub = side            # ROCm 7.0 crashes on direct waits between two side streams)
     cur = torch.cuda.current_stream(ws.device) if side is not None else None
     if side is not None:
-        side.wait_stream(cur)
+        if hub is not None:
+            hub.wait_stream(cur)
+            side.wait_stream(hub)
+        else:
+            side.wait_stream(cur)
         torch.cuda.set_stream(side)
     try:
         _lib.call("gol_bin_sort", c_int(B), c_int(N), v(pj.xys), v(pj.depths), v(pj.radii), v(pj.conics), v(pj.opac_eff),
@@ -490,7 +497,11 @@ def _render_fwd_stages_projected(B, N, img_h, img_w, pj, background, with_depth,
     finally:
         if side is not None:
             torch.cuda.set_stream(cur)
-            cur.wait_stream(side)
+            if hub is not None:
+                hub.wait_stream(side)
+                cur.wait_stream(hub)
+            else:
+                cur.wait_stream(side)
     _lib.call("gol_rasterize_fwd", c_int(B), c_int(N), c_int(img_h), c_int(img_w), c_int(BLOCK), c_int(1),
               p(L.tile_bins), p(L.sorted_ids), c_i64(cap), v(pj.records), c_int(1 if with_depth else 0), fptr(background),
               fptr(out_img), fptr(out_depth), p(L.final_T), p(L.final_idx), fptr(alpha), fptr(depth_norm),
