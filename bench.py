@@ -319,6 +319,7 @@ def step(t, cfg, world):
         for hi in his:
             hi.wait_stream(main)
         recs, g_recs = [], []
+        stop = os.environ.get("GOL_PIPE_STOP", "")   # diagnostics: truncate the step after the forward / the raster backward
         for mb, stream, hi in zip(micro, streams, his):
             with torch.cuda.stream(hi):
                 for k in ("f_vn", "f_vc", "postex", "tn", "albedo"):
@@ -329,17 +330,27 @@ def step(t, cfg, world):
             main.wait_stream(hi)
             stream.wait_stream(main)
             with torch.cuda.stream(stream):
-                from goliath_amd import splat
+                from goliath_amd import splat, views as _views
 
+                # the render sees the records as a LEAF of its own stream (same memory): the autograd graph of a micro-batch is
+                # cut at the stream boundary, so the engine never synchronises two side streams itself (its cross-stream
+                # handling of a gradient whose producer ran on another captured stream is what crashed the capture)
+                pr = p["projected"]
+                rec_leaf = pr.records.detach().requires_grad_(True)
+                p2 = dict(p, projected=_views.Projected(pr.views, rec_leaf, pr.pack, p))
                 splat.BIN_STREAM = (lambda dev, h=hi: (h, main)) if cfg.get("prio") == "shade+bin" else None
                 try:
-                    loss = render_gs.render_batch(mb["K"], mb["Rt"], p, cfg["height"], cfg["width"], l1_target=mb["target"])[3]
+                    loss = render_gs.render_batch(mb["K"], mb["Rt"], p2, cfg["height"], cfg["width"], l1_target=mb["target"])[3]
                 finally:
                     splat.BIN_STREAM = None
-                rec = p["projected"].records
-                g_recs.append(torch.autograd.grad(loss, [rec])[0])
-                recs.append(rec)
+                if stop == "fwd":
+                    continue
+                loss.backward()
+                g_recs.append(rec_leaf.grad)
+                recs.append(pr.records)
         for stream, hi, rec, g in zip(streams, his, recs, g_recs):
+            if stop == "rbwd":
+                break
             main.wait_stream(stream)
             hi.wait_stream(main)
             with torch.cuda.stream(hi):
@@ -367,7 +378,7 @@ def step(t, cfg, world):
     for stream in streams:
         main.wait_stream(stream)
     # the path's only parameter (albedo, rgca.py:462-464) is shared by all views: sum the micro-batch grads
-    grads = [mb["albedo"].grad for mb in t["micro"]]
+    grads = [mb["albedo"].grad if mb["albedo"].grad is not None else torch.zeros_like(mb["albedo"]) for mb in t["micro"]]
     t["_albedo_grad"] = grads[0] if len(grads) == 1 else (
         torch.add(grads[0], grads[1]) if len(grads) == 2 else torch.stack(grads).sum(0))
     t["albedo"].grad = t["_albedo_grad"]
@@ -412,8 +423,9 @@ def make_step_inputs(cfg, device, rank, n_micro):
             mb["mips"] = micro[0]["mips"]                            # ONE pyramid in HBM for the whole step
     t = {"micro": micro, "albedo": albedo, "streams": [torch.cuda.Stream(device=device) for _ in range(n_micro)]}
     if cfg.get("prio", "none") != "none":
-        t["hi_streams"] = [torch.cuda.Stream(device=device, priority=0 if cfg["prio"] == "pipe" else -1)
-                           for _ in range(n_micro)]
+        t["hi_streams"] = (list(t["streams"]) if cfg["prio"] == "pipe-same" else   # (diagnostic: the two-stage backward alone)
+                           [torch.cuda.Stream(device=device, priority=0 if cfg["prio"] == "pipe" else -1)
+                            for _ in range(n_micro)])
     return t
 
 
@@ -1058,7 +1070,7 @@ def parse_args(argv=None):
                          "cannot be taken inside a graph: they come from an eager pass right after the timed replays")
     ap.add_argument("--workload", choices=["rgca", "mvp", "urhand", "sg", "e2e"], default="rgca",
                     help="rgca = the BASELINE metric (default); mvp = secondary BASELINE config 5 line")
-    ap.add_argument("--prio", choices=["none", "pipe", "shade", "shade+bin"], default="none",
+    ap.add_argument("--prio", choices=["none", "pipe", "pipe-same", "shade", "shade+bin"], default="none",
                     help="rgca experiment (round 6): the HBM-bound calls on HIGH-PRIORITY streams of their own -- shade: the "
                          "shading forward / backward; shade+bin: also the binning kernels (the raster kernels stay on the "
                          "normal-priority micro-batch streams); pipe: the same four-stream dependency graph at normal priority")

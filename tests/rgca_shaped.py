@@ -78,7 +78,9 @@ def fill_(module, seed):
 class ShapedPrimDecoder(nn.Module):
     """Attribute layout of PrimDecoder (rgca.py:392-464) with an 8 -> S ladder of 3 transposed convs per stack."""
 
-    def __init__(self, seed=0, nudges=None):
+    def __init__(self, seed=0, nudges=None, raw=False):
+        """raw: the UN-manicured scene of the fourth fixture case (tests/golden/rgca_model_raw_golden.npz): no depth nudges, no
+        roughness conditioning -- whatever discontinuities the seeded scene happens to contain stay in."""
         super().__init__()
         from goliath_amd import decoder as D
 
@@ -113,8 +115,9 @@ class ShapedPrimDecoder(nn.Module):
             # roughness: sigma = 0.1 exp(x) in about 0.08 .. 0.25 -- SG lobes that fp32 resolves.  (At sigma = 0.01, the floor
             # of rgca.py:527, two fp32 evaluations of exp(-angle^2 / 2 sigma^2) differ by 1e-3: d/d angle = angle / sigma^2 times
             # the 1e-6 rad rounding of acos near 1; the reference's own sg.cu is that far from its fp64 evaluation there.)
-            b[nd + 11] += 0.3
-            self.vnocond_mod[-1].weight_v[:, nd + 11] *= 0.3
+            if not raw:
+                b[nd + 11] += 0.3
+                self.vnocond_mod[-1].weight_v[:, nd + 11] *= 0.3
             # depth separation (computed once by the fixture's generator, stored in the fixture): per-Gaussian z offsets through
             # the untied bias, so that no two Gaussians sharing a tile are within 32 ulps in depth in any view of the fixture.
             # Otherwise their compositing ORDER -- and with it rgb and every gradient -- hinges on the last bit of
@@ -161,10 +164,10 @@ class ShapedAutoEncoder(nn.Module):
     """Attribute layout of AutoEncoder (rgca.py:50-110).  `encoder` / `geomdecoder` return the leaves `embs` / `geom`
     (they are inputs of the path under test; gradients w.r.t. them are compared)."""
 
-    def __init__(self, embs, geom, seed=0, cal=True, blur=True, nudges=None):
+    def __init__(self, embs, geom, seed=0, cal=True, blur=True, nudges=None, raw=False):
         super().__init__()
         self.height, self.width, self.n_diff_sh, self.bg_weight = H, W, 8, 1.0
-        self.decoder = ShapedPrimDecoder(seed, nudges)
+        self.decoder = ShapedPrimDecoder(seed, nudges, raw)
         self.geo_fn = self.decoder.geo_fn
         self._embs, self._geom = embs, geom
         self.cal_enabled, self.learn_blur_enabled = bool(cal), bool(blur)
