@@ -308,77 +308,27 @@ def step(t, cfg, world):
         return loss
 
     preds, loss = [], None
-    his = t.get("hi_streams")
-    if his:
-        # --prio (round 6 experiment): the HBM-bound shading calls of a micro-batch on a stream of their own (high priority
-        # unless "pipe"), the VALU-bound renders on another, so that shading B can run under raster A and the shading backward
-        # of A under raster B.  Every cross-stream edge goes THROUGH `main` (fork / join; direct waits between side streams --
-        # which is what autograd issues when a backward crosses streams -- crash hipStreamEndCapture on ROCm 7.0), so the
-        # backward is run in two stages by hand: raster backward -> gradient records on the render stream, then the shading
-        # backward on the shading stream.  main only ever waits, it runs nothing.
-        for hi in his:
-            hi.wait_stream(main)
-        recs, g_recs = [], []
-        stop = os.environ.get("GOL_PIPE_STOP", "")   # diagnostics: truncate the step after the forward / the raster backward
-        for mb, stream, hi in zip(micro, streams, his):
-            with torch.cuda.stream(hi):
-                for k in ("f_vn", "f_vc", "postex", "tn", "albedo"):
-                    mb[k].grad = None
-                vs = render_gs.view_set(mb["K"], mb["Rt"], cfg["height"], cfg["width"])
-                p = shade.shading_tail(mb["f_vn"], mb["f_vc"], mb["postex"], mb["tn"], mb["albedo"], mb["light_sh"],
-                                       mb["campos"], preconv_envmap=mb["mips"], lightrot=mb["lightrot"], views=vs)
-            main.wait_stream(hi)
-            stream.wait_stream(main)
+    for mb, stream in zip(micro, streams):
+        with torch.cuda.stream(stream):
+            for k in ("f_vn", "f_vc", "postex", "tn", "albedo"):
+                mb[k].grad = None
+            # the cameras go into the shading call: its kernel projects the Gaussians it produces, the render starts at the
+            # tile count and hands its gradient records back to the shading backward (what AutoEncoder.forward does,
+            # goliath_amd/rgca.py); --unfused-projection: gol_project_fwd / bwd as kernels of their own (rounds 1-3)
+            vs = render_gs.view_set(mb["K"], mb["Rt"], cfg["height"], cfg["width"]) if cfg.get("fused_projection", True) else None
+            preds.append(shade.shading_tail(mb["f_vn"], mb["f_vc"], mb["postex"], mb["tn"], mb["albedo"], mb["light_sh"],
+                                            mb["campos"], preconv_envmap=mb["mips"], lightrot=mb["lightrot"], views=vs))
+            if not align:
+                loss = render_and_backward(mb, preds[-1])
+    if align:
+        _join_streams(streams, main)
+        for mb, stream, p in zip(micro, streams, preds):
             with torch.cuda.stream(stream):
-                from goliath_amd import splat, views as _views
-
-                # the render sees the records as a LEAF of its own stream (same memory): the autograd graph of a micro-batch is
-                # cut at the stream boundary, so the engine never synchronises two side streams itself (its cross-stream
-                # handling of a gradient whose producer ran on another captured stream is what crashed the capture)
-                pr = p["projected"]
-                rec_leaf = pr.records.detach().requires_grad_(True)
-                p2 = dict(p, projected=_views.Projected(pr.views, rec_leaf, pr.pack, p))
-                splat.BIN_STREAM = (lambda dev, h=hi: (h, main)) if cfg.get("prio") == "shade+bin" else None
-                try:
-                    loss = render_gs.render_batch(mb["K"], mb["Rt"], p2, cfg["height"], cfg["width"], l1_target=mb["target"])[3]
-                finally:
-                    splat.BIN_STREAM = None
-                if stop == "fwd":
-                    continue
-                loss.backward()
-                g_recs.append(rec_leaf.grad)
-                recs.append(pr.records)
-        for stream, hi, rec, g in zip(streams, his, recs, g_recs):
-            if stop == "rbwd":
-                break
-            main.wait_stream(stream)
-            hi.wait_stream(main)
-            with torch.cuda.stream(hi):
-                torch.autograd.backward([rec], [g])
-        for hi in his:
-            main.wait_stream(hi)
-    else:
-        for mb, stream in zip(micro, streams):
-            with torch.cuda.stream(stream):
-                for k in ("f_vn", "f_vc", "postex", "tn", "albedo"):
-                    mb[k].grad = None
-                # the cameras go into the shading call: its kernel projects the Gaussians it produces, the render starts at the
-                # tile count and hands its gradient records back to the shading backward (what AutoEncoder.forward does,
-                # goliath_amd/rgca.py); --unfused-projection: gol_project_fwd / bwd as kernels of their own (rounds 1-3)
-                vs = render_gs.view_set(mb["K"], mb["Rt"], cfg["height"], cfg["width"]) if cfg.get("fused_projection", True) else None
-                preds.append(shade.shading_tail(mb["f_vn"], mb["f_vc"], mb["postex"], mb["tn"], mb["albedo"], mb["light_sh"],
-                                                mb["campos"], preconv_envmap=mb["mips"], lightrot=mb["lightrot"], views=vs))
-                if not align:
-                    loss = render_and_backward(mb, preds[-1])
-        if align:
-            _join_streams(streams, main)
-            for mb, stream, p in zip(micro, streams, preds):
-                with torch.cuda.stream(stream):
-                    loss = render_and_backward(mb, p)
+                loss = render_and_backward(mb, p)
     for stream in streams:
         main.wait_stream(stream)
     # the path's only parameter (albedo, rgca.py:462-464) is shared by all views: sum the micro-batch grads
-    grads = [mb["albedo"].grad if mb["albedo"].grad is not None else torch.zeros_like(mb["albedo"]) for mb in t["micro"]]
+    grads = [mb["albedo"].grad for mb in t["micro"]]
     t["_albedo_grad"] = grads[0] if len(grads) == 1 else (
         torch.add(grads[0], grads[1]) if len(grads) == 2 else torch.stack(grads).sum(0))
     t["albedo"].grad = t["_albedo_grad"]
@@ -421,12 +371,7 @@ def make_step_inputs(cfg, device, rank, n_micro):
         mb["albedo"] = albedo.detach().clone().requires_grad_(True)  # per-stream alias of the shared parameter
         if not cfg.get("env_per_view"):
             mb["mips"] = micro[0]["mips"]                            # ONE pyramid in HBM for the whole step
-    t = {"micro": micro, "albedo": albedo, "streams": [torch.cuda.Stream(device=device) for _ in range(n_micro)]}
-    if cfg.get("prio", "none") != "none":
-        t["hi_streams"] = (list(t["streams"]) if cfg["prio"] == "pipe-same" else   # (diagnostic: the two-stage backward alone)
-                           [torch.cuda.Stream(device=device, priority=0 if cfg["prio"] == "pipe" else -1)
-                            for _ in range(n_micro)])
-    return t
+    return {"micro": micro, "albedo": albedo, "streams": [torch.cuda.Stream(device=device) for _ in range(n_micro)]}
 
 
 # algorithmic HBM bytes per view of each ABI call: what the call has to move given the data layout
@@ -1070,10 +1015,6 @@ def parse_args(argv=None):
                          "cannot be taken inside a graph: they come from an eager pass right after the timed replays")
     ap.add_argument("--workload", choices=["rgca", "mvp", "urhand", "sg", "e2e"], default="rgca",
                     help="rgca = the BASELINE metric (default); mvp = secondary BASELINE config 5 line")
-    ap.add_argument("--prio", choices=["none", "pipe", "pipe-same", "shade", "shade+bin"], default="none",
-                    help="rgca experiment (round 6): the HBM-bound calls on HIGH-PRIORITY streams of their own -- shade: the "
-                         "shading forward / backward; shade+bin: also the binning kernels (the raster kernels stay on the "
-                         "normal-priority micro-batch streams); pipe: the same four-stream dependency graph at normal priority")
     ap.add_argument("--no-align", action="store_true",
                     help="rgca: do not join the micro-batch streams after the shading calls (see step())")
     ap.add_argument("--unfused-projection", action="store_true",
@@ -1110,7 +1051,7 @@ def run_rgca(args, D, views, scaling, workload, overlap, micro=None, extras=True
     other ranks).  overlap: exchange mode for N > 1 (see run_step).  extras: intersection counts, per-call HBM table."""
     cfg = dict(CFG, workload=workload, views_per_gpu=views, coherent_uv=bool(args.coherent_uv),
                smooth_normals=bool(args.smooth_normals), fused_projection=not args.unfused_projection,
-               env_per_view=bool(getattr(args, "env_per_view", False)), prio=getattr(args, "prio", "none"))
+               env_per_view=bool(getattr(args, "env_per_view", False)))
     # with the projection fused in, micro-batches of >= 4 views are joined once after their shading kernels (see step();
     # measured: 8 views 2803 -> 2855 views/s; 2 + 2 and 1 + 1 views are faster left alone, and so is the unfused path)
     cfg["align_micro_batches"] = (cfg["fused_projection"] and views // max(1, min(args.micro if micro is None else micro, views)) >= 4

@@ -467,41 +467,14 @@ def _render_bwd_stages(B, N, img_h, img_w, glob_scale, means, scales, quats, opa
               fptr(v_scale_g), fptr(v_quat), fptr(v_opacity), stream_ptr())
 
 
-# Optional: a side stream for the binning kernels of the projected path (callable: device -> torch.cuda.Stream or None).
-# The binning is memory- / latency-bound and issues almost no VALU; on a HIGH-PRIORITY stream its small grids are dispatched
-# ahead of the other micro-batch's 43 k raster workgroups instead of queueing behind them (bench.py --prio; round 6 A/B).
-BIN_STREAM = None
-
-
 def _render_fwd_stages_projected(B, N, img_h, img_w, pj, background, with_depth, norm_lo, cap, ws, L, out_img, out_depth,
                                  alpha, depth_norm, l1_target, l1_mask, l1_mask_c, l1_partial, l1_out, l1_scale):
-    """gol_render_fwd_projected, stage by stage (per-stage event timing; or binning on BIN_STREAM)."""
+    """gol_render_fwd_projected, stage by stage (per-stage event timing)."""
     p = lambda off: ctypes.c_void_p(ws.data_ptr() + off) if off >= 0 else ctypes.c_void_p(0)
     v = ctypes.c_void_p
-    side = BIN_STREAM(ws.device) if BIN_STREAM is not None else None
-    hub = None
-    if isinstance(side, tuple):     # (side stream, hub): fork / join through a stream that runs nothing (graph capture on
-        side, hub = side            # ROCm 7.0 crashes on direct waits between two side streams)
-    cur = torch.cuda.current_stream(ws.device) if side is not None else None
-    if side is not None:
-        if hub is not None:
-            hub.wait_stream(cur)
-            side.wait_stream(hub)
-        else:
-            side.wait_stream(cur)
-        torch.cuda.set_stream(side)
-    try:
-        _lib.call("gol_bin_sort", c_int(B), c_int(N), v(pj.xys), v(pj.depths), v(pj.radii), v(pj.conics), v(pj.opac_eff),
-                  c_int(img_h), c_int(img_w), c_int(BLOCK), c_i64(cap), p(L.tile_count), p(L.tile_bins), p(L.keys),
-                  p(L.sorted_ids), p(L.n_isect), ctypes.c_void_p(0), stream_ptr())
-    finally:
-        if side is not None:
-            torch.cuda.set_stream(cur)
-            if hub is not None:
-                hub.wait_stream(side)
-                cur.wait_stream(hub)
-            else:
-                cur.wait_stream(side)
+    _lib.call("gol_bin_sort", c_int(B), c_int(N), v(pj.xys), v(pj.depths), v(pj.radii), v(pj.conics), v(pj.opac_eff),
+              c_int(img_h), c_int(img_w), c_int(BLOCK), c_i64(cap), p(L.tile_count), p(L.tile_bins), p(L.keys),
+              p(L.sorted_ids), p(L.n_isect), ctypes.c_void_p(0), stream_ptr())
     _lib.call("gol_rasterize_fwd", c_int(B), c_int(N), c_int(img_h), c_int(img_w), c_int(BLOCK), c_int(1),
               p(L.tile_bins), p(L.sorted_ids), c_i64(cap), v(pj.records), c_int(1 if with_depth else 0), fptr(background),
               fptr(out_img), fptr(out_depth), p(L.final_T), p(L.final_idx), fptr(alpha), fptr(depth_norm),
@@ -560,7 +533,7 @@ class _RenderViews(torch.autograd.Function):
         def run(cap):
             L = _layout(B, N, img_h, img_w, cap, with_l1, projected)
             ws = torch.empty(max(L.total, 1), dtype=torch.uint8, device=dev)
-            if projected and (_lib.TIMING is not None or BIN_STREAM is not None):
+            if projected and _lib.TIMING is not None:
                 _render_fwd_stages_projected(B, N, img_h, img_w, pj, background, with_depth, depth_norm_lo, cap, ws, L,
                                              out_img, out_depth, alpha, depth_norm, l1_target, l1_mask, l1_mask_c,
                                              l1_partial, l1_out, l1_inv_n)
