@@ -337,11 +337,17 @@ def _raw_predicates(G, rgb_hip, alpha_hip):
     return torch.stack(out), stats
 
 
-def test_raw_scene_point_lights_w_protocol():
+@pytest.mark.parametrize("fused_tail", [False, True])
+def test_raw_scene_point_lights_w_protocol(fused_tail, monkeypatch):
     """train_point's call on the scene nobody screened: plain seeded leaves, no depth nudges, no roughness conditioning
-    (tests/golden/make_rgca_model_golden.py: raw_case).  Every returned key, images, per-Gaussian gradients at the decoder
-    outputs by the W-protocol; parameter gradients reported against a coarse bar."""
+    (tests/golden/make_rgca_model_golden.py: raw_case).  Every returned key, images, parameter gradients against a coarse
+    bar; and -- with the decoder's last layers un-fused (GOLIATH_FUSED_TAIL=0: the product's default contracts the light
+    into them and never materialises the 125-channel activation, goliath_amd/tail.py) -- the per-Gaussian gradients at the
+    decoder outputs by the W-protocol."""
     from scenes import worst_set
+
+    monkeypatch.setenv("GOLIATH_FUSED_TAIL", "1" if fused_tail else "0")
+    tag = "raw_point" + ("_fused_tail" if fused_tail else "")
 
     G = np.load(RAW_PATH)
     st = _stored(G, "raw_point")
@@ -371,7 +377,8 @@ def test_raw_scene_point_lights_w_protocol():
         h.remove()
     report = {}
     _compare_outputs(G, "raw_point", preds, report)
-    for k in ("f_vnocond", "f_vcond"):       # the decoder ladder itself (MIOpen / ATen on both sides of the boundary)
+    assert bool(kept) == (not fused_tail)    # the fused tail never calls the two stacks as a whole
+    for k in kept:                           # the decoder ladder itself (MIOpen / ATen on both sides of the boundary)
         report[f"mid/{k}"] = rel_l2(kept[k].detach().cpu(), _t(G[f"raw_point/mid/{k}"]))
     flagged, stats = _raw_predicates(G, preds["rgb"].detach(), preds["alpha"].detach())     # [B, N] bool
     # images: the pixels outside the flagged set must agree to the image bar; the flagged set must be small
@@ -380,7 +387,7 @@ def test_raw_scene_point_lights_w_protocol():
     _backprop(preds)
     _compare_grads(G, "raw_point", m, embs, geom, report)
     w = {}
-    for k in ("f_vnocond", "f_vcond"):
+    for k in kept:
         a = kept[k].grad.reshape(B, -1, N)
         b = _t(G[f"raw_point/grad/{k}"]).reshape(B, -1, N)
         W_idx, all_rel, rest_rel = worst_set(a, b, 1e-4)
@@ -390,20 +397,25 @@ def test_raw_scene_point_lights_w_protocol():
         w[k] = {"rel_l2_all_gaussians": all_rel, "rel_l2_without_flagged": float((e2[~fl].sum() / r2[~fl].sum()).sqrt()),
                 "flagged_fraction": float(fl.float().mean()), "rel_l2_without_W": rest_rel, "W_size": int(W_idx.numel()),
                 "W_unexplained": int((~fl[W_idx]).sum())}
-    print(f"\nRGCA_MODEL_GOLDEN raw_point " + " ".join(f"{k}={v:.2e}" for k, v in sorted(report.items())))
-    print("RGCA_MODEL_GOLDEN raw_point predicates", stats, "decoder-output gradients", w)
+    print(f"\nRGCA_MODEL_GOLDEN {tag} " + " ".join(f"{k}={v:.2e}" for k, v in sorted(report.items())))
+    print(f"RGCA_MODEL_GOLDEN {tag} predicates", stats, "decoder-output gradients", w)
     out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
     if os.path.isdir(out_dir):
         import json
 
         path = os.path.join(out_dir, "rgca_model_parity.json")
         data = json.load(open(path)) if os.path.exists(path) else {}
-        data["raw_point"] = dict(report, predicates=stats, decoder_output_gradients=w)
+        data[tag] = dict(report, predicates=stats, decoder_output_gradients=w)
         json.dump(data, open(path, "w"), indent=1)
+    # measured (round 6, profiles/r06_rgca_model_parity.json): 262 same-tile pairs within 32 depth-ulps, NONE composited in a
+    # different order on the GPU; 1 flip pixel; every parameter / leaf gradient <= 5.9e-5, every decoder-output gradient
+    # <= 5.7e-5 with W empty.  While the scene shows (almost) no realised discontinuity the parameter gradients are held to
+    # 1.5e-4; a box on which a tied pair swaps falls back to the coarse bar and must explain itself per Gaussian below.
+    quiet = stats["tie_pixels_that_differ"] == 0 and stats["flip_pixels"] <= 4
     for k, v in report.items():
         assert v == v, (k, "NaN")
         if k.startswith("grad/"):
-            assert v < RAW_BAR_PARAM_GRAD, (k, v)
+            assert v < (1.5e-4 if quiet else RAW_BAR_PARAM_GRAD), (k, v, stats)
         elif k in ("out/rgb", "out/depth"):
             assert v < 2e-3, (k, v)                   # whole image incl. its flip / tie pixels
         elif k == "out/alpha":
