@@ -27,7 +27,7 @@ TOL = 1e-4           # north_star: within 1e-4 L2 -- outputs AND gradients
 # percents on a tensor -- round 3 saw 2.75e-2 from 8 Gaussians: if the cap trips with every member of W flip-explained,
 # say so in the failure instead of loosening the cap)
 ALL_CAP = {"config2": 2.5e-3, "config1": 1.5e-3}
-UNFLAGGED_BAR = 2e-4  # rel-L2 over the Gaussians no predicate flags (measured in round 6: see profiles/r06_fullsize_parity.json)
+UNFLAGGED_BAR = 1e-4  # north_star's bar, over the Gaussians NO a-priori predicate flags (79-87 % of them; measured <= 7.6e-5: profiles/r06_fullsize_parity.json)
 MAX_EXPLAINED = 2e-3  # at most this fraction of the Gaussians may need an explanation (measured: ~1e-4)
 LEAVES = ("f_vn", "f_vc", "postex", "tn", "albedo")
 STAGE = ("color", "opacity", "primpos", "primscale", "primqvec")
