@@ -697,294 +697,6 @@ __global__ __launch_bounds__(64 * Pix<PPL>::kWaves) void raster_bwd_kernel(
   }
 }
 
-// ---- backward, split footprint (round 6) ---------------------------------------------------------------------------------
-// The same two-pixels-per-lane arithmetic, but the wave's 16x8 half-tile is cut into two 8x8 SQUARES, one per 32-lane half
-// of the wave, and each half walks ITS OWN sequence of list entries: a visit serves the next entry that reaches the left
-// square in lanes 0-31 and the next entry that reaches the right square in lanes 32-63 (two different Gaussians in one
-// instruction stream -- the per-Gaussian operands are per-lane LDS reads anyway).  Entries that reach only one square -- 37 %
-// of today's visits at 250 k Gaussians, 50 % at 1 M (tools/pair_sim.py) -- no longer cost the other square's lanes a visit:
-// a batch costs max(left count, right count) visits instead of |left u right|: 0.86x / 0.81x.  The two halves never touch
-// the same pixel, and each sees its entries in list order, so the per-pixel recurrences are unchanged; the cross-lane
-// reductions become 32-lane sums (gol_half_sum4: both halves at once, no more instructions than the 64-lane form) into
-// per-HALF gradient slots, merged with the other waves' as before.
-// lane -> pixel: half h = lane >> 5 owns columns 8h..8h+7; inside it lane & 7 is the column and (lane >> 3) & 3 the row pair.
-
-// 32-lane sums of four values, both halves of the wave at once.  Per half h (lanes 32h .. 32h+31):
-//   lane 32h+15 = sum(a)   lane 32h+31 = sum(b)   lane 32h+7 = sum(c)   lane 32h+23 = sum(d)
-// 2 swaps + 2 adds fold the half's two 16-lane rows (rows [a01, b01, a23, b23]); one row_shr:8 add each leaves 8 column
-// sums per value; the second register's eight move into the free lanes 0..7 of the first, and three more DPP adds finish
-// both 8-lane groups together: 10 instructions for 8 sums.
-__device__ __forceinline__ float gol_half_sum4(float a, float b, float c, float d) {
-  float m = gol_add_row_shr8(gol_swap16_sum(a, b));
-  const float q = gol_add_row_shr8(gol_swap16_sum(c, d));
-  // (assembly for the same reason as gol_add_row_shr8: from the builtins the compiler emits v_mov 0 + v_mov_dpp + v_add for
-  // every masked step; the s_nop covers the two wait states of a DPP read after a VALU write of its source)
-  asm("s_nop 1\n\tv_mov_b32_dpp %0, %1 row_shl:8 row_mask:0xf bank_mask:0x3" : "+v"(m) : "v"(q));   // lanes 0..7 <- q's 8..15
-  asm("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xa" : "+v"(m));        // lanes 4..7, 12..15 only
-  asm("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf" : "+v"(m));
-  asm("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(m));        // lane 7 / lane 15 of every row
-  return m;
-}
-
-template <bool EXTRA, bool PACKED>
-__global__ __launch_bounds__(128) void raster_bwd_split_kernel(
-    int N, int img_h, int img_w, int planar, int tiles_x, int tiles_y, const int2* __restrict__ tile_bins,
-    const int32_t* __restrict__ sorted_ids, int64_t capacity, const float* __restrict__ records,
-    const float* __restrict__ background,
-    const float* __restrict__ final_Ts, const int32_t* __restrict__ final_idx,
-    const float* __restrict__ v_out_img, const float* __restrict__ v_out_extra,
-    const float* __restrict__ v_out_alpha, float* __restrict__ v_xy, float* __restrict__ v_conic,
-    float* __restrict__ v_colors, float* __restrict__ v_extra, float* __restrict__ v_opacity,
-    const uint8_t* __restrict__ v_sign, const float* __restrict__ v_sign_mask, int v_sign_mask_c,
-    const float* __restrict__ v_img_scale, float v_img_scale_mul, int n_views) {
-  constexpr int PPL = 2, NW = 2, NT = 128, NH = 2 * NW;   // NH half-waves = gradient slot owners
-  typedef typename Pix<PPL>::fv fv;
-  typedef typename Pix<PPL>::iv iv;
-  // LDS budget: 12 workgroups per CU (6 waves per SIMD, what the kernel's 77 VGPRs allow) need <= 13.3 KB.  The entry's
-  // 4-bit square mask (square q = x half q & 1, y half q >> 1: Pix<1>'s footprints) and its Gaussian id ride in the padding
-  // of its staged row; the gradient slots are zeroed per batch instead of carrying "touched" flags, 10 floats apart in the
-  // record layout (the dense layout reads them as float4: 12).
-  constexpr int kStride = PACKED ? 10 : kAcc;
-  __shared__ StagedRow s_e[kBatchB];
-  __shared__ __attribute__((aligned(16))) float s_acc[NH * kBatchB * kStride];
-  __shared__ int32_t s_wmax[NW];
-  const int T = tiles_x * tiles_y;
-  const int view = blockIdx.x % n_views, slot = blockIdx.x / n_views;
-  const TileCoord tc = tile_of_block(slot, T, tiles_x);
-  if (!tc.ok) return;
-  const int2 range = tile_bins[(size_t)view * T + tc.tile];
-  if (range.y <= range.x) return;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int half = lane >> 5;
-  const int j = tc.tx * 16 + 8 * half + (lane & 7);
-  const int i0 = tc.ty * 16 + wave * 8 + ((lane >> 3) & 3) * 2;
-  const float px = (float)j + 0.5f;
-  const size_t hw = (size_t)img_h * img_w;
-  const int32_t* ids = sorted_ids + (size_t)view * capacity;
-  const size_t goff = (size_t)view * N;
-  bool in[PPL];
-  size_t pp[PPL];
-  fv py, T_final;
-  iv bin_final;
-#pragma unroll
-  for (int q = 0; q < PPL; ++q) {
-    in[q] = (i0 + q < img_h) && (j < img_w);
-    py[q] = (float)(i0 + q) + 0.5f;
-    pp[q] = in[q] ? ((size_t)view * img_h + i0 + q) * img_w + j : 0;
-    T_final[q] = in[q] ? final_Ts[pp[q]] : 1.f;
-    bin_final[q] = in[q] ? final_idx[pp[q]] : (range.x - 1);
-  }
-  fv T_cur = T_final;
-  fv vo0 = 0.f, vo1 = 0.f, vo2 = 0.f, vo3 = 0.f, voa = 0.f;
-  {
-    const float vsc = (v_img_scale ? v_img_scale[0] : 1.f) * v_img_scale_mul;
-    const size_t os = planar ? hw : 1;
-#pragma unroll
-    for (int q = 0; q < PPL; ++q) {
-      if (!in[q]) continue;
-      const size_t p = pp[q];
-      const int i = i0 + q;
-      const size_t o = planar ? (size_t)view * 3 * hw + (size_t)i * img_w + j : 3 * p;
-      float g0 = 0.f, g1 = 0.f, g2 = 0.f;
-      if (v_out_img) { g0 = v_out_img[o]; g1 = v_out_img[o + os]; g2 = v_out_img[o + 2 * os]; }
-      if (v_sign) {
-        const unsigned code = v_sign[p];
-        float m0 = vsc, m1 = vsc, m2 = vsc;
-        if (v_sign_mask) {
-          const float* mk = v_sign_mask + (size_t)view * v_sign_mask_c * hw + (size_t)i * img_w + j;
-          m0 *= mk[0]; m1 *= (v_sign_mask_c == 3) ? mk[hw] : mk[0]; m2 *= (v_sign_mask_c == 3) ? mk[2 * hw] : mk[0];
-        }
-        g0 += (float)((int)(code & 3u) - 1) * m0;
-        g1 += (float)((int)((code >> 2) & 3u) - 1) * m1;
-        g2 += (float)((int)((code >> 4) & 3u) - 1) * m2;
-      }
-      vo0[q] = g0; vo1[q] = g1; vo2[q] = g2;
-      if (EXTRA && v_out_extra) vo3[q] = v_out_extra[p];
-      if (v_out_alpha) voa[q] = v_out_alpha[p];
-    }
-  }
-  const fv tail = T_final * (voa - (background[0] * vo0 + background[1] * vo1 + background[2] * vo2));
-  fv qsum = 0.f;
-
-  // last list index each 32-lane half / the wave / the tile has to walk
-  int hmax = max(bin_final[0], bin_final[1]);
-#pragma unroll
-  for (int off = 16; off > 0; off >>= 1) hmax = max(hmax, __shfl_xor(hmax, off, 64));
-  const int wmaxU = __builtin_amdgcn_readlane(hmax, 0), wmaxL = __builtin_amdgcn_readlane(hmax, 32);
-  const int wmax = max(wmaxU, wmaxL);
-  if (lane == 0) s_wmax[wave] = wmax;
-  __syncthreads();
-  int bmax = max(s_wmax[0], s_wmax[1]);
-  bmax = min(bmax, range.y - 1);
-  if (bmax < range.x) return;
-
-  // this lane's gradient slot column: the lanes with (lane & 7) == 7 hold the half's sums (gol_half_sum4):
-  //   lane & 31 ==  7 -> sum c (slot 2 / 6)   15 -> sum a (slot 0 / 4)   23 -> sum d (slot 3 / 7)   31 -> sum b (slot 1 / 5)
-  const int sub = (lane >> 3) & 3;
-  const int col = (sub == 0) ? 2 : (sub == 1) ? 0 : (sub == 2) ? 3 : 1;
-  const int acc_lane = (2 * wave + half) * kBatchB * kStride + col;   // index of entry 0's slot column of this lane
-  const unsigned long long kLo = 0x00000000ffffffffull, kHi = 0xffffffff00000000ull;
-  const int n_batches = (bmax - range.x + kBatchB) / kBatchB;
-  auto entry_id = [&](int bb2) {
-    const int e = bmax - bb2 * kBatchB - tid;
-    return (tid < kBatchB && e >= range.x) ? ids[e] : 0;
-  };
-  int gid_next = entry_id(0);
-  for (int bb = 0; bb < n_batches; ++bb) {
-    __syncthreads();
-    const int batch_end = bmax - bb * kBatchB;
-    const int batch_size = min(kBatchB, batch_end + 1 - range.x);
-    const int gid = gid_next;
-    if (tid < kBatchB) {
-      if (tid < batch_size) {
-        const Staged st = stage_entry<1>(records, goff + (size_t)gid, (float)(tc.tx * 16), (float)(tc.ty * 16));
-        s_e[tid].a = st.a; s_e[tid].b = st.b; s_e[tid].c = st.c;
-        s_e[tid].pad = make_float2(__int_as_float(st.mask), __int_as_float(gid));
-      } else {
-        s_e[tid].pad = make_float2(0.f, 0.f);
-      }
-    }
-    if (bb + 1 < n_batches) gid_next = entry_id(bb + 1);
-    for (int k = tid; k < NH * kBatchB * kStride / 4; k += NT) reinterpret_cast<float4*>(s_acc)[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-    __syncthreads();
-
-    const int mk = __float_as_int(s_e[lane].pad.x) >> (2 * wave);
-    unsigned long long bU = gol_ballot(mk & 1), bL = gol_ballot((mk >> 1) & 1);
-    {
-      const int t0U = max(0, batch_end - wmaxU), t0L = max(0, batch_end - wmaxL);   // entries beyond the half's last index
-      bU = t0U >= 64 ? 0ull : (bU & (~0ull << t0U));
-      bL = t0L >= 64 ? 0ull : (bL & (~0ull << t0L));
-    }
-    while (bU | bL) {
-      int tU = 0, tL = 0;
-      unsigned long long vmask = 0ull;
-      if (bU) { tU = __builtin_ctzll(bU); bU &= bU - 1; vmask |= kLo; }
-      if (bL) { tL = __builtin_ctzll(bL); bL &= bL - 1; vmask |= kHi; }
-      const int t = half ? tL : tU;                         // this lane's entry (its half may have none: vmask)
-      const StagedRow* row = gol_at(&s_e[0], (unsigned)t * (unsigned)sizeof(StagedRow));
-      const float4 a4 = row->a;
-      const float4 b4 = row->b;
-      const float2 c2 = row->c;
-      const int li = batch_end - t;
-      const float dx = a4.x - px;
-      const fv dy = a4.y - py;
-      fv sigma, vis;
-#ifndef GOL_EXACT_MATH
-      sigma = (a4.z * dx * dx + b4.x * dy * dy) + (a4.w * dx) * dy;
-#pragma unroll
-      for (int q = 0; q < PPL; ++q) vis[q] = __builtin_amdgcn_exp2f(-sigma[q]);
-#else
-#pragma unroll
-      for (int q = 0; q < PPL; ++q) { sigma[q] = exact_sigma(a4.z, a4.w, b4.x, dx, dy[q]); vis[q] = exact_exp_neg(sigma[q]); }
-#endif
-      fv alpha = b4.y * vis;
-      unsigned long long mv[PPL], many = 0ull;
-#pragma unroll
-      for (int q = 0; q < PPL; ++q) {
-        alpha[q] = fminf(GOL_ALPHA_CAP_BWD, alpha[q]);
-        mv[q] = gol_ballot(li <= bin_final[q]) & gol_ballot(!(sigma[q] < 0.f)) & gol_ballot(!(alpha[q] < GOL_ALPHA_FLOOR)) & vmask;
-        many |= mv[q];
-      }
-      if (many == 0ull) continue;
-      bool v[PPL];
-      fv ra;
-#pragma unroll
-      for (int q = 0; q < PPL; ++q) {
-        v[q] = __builtin_amdgcn_inverse_ballot_w64(mv[q]);
-        alpha[q] = v[q] ? alpha[q] : 0.f;
-      }
-      const fv one_m = 1.f - alpha;
-#pragma unroll
-      for (int q = 0; q < PPL; ++q) ra[q] = __builtin_amdgcn_rcpf(one_m[q]);
-      const fv T_new = T_cur * ra;
-      const fv fac = alpha * T_new;
-      T_cur = T_new;
-      fv w = b4.z * vo0 + b4.w * vo1 + c2.x * vo2;
-      if (EXTRA) w += c2.y * vo3;
-      const fv v_alpha = T_new * w + ra * (tail - qsum);
-      qsum += fac * w;
-      fv gop = vis * v_alpha;
-#pragma unroll
-      for (int q = 0; q < PPL; ++q) gop[q] = v[q] ? gop[q] : 0.f;
-      const fv gy = gop * dy;
-      const fv gyy = gy * dy;
-      const float g0s = __builtin_fmaf(fac[0], vo0[0], fac[1] * vo0[1]);
-      const float g1s = __builtin_fmaf(fac[0], vo1[0], fac[1] * vo1[1]);
-      const float g2s = __builtin_fmaf(fac[0], vo2[0], fac[1] * vo2[1]);
-      const float g3 = EXTRA ? __builtin_fmaf(fac[0], vo3[0], fac[1] * vo3[1]) : 0.f;
-      const float m0 = gop[0] + gop[1];
-      const float my = gy[0] + gy[1];
-      const float myy = gyy[0] + gyy[1];
-      const float mx = m0 * dx, mxx = mx * dx, mxy = my * dx;
-      // per half: lane 15 / 31 / 7 / 23 (mod 32) = sums of the 1st / 2nd / 3rd / 4th argument
-      const float r0 = gol_half_sum4(g0s, g1s, g2s, m0);
-      const float r1 = gol_half_sum4(mx, my, mxx, mxy);
-      const float r2 = gol_row_sum_to_lane15(gol_swap16_sum(myy, g3));   // lane 15 (mod 32) = sum myy, lane 31 = sum g3
-      // the result lanes ((lane & 7) == 7) of a half whose entry got a taker store -- as ONE scalar lane mask (a half
-      // without a taker leaves its entry's slot alone: that entry may be the other half's, or nobody's)
-      const unsigned long long wm = ((many & kLo) ? 0x0000000080808080ull : 0ull) | ((many & kHi) ? 0x8080808000000000ull : 0ull);
-      if (__builtin_amdgcn_inverse_ballot_w64(wm)) {
-        float* a = &s_acc[acc_lane + t * kStride];
-        a[0] = r0; a[4] = r1;
-        if ((lane & 15) == 15) a[8] = r2;           // lane 15 (col 0) -> slot 8 = myy; lane 31 (col 1) -> slot 9 = extra
-      }
-    }
-    __syncthreads();
-    if (PACKED) {
-      float* rec = v_colors;
-      for (int idx = tid; idx < batch_size * 16; idx += NT) {
-        const int t = idx >> 4, c = idx & 15;
-        if (c > (EXTRA ? 9 : 8)) continue;
-        const float4 a4 = s_e[t].a;
-        const float4 b4 = s_e[t].b;
-        const float nop = -b4.y, cc = b4.x;
-        const int k1 = (c == 5) ? 4 : c, k2 = 5;
-        const float w1 = (c == 4) ? nop * a4.z * kUnA : (c == 5) ? nop * a4.w * kUnB : (c == 6 || c == 8) ? 0.5f * nop
-                       : (c == 7) ? nop : 1.f;
-        const float w2 = (c == 4) ? nop * a4.w * kUnB : (c == 5) ? nop * cc * kUnA : 0.f;
-        float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-        for (int w = 0; w < NH; ++w) {
-          s1 += s_acc[(w * kBatchB + t) * kStride + k1];
-          s2 += s_acc[(w * kBatchB + t) * kStride + k2];
-        }
-        // (an entry nobody took has all-zero slots: no atomic for it -- adding 0 would change nothing)
-        if (s1 != 0.f || s2 != 0.f)
-          atomicAdd(rec + (goff + (size_t)__float_as_int(s_e[t].pad.y)) * 16 + c, w1 * s1 + w2 * s2);
-      }
-    } else if (tid < batch_size) {
-      float a[kAcc];
-#pragma unroll
-      for (int k = 0; k < kAcc; ++k) a[k] = 0.f;
-      bool any = false;
-#pragma unroll
-      for (int w = 0; w < NH; ++w) {
-        const float4* q = reinterpret_cast<const float4*>(&s_acc[(w * kBatchB + tid) * kStride]);
-        const float4 q0 = q[0], q1 = q[1], q2 = q[2];
-        a[0] += q0.x; a[1] += q0.y; a[2] += q0.z; a[3] += q0.w;
-        a[4] += q1.x; a[5] += q1.y; a[6] += q1.z; a[7] += q1.w;
-        a[8] += q2.x; a[9] += q2.y;
-      }
-#pragma unroll
-      for (int k = 0; k < 10; ++k) any = any || (a[k] != 0.f);
-      if (any) {
-        const size_t g = goff + (size_t)__float_as_int(s_e[tid].pad.y);
-        const float4 a4 = s_e[tid].a;
-        const float4 b4 = s_e[tid].b;
-        const float nop = -b4.y;
-        const float ca = a4.z * kUnA, cb = a4.w * kUnB, cc = b4.x * kUnA;
-        atomicAdd(v_colors + 3 * g, a[0]); atomicAdd(v_colors + 3 * g + 1, a[1]); atomicAdd(v_colors + 3 * g + 2, a[2]);
-        atomicAdd(v_opacity + g, a[3]);
-        atomicAdd(v_xy + 2 * g, nop * (ca * a[4] + cb * a[5]));
-        atomicAdd(v_xy + 2 * g + 1, nop * (cb * a[4] + cc * a[5]));
-        atomicAdd(v_conic + 3 * g, 0.5f * nop * a[6]); atomicAdd(v_conic + 3 * g + 1, nop * a[7]);
-        atomicAdd(v_conic + 3 * g + 2, 0.5f * nop * a[8]);
-        if (EXTRA && v_extra) atomicAdd(v_extra + g, a[9]);
-      }
-    }
-  }
-}
-
 // DIAGNOSTIC (bench.py's algorithmic roofline): per view, the number of (pixel, list entry) pairs up to the pixel's
 // final_idx ("tested": what any per-pixel compositor has to look at) and of those with alpha >= 1/255 ("taken": what is
 // composited and differentiated).  One thread per pixel, no staging: slow and simple.
@@ -1174,16 +886,9 @@ extern "C" int gol_rasterize_bwd(int B, int N, int img_h, int img_w, int block, 
   GOL_REQUIRE(pixels_per_lane >= 0 && pixels_per_lane <= 2, "pixels_per_lane: 0 (2), 1 or 2");
   const int ppl = pixels_per_lane ? pixels_per_lane : 2;
   const bool ex = with_extra && (v_out_extra || v_extra);
-  static const bool split = getenv("GOL_RASTER_SPLIT") ? atoi(getenv("GOL_RASTER_SPLIT")) != 0 : false;
 #define GOL_LAUNCH_BWD(EX, PK)                                                                                          \
   do {                                                                                                                  \
-    if (ppl == 2 && split)                                                                                              \
-      raster_bwd_split_kernel<EX, PK><<<grid, 128, 0, s>>>(N, img_h, img_w, planar, tiles_x, tiles_y, bins, sorted_ids, \
-                                                        capacity, records, background, final_Ts, final_idx, v_out_img, \
-                                                        EX ? v_out_extra : nullptr, v_out_alpha, v_xy, v_conic,        \
-                                                        v_colors, EX ? v_extra : nullptr, v_opacity, v_sign,           \
-                                                        v_sign_mask, v_sign_mask_c, v_img_scale, v_img_scale_mul, B);  \
-    else if (ppl == 2)                                                                                                  \
+    if (ppl == 2)                                                                                                       \
       raster_bwd_kernel<EX, PK, 2><<<grid, 128, 0, s>>>(N, img_h, img_w, planar, tiles_x, tiles_y, bins, sorted_ids,   \
                                                         capacity, records, background, final_Ts, final_idx, v_out_img, \
                                                         EX ? v_out_extra : nullptr, v_out_alpha, v_xy, v_conic,        \
