@@ -18,7 +18,7 @@ CALLS = {  # kernel-name prefix -> ABI call
     "shade_fwd_kernel": "gol_shade_fwd", "shade_bwd_kernel": "gol_shade_bwd", "sum_views_kernel": "gol_shade_bwd", "project_fwd_kernel": "gol_project_fwd",
     "project_bwd_kernel": "gol_project_bwd", "count_lds_kernel": "gol_bin_sort", "count_kernel": "gol_bin_sort",
     "scan_kernel": "gol_bin_sort", "scatter_lds_kernel": "gol_bin_sort", "scatter_kernel": "gol_bin_sort",
-    "sort_kernel": "gol_bin_sort", "sort_queue_kernel": "gol_bin_sort", "sort_big_kernel": "gol_bin_sort", "bin_": "gol_bin_sort",
+    "sort_kernel": "gol_bin_sort", "sort_mid_kernel": "gol_bin_sort", "sort_queue_kernel": "gol_bin_sort", "sort_big_kernel": "gol_bin_sort", "bin_": "gol_bin_sort",
     "raster_fwd_kernel": "gol_rasterize_fwd", "l1_sum_kernel": "gol_rasterize_fwd", "splat_pack_kernel": "gol_splat_pack",
     "raster_bwd_kernel": "gol_rasterize_bwd", "l1_kernel<false>": "gol_l1_fwd", "l1_kernel<true>": "gol_l1_bwd",
     "tail_conv_fwd_kernel": "gol_tail_conv_fwd", "tail_bias_fwd_kernel": "gol_tail_conv_fwd", "tail_conv_bwd": "gol_tail_conv_bwd",
