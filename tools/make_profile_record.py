@@ -29,9 +29,13 @@ CALLS = {  # kernel-name prefix -> ABI call
 
 def call_of(kernel):
     c = next((c for p, c in CALLS.items() if kernel.startswith(p)), None)
-    # the shading kernels with the projection fused in (last template argument true) belong to gol_shade_project_fwd / bwd
-    if c in ("gol_shade_fwd", "gol_shade_bwd") and kernel.startswith("shade_") and kernel.rstrip().endswith("true>"):
-        c = c.replace("gol_shade_", "gol_shade_project_")
+    # the shading kernels with the projection fused in belong to gol_shade_project_fwd / bwd: PROJ is the THIRD template
+    # argument of shade_fwd_kernel<ENV, RAND, PROJ, VEC4> (round 6) and the LAST of shade_bwd_kernel<ENV, RAND, VEC4, PROJ>
+    if c in ("gol_shade_fwd", "gol_shade_bwd") and kernel.startswith("shade_") and "<" in kernel:
+        args = [a.strip() for a in kernel[kernel.index("<") + 1:kernel.rindex(">")].split(",")]
+        proj = args[2] if c == "gol_shade_fwd" and len(args) == 4 else args[-1]
+        if proj == "true":
+            c = c.replace("gol_shade_", "gol_shade_project_")
     return c
 
 
