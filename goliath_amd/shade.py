@@ -6,8 +6,8 @@ shapes in the returned dict, gradients to f_vnocond, f_vcond, the uv position / 
 albedo parameter.  The decoder outputs are consumed in their native NCHW layout (no permute copies).
 """
 import ctypes
-
 import os
+import weakref
 
 import torch
 
@@ -235,14 +235,15 @@ def _check_rotation(lightrot):
     if os.environ.get("GOLIATH_CHECK_LIGHTROT", "1") == "0" or torch.cuda.is_current_stream_capturing():
         return
     key = (lightrot.data_ptr(), lightrot._version, tuple(lightrot.shape))
-    if key in _ROT_CHECKED:
+    seen = _ROT_CHECKED.get(key)
+    if seen is not None and seen() is lightrot:     # the SAME tensor object (a freed tensor's address can come back)
         return
     err = float((lightrot @ lightrot.transpose(-1, -2) - torch.eye(3, device=lightrot.device)).abs().max())
     if not err < 1e-3:
         raise ValueError(f"lightrot is not a rotation (max |R R^T - I| = {err:.3g}): the env-map lookup needs a unit direction")
     while len(_ROT_CHECKED) >= 64:
         _ROT_CHECKED.pop(next(iter(_ROT_CHECKED)))
-    _ROT_CHECKED[key] = True
+    _ROT_CHECKED[key] = weakref.ref(lightrot)
 
 
 def shading_tail(f_vnocond, f_vcond, postex, tn, albedo, headrel_light_sh, headrel_campos,
