@@ -906,7 +906,9 @@ def e2e_main(args, emit_line=True):
                           "trainable_params": sum(p.numel() for p in params),
                           "parallelism": f"view-parallel x{world}", "rccl_world_size": world,
                           "grad_sync": "bucketed reduce-scatter + all-gather, launched from backward hooks"},
-               "kernels_ms_per_call": ms, "hot_path_ms_per_step": sum(sum(v) for v in per.values()) / args.steps,
+               "kernels_ms_per_call": ms,
+               # the C-ABI calls of a step: per-call MEDIAN x calls per step (the mean rode on the first steps' outliers)
+               "hot_path_ms_per_step": sum(_median(v) * len(v) / args.steps for v in per.values()),
                # sanity signal of the whole gradient chain: the training loss on the fixed batch, first vs last step
                "loss_first_step": float(loss_first) if loss_first is not None else None,
                "loss_last_step": float(l.detach()),
