@@ -34,7 +34,8 @@ _ROWS = {
     "test_gpu_splat": "R1-R5  project / bin+sort / raster fwd+bwd vs oracle/gsplat_oracle.c (unpinned)",
     "test_gpu_edges": "R0-R5  edge cases of the render path", "test_gpu_exact_math": "R3-R5  raster boundary, identical inputs",
     "test_gpu_fullsize": "R0-R5 + S  the bench step at config 2 / config 1 size",
-    "test_gpu_model_forward": "R0  AutoEncoder.render / forward", "test_gpu_rgca_dropin": "(b)  ca_code drop-in",
+    "test_gpu_model_forward": "SELF-CONSISTENCY (no oracle): fused vs layer-by-layer host paths of the model glue",
+    "test_gpu_rgca_dropin": "SELF-CONSISTENCY (no oracle): drop-in plumbing on a stand-in (parity lives in test_gpu_rgca_model_golden)",
     "test_gpu_rgca_model_golden": "R0 / (b)  AutoEncoder.forward / render / PrimDecoder.forward / env-relight driver vs the "
                                   "reference's own code (tests/golden/rgca_model_golden.npz)",
     "test_gpu_mvp": "M1-M4  mvpraymarch / aabb / raydirs (mvp.hip)", "test_gpu_mvp_fullsize": "M2  config-5 size crops",
