@@ -22,7 +22,10 @@
 //     ds_bpermute exchanges per key kept the LDS crossbar busy for 0.32 ms per 8 views.  Lists with pathological
 //     depth clustering (a bucket of more than 48 entries) fall back to the network;
 //   * round 4: the tile scan is one pass (counts staged in LDS); lists of more than 2048 entries are queued for a 1024-thread
-//     kernel that bucket-sorts up to 16384 keys in LDS (a third of the tiles at 1 M Gaussians).
+//     kernel that bucket-sorts up to 16384 keys in LDS (a third of the tiles at 1 M Gaussians);
+//   * round 6: two queues -- lists of 2049 ... 4096 entries (all the long lists there are at 250 k and at 1 M Gaussians) go to
+//     256-thread workgroups with 36 KB of static LDS, four per CU (sort_mid_kernel: 0.35 -> 0.18 ms per 8 views at 1 M); the
+//     1024-thread kernel keeps the lists above 4096 and no longer REQUIRES its 147 KB of dynamic LDS (global-memory fallback).
 // Traffic: 8 B written + 8 B read + 4 B written per intersection, everything else stays in LDS.
 #include <atomic>
 #include <cstdlib>
@@ -877,7 +880,9 @@ extern "C" int gol_bin_sort(int B, int N, const float* xys, const float* depths,
                                                                                           sorted_ids, tile_count);
     {
       const size_t lds = sizeof(uint64_t) * (size_t)bucket_sort_lds_words(kBigN, kBigThreads, kBigBuckets);
-      const bool granted = ensure_lds_limit(2, (const void*)sort_big_kernel, lds);
+      // (GOL_SORT_BIG_NO_LDS=1: take the refusal path on purpose -- tests/test_gpu_splat.py exercises the fallback with it)
+      static const bool refuse = getenv("GOL_SORT_BIG_NO_LDS") && atoi(getenv("GOL_SORT_BIG_NO_LDS")) != 0;
+      const bool granted = !refuse && ensure_lds_limit(2, (const void*)sort_big_kernel, lds);
       sort_big_kernel<<<dim3(256, B), kBigThreads, granted ? lds : 0, s>>>(T, capacity, tile_bins, isect_keys, sorted_ids,
                                                                           tile_count, granted ? 1 : 0);
     }

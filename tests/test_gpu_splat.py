@@ -4,6 +4,8 @@ gsplat-0.1.11 path (PARITY UNPINNED upstream, see oracle/gsplat_oracle.c).
 Bars: integer/index outputs (radii, tile counts, sorted ids) exact up to ulp-flips of ceil()/(int);
 floating point rel-L2 <= 1e-4 (north_star), gradients included.
 """
+import os
+
 import pytest
 import torch
 
@@ -123,6 +125,34 @@ def test_bin_sort_one_tile_every_size_class(N):
     ws = splat._Workspace(1, N, 16, N, "cuda")
     splat._bin_sort(1, N, xys, depths, radii, 64, 64, ws)
     assert torch.equal(ws.sorted_ids[0, :N].cpu(), ids)
+
+
+def test_long_lists_sort_without_the_big_lds_allocation():
+    """gol_bin_sort used to FAIL when the device would not grant sort_big_kernel its 147 KB of dynamic
+    LDS.  Now the kernel falls back to the compare-exchange network on global memory; GOL_SORT_BIG_NO_LDS=1 takes that path
+    on purpose (a static of the library: own process).  One tile with 6000 and 20000 entries, ids exact against the oracle."""
+    import subprocess
+    import sys
+
+    code = (
+        "import sys, torch\n"
+        "sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "from goliath_amd import splat\n"
+        "from oracle import cref\n"
+        "for N in (6000, 20000):\n"
+        "    g = torch.Generator().manual_seed(3 + N)\n"
+        "    xys = (torch.rand(N, 2, generator=g) * 10 + 3).cuda()\n"
+        "    depths = (torch.rand(N, generator=g) + 1).cuda()\n"
+        "    depths[100:200] = depths[100]\n"
+        "    radii = torch.ones(N, dtype=torch.int32).cuda()\n"
+        "    _, ids, bins = cref.bin_and_sort(xys.cpu(), depths.cpu(), radii.cpu(), torch.ones(N, dtype=torch.int32), 64, 64, 16)\n"
+        "    ws = splat._Workspace(1, N, 16, N, 'cuda')\n"
+        "    splat._bin_sort(1, N, xys, depths, radii, 64, 64, ws)\n"
+        "    assert torch.equal(ws.sorted_ids[0, :N].cpu(), ids), N\n"
+        "print('NO_LDS_OK')\n") % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600,
+                       env=dict(os.environ, GOL_SORT_BIG_NO_LDS="1"))
+    assert r.returncode == 0 and "NO_LDS_OK" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
 
 
 @pytest.mark.parametrize("H,W,N", [(512, 512, 10_000), (100, 77, 1_500)])
