@@ -109,6 +109,9 @@ def _sec_brief(s):
     r = s.get("roofline") or {}
     out = {"value": s.get("value"), "unit": s.get("unit"), "ms_per_step": s.get("ms_per_step"),
            "roofline": {"kernel": r.get("kernel"), "bound": r.get("bound"), "frac": r.get("frac")}}
+    if r.get("limiter") == "valu_issue" and (r.get("valu") or {}).get("issued_frac") is not None:
+        # a VALU-bound kernel: its HBM fraction alone says little -- the issue fraction beside it
+        out["roofline"].update(limiter="valu_issue", valu_issued_frac=r["valu"]["issued_frac"])
     w = s.get("windows") or {}
     if w.get("ms_per_step_median") is not None:
         out["ms_per_step_median"] = w["ms_per_step_median"]
