@@ -35,7 +35,7 @@ def _hip_from_golden(G, tag, n_keep=None):
 
 
 @pytest.mark.parametrize("tag", ["sg_eval", "sg_train", "env_eval"])
-@pytest.mark.parametrize("n_keep", [None, 62, 61])  # 64 Gaussians -> 16-byte path; 62 -> 8-byte; 61 -> scalar
+@pytest.mark.parametrize("n_keep", [None, 62, 61])  # 64 Gaussians -> 16-byte plane loads (N % 4 == 0); 62, 61 -> the scalar-plane path, one / three Gaussians short of a lane's four
 def test_shade_matches_reference_golden(tag, n_keep):
     G = load_golden()
     leaf, out = _hip_from_golden(G, tag, n_keep)
