@@ -169,3 +169,20 @@ def test_emit_writes_the_detail_record_and_one_line(tmp_path, capfd):
     assert json.loads(lines[0])["value"] == float(f"{full['value']:.5g}")
     assert json.load(open(tmp_path / "d" / "bench_detail.json"))["secondary"]["mvp"]["config"]["prims"] == 4096
     assert "bench.py detail:" in err
+
+
+def test_scaling_model_reproduces_its_record(tmp_path):
+    """tools/scaling_model.py on the committed one-GPU measurements (no GPU needed): the expected config-3 curve of DESIGN
+    section 7 -- compute at 8 / 4 / 2 / 1 views per GPU + the xGMI exchange model -- comes out as recorded."""
+    rec = os.path.join(ROOT, "profiles", "r06_scaling_model.json")
+    out = str(tmp_path / "m.json")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "scaling_model.py"), "--from-json", rec, "--out", out],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    want, got = json.load(open(rec)), json.load(open(out))
+    assert [p["n_gpus"] for p in got["predicted"]] == [1, 2, 4, 8]
+    for a, b in zip(want["predicted"], got["predicted"]):
+        assert abs(a["direct_serial"]["views_per_s"] - b["direct_serial"]["views_per_s"]) < 1e-6 * a["direct_serial"]["views_per_s"]
+    p8 = got["predicted"][3]
+    # one view per GPU at N = 8: the exchange over 7 links (direct) is shorter than the compute, over one ring it is not
+    assert p8["direct_serial"]["exchange_ms"] < p8["compute_ms"] < p8["ring_serial"]["exchange_ms"]
